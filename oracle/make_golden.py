@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by importing and RUNNING THE REFERENCE
+(Osilly/dynamic_llava under /root/reference) in the build container.
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+
+The reference cannot travel to the GPU box, so the vectors are committed (inputs are regenerated from
+seeds by oracle/fixtures.py; the files hold the reference's outputs).  The driver loop is the
+reference's own hand-rolled greedy loop (llava/dynamic_eval/bench_test/dynamic_llava_long_text_mem.py:
+310-337) because HF `generate()` does not exist on transformers 5.x models.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+from oracle import fixtures as fx
+from oracle._ref_import import import_reference
+
+SD_SEED = 2  # chosen so that the output-text predictor yields a keep/evict mix (seeds 0,1,3 are one-sided)
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# name -> dict(dtype, sparse overrides, prompts [(n_sys, n_q)], steps, predictor_gain)
+CASES = {
+    "tiny_fp32_b1": dict(dtype="float32", sparse={}, prompts=[(5, 7)], steps=12, gain=1.0),
+    "tiny_fp32_b1_greedy": dict(dtype="float32", sparse={}, prompts=[(5, 7)], steps=12, gain=50.0, greedy=True),
+    "tiny_fp32_b1_gain50": dict(dtype="float32", sparse={}, prompts=[(5, 7)], steps=12, gain=50.0),
+    "tiny_bf16_b1_gain50": dict(dtype="bfloat16", sparse={}, prompts=[(5, 7)], steps=12, gain=50.0),
+    "tiny_bf16_b1_ties": dict(dtype="bfloat16", sparse={}, prompts=[(5, 7)], steps=6, gain=1.0),
+    "tiny_fp16_b1_gain50": dict(dtype="float16", sparse={}, prompts=[(5, 7)], steps=8, gain=50.0),
+    "tiny_fp32_dense": dict(dtype="float32", sparse=dict(vision_keep_rate=1.0, use_text_predictor=False, use_output_text_predictor=False), prompts=[(5, 7)], steps=6, gain=1.0),
+    "tiny_fp32_keep50": dict(dtype="float32", sparse=dict(vision_keep_rate=0.5), prompts=[(3, 11)], steps=8, gain=50.0),
+    "tiny_fp32_benchprompt": dict(dtype="float32", sparse=dict(use_text_predictor=False, use_output_text_predictor=False), prompts=[(1, 1)], steps=4, gain=50.0),
+    "tiny_fp32_b3_same": dict(dtype="float32", sparse={}, prompts=[(5, 7)] * 3, steps=8, gain=50.0),
+}
+
+
+def build_reference_model(dll, cfg, sd, clip, dtype):
+    """Instantiates the reference DynamicLlavaLlamaForCausalLM on `cfg` and loads `sd` + `clip`."""
+    from transformers import CLIPImageProcessor
+
+    rcfg = dll.DynamicLlavaConfig(
+        hidden_size=cfg.hidden_size,
+        intermediate_size=cfg.intermediate_size,
+        num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads,
+        num_key_value_heads=cfg.num_key_value_heads,
+        vocab_size=cfg.vocab_size,
+        max_position_embeddings=cfg.max_position_embeddings,
+        rms_norm_eps=cfg.rms_norm_eps,
+    )
+    rcfg.rope_theta = cfg.rope_theta
+    rcfg.rope_scaling = None
+    rcfg.sparse_config = copy.deepcopy(cfg.sparse_config)
+    rcfg.mm_projector_type = cfg.mm_projector_type
+    rcfg.mm_hidden_size = cfg.mm_hidden_size
+    rcfg.mm_vision_select_layer = cfg.mm_vision_select_layer
+    rcfg.mm_vision_select_feature = cfg.mm_vision_select_feature
+    tmp = tempfile.mkdtemp(prefix="dl_clip_")
+    clip.float().save_pretrained(tmp)
+    CLIPImageProcessor(size={"shortest_edge": cfg.clip["image_size"]}, crop_size=cfg.clip["image_size"]).save_pretrained(tmp)
+    rcfg.mm_vision_tower = tmp
+    model = dll.DynamicLlavaLlamaForCausalLM(rcfg)
+    missing, unexpected = model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+    missing = [m for m in missing if "vision_tower" not in m]
+    assert not missing and not unexpected, (missing, unexpected)
+    vt = model.get_vision_tower()
+    vt.load_model()
+    model = model.to(dtype).eval()
+    return model
+
+
+def run_reference(dll, cfg, sd, clip, dtype, input_ids, images, steps, forced=None):
+    """Greedy loop over reference forward() with hooks capturing layer-`sparse_layer` inputs."""
+    model = build_reference_model(dll, cfg, sd, clip, dtype)
+    cap = {}
+    L = cfg.sparse_config["sparse_layer"]
+
+    def pre(mod, args, kwargs):
+        cap["position_ids"] = kwargs.get("position_ids")
+        cap["text_decision"] = kwargs.get("text_decision")
+
+    model.model.layers[L].register_forward_pre_hook(pre, with_kwargs=True)
+    if hasattr(model.model, "image_score_predictor"):
+        model.model.image_score_predictor.register_forward_hook(lambda m, i, o: cap.__setitem__("vision_logit", o))
+    out = dict(step_logits=[], text_decision=[], len_first=[], len_last=[], kv_len_last=[], kv_len_first=[], ids=[])
+    pkv = None
+    cur = input_ids
+    imgs = images.to(dtype)
+    B = input_ids.shape[0]
+    with torch.inference_mode():
+        img_feat = model.encode_images(imgs)
+        for j in range(steps + 1):
+            cap.clear()
+            o = model(cur, images=imgs if j == 0 else None, past_key_values=pkv)
+            pkv = o.past_key_values
+            logits = o.logits[:, -1, :].float()
+            out["step_logits"].append(logits.numpy().copy())
+            if j == 0:
+                out["prefill_logits_shape"] = np.array(o.logits.shape)
+                out["position_ids"] = cap["position_ids"].numpy().copy()
+                if "vision_logit" in cap:
+                    out["vision_logit"] = cap["vision_logit"].float().numpy().copy()
+            td = cap.get("text_decision")
+            out["text_decision"].append(np.full((B,), -1, dtype=np.int64) if td is None else td[:, 0].long().numpy().copy())
+            out["len_first"].append(pkv[1][0].numpy().copy())
+            out["len_last"].append(pkv[1][-1].numpy().copy())
+            out["kv_len_first"].append(pkv[0][0][0].shape[-2])
+            out["kv_len_last"].append(pkv[0][-1][0].shape[-2])
+            nxt = logits.argmax(dim=-1)
+            out["ids"].append(nxt.numpy().copy())
+            cur = nxt[:, None] if forced is None else forced[j][:, None]
+    res = {k: (np.stack(v) if isinstance(v, list) else v) for k, v in out.items()}
+    res["image_features"] = img_feat.float().numpy()
+    return res
+
+
+def pad_prompts(prompts):
+    n = max(p.shape[0] for p in prompts)
+    assert all(p.shape[0] == n for p in prompts), "golden cases use equal-length rows (reference B>1 + padding is not a supported eval mode)"
+    return torch.stack(prompts)
+
+
+def main():
+    dll = import_reference()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, c in CASES.items():
+        torch.manual_seed(0)
+        dtype = getattr(torch, c["dtype"])
+        cfg = fx.tiny_config(**c["sparse"])
+        sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
+        clip = fx.build_clip(cfg, seed=1)
+        prompts = [fx.make_prompt(cfg, ns, nq, seed=i) for i, (ns, nq) in enumerate(c["prompts"])]
+        input_ids = pad_prompts(prompts)
+        images = fx.make_images(cfg, len(prompts), seed=0)
+        forced = None
+        if not c.get("greedy", False):  # teacher forcing, like the reference's own loop (BLTM:310-337 feeds label ids)
+            forced = fx.make_forced_tokens(cfg, c["steps"] + 1, len(prompts), seed=0)
+        res = run_reference(dll, cfg, sd, clip, dtype, input_ids, images, c["steps"], forced)
+        res["input_ids"] = input_ids.numpy()
+        if forced is not None:
+            res["forced"] = forced.numpy()
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **res)
+        print(name, "ids", res["ids"][:, 0].tolist(), "kv_last", res["kv_len_last"].tolist(), "dec", res["text_decision"][:, 0].tolist())
+
+
+if __name__ == "__main__":
+    sys.exit(main())

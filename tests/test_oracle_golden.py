@@ -1,0 +1,72 @@
+"""CPU: the oracle (oracle/ref_cpu.py) against the committed golden vectors, which were produced by
+running the reference itself (oracle/make_golden.py).  Bit-exact: same torch ops in the same order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle.make_golden import CASES, SD_SEED
+from oracle.ref_cpu import Oracle, topk_keep_index
+
+
+def _run_case(name, golden_dir, tie_break):
+    c = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dtype = getattr(torch, c["dtype"])
+    cfg = fx.tiny_config(**c["sparse"])
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
+    clip = fx.build_clip(cfg, seed=1)
+    o = Oracle(cfg, sd, dtype, clip=clip, tie_break=tie_break)
+    ids = torch.from_numpy(g["input_ids"])
+    B = ids.shape[0]
+    images = fx.make_images(cfg, B, seed=0).to(dtype)
+    forced = torch.from_numpy(g["forced"]) if "forced" in g.files else None
+    pkv, cur = None, ids
+    with torch.no_grad():
+        for j in range(g["step_logits"].shape[0]):
+            logits, pkv = o.forward(cur, images=images if j == 0 else None, past_key_values=pkv)
+            last = logits[:, -1].float().numpy()
+            np.testing.assert_array_equal(last, g["step_logits"][j], err_msg=f"{name} step {j}")
+            if j == 0:
+                assert tuple(logits.shape) == tuple(g["prefill_logits_shape"])
+                np.testing.assert_array_equal(o.records["position_ids"].numpy(), g["position_ids"])
+                if "vision_logit" in g.files:
+                    np.testing.assert_array_equal(o.records["vision_logit"].float().numpy(), g["vision_logit"])
+            td = o.records.get("text_decision")
+            tdn = np.full((B,), -1) if td is None else td[:, 0].long().numpy()
+            np.testing.assert_array_equal(tdn, g["text_decision"][j])
+            np.testing.assert_array_equal(pkv[1][0].numpy(), g["len_first"][j])
+            np.testing.assert_array_equal(pkv[1][-1].numpy(), g["len_last"][j])
+            assert pkv[0][0][0].shape[-2] == g["kv_len_first"][j]
+            assert pkv[0][-1][0].shape[-2] == g["kv_len_last"][j]
+            nxt = logits[:, -1].argmax(-1)
+            np.testing.assert_array_equal(nxt.numpy(), g["ids"][j])
+            cur = nxt[:, None] if forced is None else forced[j][:, None]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_golden(name, golden_dir):
+    # tie_break="torch" calls argsort exactly as the reference does (DML:1902-1908)
+    _run_case(name, golden_dir, "torch")
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CASES) if "ties" not in n])
+def test_pinned_tiebreak_equals_reference_when_no_ties(name, golden_dir):
+    # with distinct boundary scores the pinned (stable) rule must select the same set as the reference
+    _run_case(name, golden_dir, "stable")
+
+
+def test_topk_tie_rule():
+    s = torch.tensor([[0.5, 1.0, 0.5, 0.5, 2.0, 0.5]])
+    assert topk_keep_index(s, 3, "stable").tolist() == [[0, 1, 4]]
+    assert topk_keep_index(s, 4, "stable").tolist() == [[0, 1, 2, 4]]
+    assert topk_keep_index(s, 6, "stable").tolist() == [[0, 1, 2, 3, 4, 5]]
+
+
+def test_dense_keep_rate_one_is_identity(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_fp32_dense.npz"))
+    n = g["position_ids"].shape[1]
+    np.testing.assert_array_equal(g["position_ids"][0], np.arange(n))
+    assert g["kv_len_last"][0] == g["kv_len_first"][0]
