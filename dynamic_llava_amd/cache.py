@@ -1,0 +1,147 @@
+"""KV slab with in-place eviction -- the MI355X-native counterpart of the reference's DynamicCachePlus
+(llava/model/language_model/cache_utils.py:63-320).
+
+Reference behaviour being replaced: per layer per decoded token a whole-cache `torch.cat` re-allocation
+(cache_utils.py:155-160, 243-248), a host sync on `cache_decision[0, 0]` (cache_utils.py:153-154) and, for B > 1, a
+Python loop that slices / zero-pads / stacks rows (cache_utils.py:165-241).
+
+Here: one pre-allocated slab per layer, K and V each [B, n_kv_heads, T_cap, head_dim] (sized for the whole
+generation up front: 288 GB of HBM makes this the cheap option), and two device-resident int32 length vectors --
+only two distinct length vectors exist in the reference's L x [B] `true_cache_length`: layers < sparse_layer (never
+evicted) and layers >= sparse_layer (image tokens dropped at prefill, generated tokens kept only if the
+output-text predictor says so).  A decode token is always written at slot len[b]; keeping it = `len[b] += 1`,
+evicting it = leaving len[b] alone (the slot is overwritten by the next token).  No copies, no host syncs, and
+the whole decode step is hipGraph-capturable.
+
+Legacy view (what the harness indexes, dynamic_llava_long_text_mem.py:337-338):
+    pkv[0][layer][0].shape[-2]  -> (padded) KV length of that layer  == max_b true length
+    pkv[1]                      -> list of L CPU int64 tensors [B]   == true_cache_length
+Both are materialised lazily (they cost a device->host copy, exactly what the caller asked for).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+
+class _LayerViews:
+    def __init__(self, cache: "KVSlabCache"):
+        self._c = cache
+
+    def __len__(self):
+        return self._c.n_layers
+
+    def __getitem__(self, i):
+        c = self._c
+        if i < 0:
+            i += c.n_layers
+        if not 0 <= i < c.n_layers:
+            raise KeyError(f"Cache only has {c.n_layers} layers, attempted to access layer with index {i}")
+        T = c.padded_length(i)
+        return (c.k[i][:, :, :T, :], c.v[i][:, :, :T, :])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class KVSlabCache:
+    def __init__(self, n_layers, sparse_layer, batch, n_kv_heads, head_dim, t_cap, dtype, device):
+        self.n_layers = n_layers
+        self.sparse_layer = sparse_layer
+        self.batch = batch
+        self.n_kv_heads = n_kv_heads
+        self.head_dim = head_dim
+        self.t_cap = int(t_cap)
+        self.dtype = dtype
+        self.device = device
+        # one allocation for all layers: [L, 2, B, nKV, T_cap, d]
+        self.slab = torch.empty((n_layers, 2, batch, n_kv_heads, self.t_cap, head_dim), dtype=dtype, device=device)
+        self.k = [self.slab[i, 0] for i in range(n_layers)]
+        self.v = [self.slab[i, 1] for i in range(n_layers)]
+        # lens[0] = layers < sparse_layer, lens[1] = layers >= sparse_layer
+        self.lens = torch.zeros((2, batch), dtype=torch.int32, device=device)
+        # exact host mirror of lens[0] (advances by one per token for every row) -> capacity checks without a sync
+        self.full_len_host: List[int] = [0] * batch
+        self.seen_tokens = 0
+
+    # ---- which length vector a layer uses ----
+    def group(self, layer_idx: int) -> int:
+        return 0 if layer_idx < self.sparse_layer else 1
+
+    def len_of_layer(self, layer_idx: int) -> torch.Tensor:
+        return self.lens[self.group(layer_idx)]
+
+    @property
+    def len_full(self):
+        return self.lens[0]
+
+    @property
+    def len_sparse(self):
+        return self.lens[1]
+
+    def ensure_capacity(self, extra_tokens: int):
+        """Grow the slab (copy) if max_b full length + extra_tokens would not fit.  Returns True if it grew."""
+        need = max(self.full_len_host) + extra_tokens
+        if need <= self.t_cap:
+            return False
+        new_cap = max(need, int(self.t_cap * 1.5) + 16)
+        new = torch.empty((self.n_layers, 2, self.batch, self.n_kv_heads, new_cap, self.head_dim), dtype=self.dtype, device=self.device)
+        new[:, :, :, :, : self.t_cap, :] = self.slab
+        self.slab = new
+        self.t_cap = new_cap
+        self.k = [self.slab[i, 0] for i in range(self.n_layers)]
+        self.v = [self.slab[i, 1] for i in range(self.n_layers)]
+        return True
+
+    # ---- reference-compatible surface ----
+    def __len__(self):
+        return self.n_layers
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:  # cache_utils.py:272-276 (padded length)
+        return self.padded_length(layer_idx)
+
+    def padded_length(self, layer_idx: int) -> int:
+        if self.group(layer_idx) == 0:
+            return max(self.full_len_host) if self.batch else 0
+        return int(self.lens[1].max().item())  # device -> host copy, only when the caller asks
+
+    @property
+    def true_cache_length(self):  # cache_utils.py:79, L x [B], CPU int64 like the reference (cache_utils.py:148)
+        host = self.lens.to("cpu", torch.int64)
+        return [host[self.group(i)].clone() for i in range(self.n_layers)]
+
+    def to_legacy_cache(self):  # cache_utils.py:295-302
+        return self
+
+    def __getitem__(self, idx):
+        if idx == 0:
+            return _LayerViews(self)
+        if idx == 1:
+            return self.true_cache_length
+        raise IndexError("legacy cache tuple has two entries: (per-layer (K, V), true_cache_length)")
+
+    def __iter__(self):
+        yield self[0]
+        yield self[1]
+
+    # ---- import of a genuine legacy tuple (e.g. produced by the reference / oracle) ----
+    @classmethod
+    def from_legacy_cache(cls, pkv, sparse_layer, t_cap_extra=256, device=None):  # cache_utils.py:304-318
+        layers, lens = pkv[0], pkv[1]
+        L = len(layers)
+        k0 = layers[0][0]
+        B, nKV, _, d = k0.shape
+        device = device or k0.device
+        tmax = max(int(layers[i][0].shape[2]) for i in range(L))
+        c = cls(L, sparse_layer, B, nKV, d, tmax + t_cap_extra, k0.dtype, device)
+        for i in range(L):
+            k, v = layers[i]
+            c.k[i][:, :, : k.shape[2], :] = k.to(device)
+            c.v[i][:, :, : v.shape[2], :] = v.to(device)
+        c.lens[0] = torch.as_tensor(lens[0]).to(device=device, dtype=torch.int32)
+        c.lens[1] = torch.as_tensor(lens[L - 1]).to(device=device, dtype=torch.int32)
+        c.full_len_host = [int(x) for x in torch.as_tensor(lens[0]).tolist()]
+        c.seen_tokens = max(c.full_len_host)
+        return c

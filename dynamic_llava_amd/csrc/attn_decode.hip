@@ -1,0 +1,189 @@
+// F9 (decode) + F11: one query token per row against a ragged, evicted KV slab.
+//
+// HBM-bound (AI ~ 1 flop/byte): the only thing that matters is keeping ~every CU streaming K/V rows
+// with 16-byte loads.  Split-KV: grid = (n_splits, n_heads, B); a 256-thread workgroup owns one
+// contiguous key range of one (row, head).  Inside a wave, D/kVec lanes cooperate on one key
+// (16 lanes x 16 B = one 256-byte K row for D=128 bf16), so a wave-wide load instruction is 4 full
+// rows = 1 KiB fully coalesced.  Each lane group keeps its own online-softmax state (m, l, o[kVec]);
+// groups merge through LDS once per workgroup, splits merge in attn_decode_combine_kernel.
+// Per-row lengths are read from the device (kv_len[b] + extra): no host sync, graph-capturable,
+// and a slot beyond the true length (an evicted token) is simply never read.
+#include "dl_common.h"
+
+namespace dl {
+
+constexpr int kDecThreads = 256;
+constexpr int kDecUnroll = 4;
+
+template <typename T, int D>
+__global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
+    const void* __restrict__ q_, int64_t q_row_stride, const void* __restrict__ k_slab_, const void* __restrict__ v_slab_,
+    int64_t stride_b, int64_t stride_h, const int32_t* __restrict__ kv_len, int extra, float* __restrict__ ws,
+    void* __restrict__ out_, int64_t out_row_stride, int n_rep, float scale) {
+  constexpr int V = Elem<T>::kVec;
+  constexpr int LPK = D / V;          // lanes per key
+  constexpr int KPW = 64 / LPK;       // keys per wave per load instruction
+  constexpr int NG = 4 * KPW;         // lane groups per workgroup
+  constexpr int U = kDecUnroll;
+  using S = typename Elem<T>::storage;
+  __shared__ float sm_m[NG], sm_l[NG];
+  __shared__ float sm_o[NG][D];
+
+  const int split = blockIdx.x, n_splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
+  const int n_heads = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane / LPK, c = (lane % LPK) * V;
+  const int Tn = kv_len[b] + extra;
+  int chunk = (Tn + n_splits - 1) / n_splits;
+  chunk = (chunk + NG - 1) / NG * NG;
+  const int k0 = split * chunk;
+  const int k1 = min(Tn, k0 + chunk);
+
+  float qv[V];
+  load16<T>(reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride + (int64_t)h * D + c, qv);
+  const int kvh = h / n_rep;
+  const S* kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
+  const S* vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
+
+  float m = -INFINITY, l = 0.f, o[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) o[i] = 0.f;
+
+  // keys of this workgroup are dealt round-robin: key = base + (u * 4 + wid) * KPW + g
+  for (int base = k0; base < k1; base += NG * U) {
+    float kx[U][V], vx[U][V];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = base + (u * 4 + wid) * KPW + g;
+      ok[u] = key < k1;
+      const int64_t off = (int64_t)(ok[u] ? key : k0) * D;
+      load16<T>(kb + off, kx[u]);
+      load16<T>(vb + off, vx[u]);
+    }
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) a += qv[i] * kx[u][i];
+#pragma unroll
+      for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
+      s[u] = ok[u] ? a * scale : -INFINITY;
+    }
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) mn = fmaxf(mn, s[u]);
+    if (mn > -INFINITY) {
+      const float alpha = __expf(m - mn);  // m = -inf -> 0
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] *= alpha;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float p = __expf(s[u] - mn);  // masked key: exp(-inf) = 0
+        l += p;
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] += p * vx[u][i];
+      }
+      m = mn;
+    }
+  }
+
+  // merge the NG lane groups of this workgroup
+  const int gg = wid * KPW + g;
+  if ((lane % LPK) == 0) {
+    sm_m[gg] = m;
+    sm_l[gg] = l;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) sm_o[gg][c + i] = o[i];
+  __syncthreads();
+  if (tid < D) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) M = fmaxf(M, sm_m[i]);
+    float L = 0.f, O = 0.f;
+    if (M > -INFINITY) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const float w = __expf(sm_m[i] - M);  // empty group: exp(-inf) = 0
+        L += sm_l[i] * w;
+        O += sm_o[i][tid] * w;
+      }
+    }
+    if (n_splits == 1) {
+      store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + tid, L > 0.f ? O / L : 0.f);
+    } else {
+      float* p = ws + (((int64_t)b * n_heads + h) * n_splits + split) * (D + 2);
+      p[2 + tid] = O;
+      if (tid == 0) {
+        p[0] = M;
+        p[1] = L;
+      }
+    }
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ ws, void* __restrict__ out_,
+                                                                int64_t out_row_stride, int n_splits) {
+  const int h = blockIdx.x, b = blockIdx.y, n_heads = gridDim.x, d = threadIdx.x;
+  const float* p = ws + ((int64_t)b * n_heads + h) * n_splits * (D + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < n_splits; ++s) M = fmaxf(M, p[s * (D + 2)]);
+  float L = 0.f, O = 0.f;
+  if (M > -INFINITY) {
+    for (int s = 0; s < n_splits; ++s) {
+      const float w = __expf(p[s * (D + 2)] - M);
+      L += p[s * (D + 2) + 1] * w;
+      O += p[s * (D + 2) + 2 + d] * w;
+    }
+  }
+  store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + d, L > 0.f ? O / L : 0.f);
+}
+
+template <typename T, int D>
+static int launch_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t stride_b,
+                         int64_t stride_h, const int32_t* kv_len, int extra, void* out, int64_t out_row_stride, void* workspace,
+                         int n_splits, int B, int n_heads, int n_kv_heads, hipStream_t st) {
+  const float scale = 1.0f / sqrtf((float)D);
+  hipLaunchKernelGGL((attn_decode_split_kernel<T, D>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(kDecThreads), 0,
+                     st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,
+                     out_row_stride, n_heads / n_kv_heads, scale);
+  if (n_splits > 1)
+    hipLaunchKernelGGL((attn_decode_combine_kernel<T, D>), dim3((unsigned)n_heads, (unsigned)B), dim3(D), 0, st,
+                       reinterpret_cast<const float*>(workspace), out, out_row_stride, n_splits);
+  return 0;
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" int64_t dl_attn_decode_workspace_bytes(int B, int n_heads, int head_dim, int n_splits) {
+  if (n_splits <= 1) return 0;
+  return (int64_t)B * n_heads * n_splits * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t slab_stride_b,
+                              int64_t slab_stride_h, const int32_t* kv_len, int extra, void* out, int64_t out_row_stride,
+                              void* workspace, int n_splits, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
+                              void* stream) {
+  DL_REQUIRE(q && k_slab && v_slab && kv_len && out, "dl_attn_decode: NULL pointer");
+  DL_REQUIRE(B > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "dl_attn_decode: bad head counts");
+  DL_REQUIRE(n_splits >= 1 && n_splits <= 65535, "dl_attn_decode: bad n_splits=%d", n_splits);
+  DL_REQUIRE(n_splits == 1 || workspace, "dl_attn_decode: workspace required when n_splits > 1");
+  DL_REQUIRE(head_dim == 128 || head_dim == 64, "dl_attn_decode: head_dim=%d unsupported (64 or 128)", head_dim);
+  hipStream_t st = as_stream(stream);
+  DL_DISPATCH_DTYPE(dtype, T, {
+    if (head_dim == 128)
+      launch_decode<T, 128>(q, q_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, extra, out, out_row_stride,
+                            workspace, n_splits, B, n_heads, n_kv_heads, st);
+    else
+      launch_decode<T, 64>(q, q_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, extra, out, out_row_stride,
+                           workspace, n_splits, B, n_heads, n_kv_heads, st);
+  });
+  DL_CHECK_LAUNCH("dl_attn_decode");
+  return DL_OK;
+}

@@ -1,0 +1,280 @@
+// F9 (prefill): packed-varlen self-attention, causal (decoder, DML:1114-1122) or full (VisionPredictor,
+// CTL:164-169).  No [T,T] score matrix, no padding, no mask tensor: raggedness comes from cu_seqlens.
+//
+// f16/bf16: flash-style MFMA kernel.  One 256-thread workgroup = 64 query rows of one (sequence, head),
+// 16 rows per wave; K/V tiles of 64 keys are staged through LDS (K row-major, V transposed so that both
+// MFMA B-operands are 16-byte LDS reads); S = Q K^T and O += P V on v_mfma_f32_16x16x32_{bf16,f16};
+// online softmax in fp32 on the MFMA C layout (row = (lane>>4)*4 + reg, col = lane&15).
+// f32: simple wave-per-query kernel (parity/debug path, exact fp32 arithmetic).
+#include "dl_common.h"
+
+namespace dl {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int kBM = 64, kBN = 64, kPad = 8;
+
+template <typename T, int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
+                                                                 const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
+                                                                 void* __restrict__ out_, int64_t out_rs,
+                                                                 const int32_t* __restrict__ cu, int n_rep, float scale) {
+  using S = uint16_t;
+  constexpr int KS = D / 32;   // MFMA k-steps over the head dim
+  constexpr int DT = D / 16;   // 16-wide output column tiles
+  constexpr int NT = kBN / 16; // 16-key tiles per KV tile
+  constexpr int LDK = D + kPad;
+  constexpr int LDV = kBN + kPad;
+  constexpr int LDP = kBN + kPad;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S* Ks = reinterpret_cast<S*>(smem);   // [kBN][LDK]
+  S* Vt = Ks + kBN * LDK;               // [D][LDV]
+  S* Ps = Vt + D * LDV;                 // [4][16][LDP]
+
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  const int q0 = qt * kBM;
+  if (q0 >= L) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kvh = h / n_rep;
+  const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
+  const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+
+  // Q fragments (A operand): row = lane&15, k = (lane>>4)*8 .. +8
+  uint4 qf[KS];
+  {
+    const int qrow = q0 + w * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = make_uint4(0, 0, 0, 0);
+      if (qrow < L) qf[ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * q_rs + ks * 32 + lg * 8);
+    }
+  }
+  f32x4_t acc_o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc_o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+  }
+  S* Pw = Ps + w * 16 * LDP;
+
+  const int n_tiles = CAUSAL ? min((L + kBN - 1) / kBN, qt + 1) : (L + kBN - 1) / kBN;
+  for (int jt = 0; jt < n_tiles; ++jt) {
+    const int key0 = jt * kBN;
+    // ---- stage K (row-major) and V (transposed) tiles ----
+    constexpr int CPR = D / 8;  // 16-byte chunks per row
+#pragma unroll
+    for (int it = 0; it < (kBN * CPR) / 256; ++it) {
+      const int idx = it * 256 + tid;
+      const int key = idx / CPR, ch = idx % CPR;
+      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
+      if (key0 + key < L) {
+        kv4 = *reinterpret_cast<const uint4*>(kb + (int64_t)(key0 + key) * kv_rs + ch * 8);
+        vv4 = *reinterpret_cast<const uint4*>(vb + (int64_t)(key0 + key) * kv_rs + ch * 8);
+      }
+      *reinterpret_cast<uint4*>(Ks + key * LDK + ch * 8) = kv4;
+      const uint32_t vw[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vt[(ch * 8 + 2 * e) * LDV + key] = (S)(vw[e] & 0xffffu);
+        Vt[(ch * 8 + 2 * e + 1) * LDV + key] = (S)(vw[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T ----
+    f32x4_t acc_s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc_s[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (nt * 16 + lr) * LDK + ks * 32 + lg * 8);
+        acc_s[nt] = mfma16<T>(qf[ks], kf, acc_s[nt]);
+      }
+    }
+    // ---- online softmax on the C layout: row = lg*4 + r, col = nt*16 + lr ----
+    float alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = q0 + w * 16 + lg * 4 + r;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ki = key0 + nt * 16 + lr;
+        float s = acc_s[nt][r] * scale;
+        if (ki >= L || (CAUSAL && ki > qi)) s = -INFINITY;
+        acc_s[nt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mn = fmaxf(m[r], mx);
+      const float ms = mn == -INFINITY ? 0.f : mn;
+      alpha[r] = __expf(m[r] - ms);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float p = __expf(acc_s[nt][r] - ms);
+        acc_s[nt][r] = p;
+        rs += p;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+      l[r] = l[r] * alpha[r] + rs;
+      m[r] = mn;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha[r];
+    // ---- P (C layout) -> LDS -> A layout ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pw[(lg * 4 + r) * LDP + nt * 16 + lr] = Elem<T>::from_f(acc_s[nt][r]);
+    __syncthreads();
+    // ---- O += P V ----
+#pragma unroll
+    for (int ks = 0; ks < kBN / 32; ++ks) {
+      const uint4 pf = *reinterpret_cast<const uint4*>(Pw + lr * LDP + ks * 32 + lg * 8);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(Vt + (dt * 16 + lr) * LDV + ks * 32 + lg * 8);
+        acc_o[dt] = mfma16<T>(pf, vf, acc_o[dt]);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue ----
+  S* ob = reinterpret_cast<S*>(out_) + (int64_t)tok0 * out_rs + (int64_t)h * D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q0 + w * 16 + lg * 4 + r;
+    if (qi < L) {
+      const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) ob[(int64_t)qi * out_rs + dt * 16 + lr] = Elem<T>::from_f(acc_o[dt][r] * inv);
+    }
+  }
+}
+
+// ---- generic path: one wave per query row, lanes over keys (scores) then over dims (output) ----
+template <typename T>
+__global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
+                                                                   const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
+                                                                   void* __restrict__ out_, int64_t out_rs,
+                                                                   const int32_t* __restrict__ cu, int n_rep, float scale, int D,
+                                                                   int causal, int max_len) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);  // [4][D]
+  float* sc = qs + 4 * D;                      // [4][max_len]
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 4 + w;
+  const bool valid = qi < L;  // invalid waves still take part in the barriers
+  const int kvh = h / n_rep;
+  float* myq = qs + w * D;
+  float* mys = sc + (int64_t)w * max_len;
+  if (valid)
+    for (int e = lane; e < D; e += 64) myq[e] = load1<T>(q_, ((int64_t)tok0 + qi) * q_rs + (int64_t)h * D + e);
+  __syncthreads();
+  const int nk = valid ? (causal ? qi + 1 : L) : 0;
+  float mx = -INFINITY;
+  for (int key = lane; key < nk; key += 64) {
+    float a = 0.f;
+    const int64_t off = ((int64_t)tok0 + key) * kv_rs + (int64_t)kvh * D;
+    for (int e = 0; e < D; ++e) a += myq[e] * load1<T>(k_, off + e);
+    a *= scale;
+    mys[key] = a;
+    mx = fmaxf(mx, a);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int key = lane; key < nk; key += 64) {
+    const float p = expf(mys[key] - mx);
+    mys[key] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  if (!valid) return;
+  const float inv = 1.0f / sum;
+  for (int e = lane; e < D; e += 64) {
+    float o = 0.f;
+    for (int key = 0; key < nk; ++key) o += mys[key] * load1<T>(v_, ((int64_t)tok0 + key) * kv_rs + (int64_t)kvh * D + e);
+    store1<T>(out_, ((int64_t)tok0 + qi) * out_rs + (int64_t)h * D + e, o * inv);
+  }
+}
+
+template <typename T, int D>
+static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_rs, int64_t kv_rs, void* out, int64_t out_rs,
+                        const int32_t* cu, int B, int max_seqlen, int n_heads, int n_rep, int causal, hipStream_t st) {
+  const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + 4 * 16 * (kBN + kPad)) * 2;
+  const dim3 grid((unsigned)((max_seqlen + kBM - 1) / kBM), (unsigned)n_heads, (unsigned)B);
+  const float scale = 1.0f / sqrtf((float)D);
+  if (causal)
+    hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, true>), grid, dim3(256), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep,
+                       scale);
+  else
+    hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, false>), grid, dim3(256), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep,
+                       scale);
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" int dl_attn_prefill(const void* q, const void* k, const void* v, int64_t q_row_stride, int64_t kv_row_stride, void* out,
+                               int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen, int n_heads, int n_kv_heads,
+                               int head_dim, int causal, int dtype, void* stream) {
+  DL_REQUIRE(q && k && v && out && cu_seqlens, "dl_attn_prefill: NULL pointer");
+  DL_REQUIRE(B > 0 && max_seqlen >= 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "dl_attn_prefill: bad shape");
+  if (max_seqlen == 0) return DL_OK;
+  hipStream_t st = as_stream(stream);
+  const int n_rep = n_heads / n_kv_heads;
+  if (dtype == DL_F32) {
+    DL_REQUIRE(head_dim > 0 && head_dim <= 256, "dl_attn_prefill: head_dim=%d unsupported for f32", head_dim);
+    DL_REQUIRE(max_seqlen <= 8192, "dl_attn_prefill: f32 path supports max_seqlen <= 8192");
+    const size_t smem = (size_t)(4 * head_dim + 4 * (size_t)max_seqlen) * sizeof(float);
+    hipLaunchKernelGGL((attn_prefill_simple_kernel<f32_t>), dim3((unsigned)((max_seqlen + 3) / 4), (unsigned)n_heads, (unsigned)B),
+                       dim3(256), smem, st, q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, n_rep,
+                       1.0f / sqrtf((float)head_dim), head_dim, causal, max_seqlen);
+  } else if (dtype == DL_F16 || dtype == DL_BF16) {
+    DL_REQUIRE(head_dim == 64 || head_dim == 128, "dl_attn_prefill: head_dim=%d unsupported (64 or 128)", head_dim);
+    DL_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0, "dl_attn_prefill: row strides must be multiples of 8 elements");
+    if (dtype == DL_BF16) {
+      if (head_dim == 128) launch_mfma<bf16_t, 128>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
+      else launch_mfma<bf16_t, 64>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
+    } else {
+      if (head_dim == 128) launch_mfma<f16_t, 128>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
+      else launch_mfma<f16_t, 64>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
+    }
+  } else {
+    set_error("dl_attn_prefill: unsupported dtype %d", dtype);
+    return DL_ERR_ARG;
+  }
+  DL_CHECK_LAUNCH("dl_attn_prefill");
+  return DL_OK;
+}

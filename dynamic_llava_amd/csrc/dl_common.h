@@ -1,0 +1,207 @@
+// Shared device/host helpers for libdynllava_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dynllava.h"
+
+namespace dl {
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define DL_REQUIRE(cond, ...)             \
+  do {                                    \
+    if (!(cond)) {                        \
+      dl::set_error(__VA_ARGS__);         \
+      return DL_ERR_ARG;                  \
+    }                                     \
+  } while (0)
+
+#define DL_CHECK_LAUNCH(name)                                                  \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      dl::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+      return DL_ERR_LAUNCH;                                                    \
+    }                                                                          \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------
+// element types: storage is raw bits; arithmetic is fp32; rounding is round-to-nearest-even,
+// i.e. what torch does when an eager op writes a bf16 / fp16 tensor.
+// ---------------------------------------------------------------------------------------------
+struct f32_t {
+  float v;
+};
+struct f16_t {
+  uint16_t v;
+};
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_float(uint16_t b) {
+  _Float16 h;
+  __builtin_memcpy(&h, &b, 2);
+  return (float)h;
+}
+__device__ __forceinline__ uint16_t float_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;  // v_cvt_f16_f32: RNE
+  uint16_t b;
+  __builtin_memcpy(&b, &h, 2);
+  return b;
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<f32_t> {
+  static constexpr int kBytes = 4;
+  static constexpr int kVec = 4;  // elements per 16-byte access
+  using storage = float;
+  __device__ static __forceinline__ float to_f(float s) { return s; }
+  __device__ static __forceinline__ float from_f(float f) { return f; }
+  __device__ static __forceinline__ float round(float f) { return f; }
+};
+template <>
+struct Elem<f16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
+  using storage = uint16_t;
+  __device__ static __forceinline__ float to_f(uint16_t s) { return f16_bits_to_float(s); }
+  __device__ static __forceinline__ uint16_t from_f(float f) { return float_to_f16_bits(f); }
+  __device__ static __forceinline__ float round(float f) { return f16_bits_to_float(float_to_f16_bits(f)); }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
+  using storage = uint16_t;
+  __device__ static __forceinline__ float to_f(uint16_t s) { return bf16_bits_to_float(s); }
+  __device__ static __forceinline__ uint16_t from_f(float f) { return float_to_bf16_bits(f); }
+  __device__ static __forceinline__ float round(float f) { return bf16_bits_to_float(float_to_bf16_bits(f)); }
+};
+
+// 16-byte vector of elements <-> kVec floats
+template <typename T>
+struct Vec16 {
+  uint4 raw;
+};
+
+template <typename T>
+__device__ __forceinline__ void load16(const void* p, float (&f)[Elem<T>::kVec]) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  if constexpr (Elem<T>::kVec == 4) {
+    f[0] = __uint_as_float(r.x);
+    f[1] = __uint_as_float(r.y);
+    f[2] = __uint_as_float(r.z);
+    f[3] = __uint_as_float(r.w);
+  } else {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = Elem<T>::to_f((uint16_t)(w[i] & 0xffffu));
+      f[2 * i + 1] = Elem<T>::to_f((uint16_t)(w[i] >> 16));
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float (&f)[Elem<T>::kVec]) {
+  uint4 r;
+  if constexpr (Elem<T>::kVec == 4) {
+    r.x = __float_as_uint(f[0]);
+    r.y = __float_as_uint(f[1]);
+    r.z = __float_as_uint(f[2]);
+    r.w = __float_as_uint(f[3]);
+  } else {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)Elem<T>::from_f(f[2 * i]) | ((uint32_t)Elem<T>::from_f(f[2 * i + 1]) << 16);
+    r.x = w[0];
+    r.y = w[1];
+    r.z = w[2];
+    r.w = w[3];
+  }
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void store16(void* p, const float (&f)[Elem<T>::kVec]) {
+  *reinterpret_cast<uint4*>(p) = pack16<T>(f);
+}
+
+template <typename T>
+__device__ __forceinline__ float load1(const void* base, int64_t idx) {
+  return Elem<T>::to_f(reinterpret_cast<const typename Elem<T>::storage*>(base)[idx]);
+}
+template <typename T>
+__device__ __forceinline__ void store1(void* base, int64_t idx, float f) {
+  reinterpret_cast<typename Elem<T>::storage*>(base)[idx] = Elem<T>::from_f(f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a block of NW waves; `red` is LDS scratch of >= NW floats; result broadcast to all threads.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// dtype dispatch on the host
+#define DL_DISPATCH_DTYPE(dtype, T, ...)                 \
+  switch (dtype) {                                       \
+    case DL_F32: {                                       \
+      using T = dl::f32_t;                               \
+      __VA_ARGS__;                                       \
+    } break;                                             \
+    case DL_F16: {                                       \
+      using T = dl::f16_t;                               \
+      __VA_ARGS__;                                       \
+    } break;                                             \
+    case DL_BF16: {                                      \
+      using T = dl::bf16_t;                              \
+      __VA_ARGS__;                                       \
+    } break;                                             \
+    default:                                             \
+      dl::set_error("unsupported dtype %d", (int)dtype); \
+      return DL_ERR_ARG;                                 \
+  }
+
+}  // namespace dl

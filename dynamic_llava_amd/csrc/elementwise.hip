@@ -1,0 +1,197 @@
+// HBM-bound row kernels: RMSNorm (+fused residual add), LayerNorm (+row gather), SiLU*up.
+// One 256-thread workgroup per row, 16-byte accesses, the row cached in registers between the
+// statistics pass and the scale pass (each element is read from HBM exactly once).
+#include "dl_common.h"
+
+namespace dl {
+
+constexpr int kThreads = 256;
+constexpr int kMaxVecPerThread = 8;  // H <= 256 * 8 * kVec  (16384 for 2-byte types, 8192 for fp32)
+
+// ---- RMSNorm: DML:134-139.  ADD: h = cast(h + delta) first (DML:1289/1295), written back. ----
+template <typename T, bool ADD>
+__global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_, const void* __restrict__ delta_,
+                                                            const void* __restrict__ w_, void* __restrict__ out_, int H,
+                                                            float eps) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  S* h = reinterpret_cast<S*>(h_) + row * H;
+  const S* delta = ADD ? reinterpret_cast<const S*>(delta_) + row * H : nullptr;
+  const int nvec = H / V;
+  float x[kMaxVecPerThread][V];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = threadIdx.x + i * kThreads;
+    if (v < nvec) {
+      load16<T>(h + v * V, x[i]);
+      if constexpr (ADD) {
+        float d[V];
+        load16<T>(delta + v * V, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
+        store16<T>(h + v * V, x[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) ss += x[i][j] * x[i][j];
+    }
+  }
+  if (w_ == nullptr) return;  // residual add only
+  const float tot = block_sum<4>(ss, red);
+  const float rstd = rsqrtf(tot / (float)H + eps);
+  const S* w = reinterpret_cast<const S*>(w_);
+  S* out = reinterpret_cast<S*>(out_) + row * H;
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = threadIdx.x + i * kThreads;
+    if (v < nvec) {
+      float wv[V], o[V];
+      load16<T>(w + v * V, wv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = wv[j] * Elem<T>::round(x[i][j] * rstd);  // cast, THEN weight
+      store16<T>(out + v * V, o);
+    }
+  }
+}
+
+// ---- nn.LayerNorm over the last dim (predictors: DML:1325,1375; CTL:293,308), optional row gather ----
+template <typename T>
+__global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* __restrict__ x_, const int32_t* __restrict__ row_index,
+                                                              const void* __restrict__ w_, const void* __restrict__ b_,
+                                                              void* __restrict__ out_, int H, float eps) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int64_t src = row_index ? (int64_t)row_index[row] : row;
+  const S* xr = reinterpret_cast<const S*>(x_) + src * H;
+  const int nvec = H / V;
+  float x[kMaxVecPerThread][V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = threadIdx.x + i * kThreads;
+    if (v < nvec) {
+      load16<T>(xr + v * V, x[i]);
+#pragma unroll
+      for (int j = 0; j < V; ++j) s += x[i][j];
+    }
+  }
+  const float mean = block_sum<4>(s, red) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = threadIdx.x + i * kThreads;
+    if (v < nvec) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float d = x[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(block_sum<4>(q, red) / (float)H + eps);
+  const S* w = reinterpret_cast<const S*>(w_);
+  const S* b = reinterpret_cast<const S*>(b_);
+  S* out = reinterpret_cast<S*>(out_) + row * H;
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = threadIdx.x + i * kThreads;
+    if (v < nvec) {
+      float wv[V], bv[V], o[V];
+      load16<T>(w + v * V, wv);
+      load16<T>(b + v * V, bv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = (x[i][j] - mean) * rstd * wv[j] + bv[j];
+      store16<T>(out + v * V, o);
+    }
+  }
+}
+
+// ---- act_fn(gate) * up, DML:328 (two roundings: after silu, after the product) ----
+template <typename T>
+__global__ __launch_bounds__(kThreads) void silu_mul_kernel(const void* __restrict__ gu_, void* __restrict__ out_, int64_t rows,
+                                                             int I) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  const S* gu = reinterpret_cast<const S*>(gu_);
+  S* out = reinterpret_cast<S*>(out_);
+  const int vec_per_row = I / V;
+  const int64_t total = rows * vec_per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = idx / vec_per_row;
+    const int c = (int)(idx - r * vec_per_row) * V;
+    float g[V], u[V], o[V];
+    load16<T>(gu + r * 2 * I + c, g);
+    load16<T>(gu + r * 2 * I + I + c, u);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float sg = Elem<T>::round(g[j] / (1.0f + expf(-g[j])));
+      o[j] = sg * u[j];
+    }
+    store16<T>(out + r * I + c, o);
+  }
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" int dl_rmsnorm(const void* x, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream) {
+  DL_REQUIRE(x && w && out, "dl_rmsnorm: NULL pointer");
+  DL_REQUIRE(rows >= 0 && H > 0, "dl_rmsnorm: bad shape rows=%lld H=%d", (long long)rows, H);
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_rmsnorm: unsupported H=%d", H);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, false>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), const_cast<void*>(x),
+                       nullptr, w, out, H, eps);
+  });
+  DL_CHECK_LAUNCH("dl_rmsnorm");
+  return DL_OK;
+}
+
+extern "C" int dl_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t rows, int H, float eps, int dtype,
+                              void* stream) {
+  DL_REQUIRE(h && delta, "dl_add_rmsnorm: NULL pointer");
+  DL_REQUIRE((w == nullptr) == (out == nullptr), "dl_add_rmsnorm: w and out must both be given or both be NULL");
+  DL_REQUIRE(rows >= 0 && H > 0, "dl_add_rmsnorm: bad shape");
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm: unsupported H=%d", H);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, true>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, delta, w, out, H,
+                       eps);
+  });
+  DL_CHECK_LAUNCH("dl_add_rmsnorm");
+  return DL_OK;
+}
+
+extern "C" int dl_layernorm(const void* x, const int32_t* row_index, const void* w, const void* b, void* out, int64_t rows, int H,
+                            float eps, int dtype, void* stream) {
+  DL_REQUIRE(x && w && b && out, "dl_layernorm: NULL pointer");
+  DL_REQUIRE(rows >= 0 && H > 0, "dl_layernorm: bad shape");
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_layernorm: unsupported H=%d", H);
+    hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), x, row_index, w, b, out, H,
+                       eps);
+  });
+  DL_CHECK_LAUNCH("dl_layernorm");
+  return DL_OK;
+}
+
+extern "C" int dl_silu_mul(const void* gate_up, void* out, int64_t rows, int I, int dtype, void* stream) {
+  DL_REQUIRE(gate_up && out, "dl_silu_mul: NULL pointer");
+  DL_REQUIRE(rows >= 0 && I > 0, "dl_silu_mul: bad shape");
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(I % Elem<T>::kVec == 0, "dl_silu_mul: I=%d must be a multiple of %d", I, Elem<T>::kVec);
+    const int64_t total = rows * (I / Elem<T>::kVec);
+    const int64_t blocks = (total + kThreads - 1) / kThreads;
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+    hipLaunchKernelGGL((silu_mul_kernel<T>), dim3(grid), dim3(kThreads), 0, as_stream(stream), gate_up, out, rows, I);
+  });
+  DL_CHECK_LAUNCH("dl_silu_mul");
+  return DL_OK;
+}

@@ -1,0 +1,107 @@
+// RoPE (DML:253-285) fused with the KV-slab append (CU:109-268): one pass over the freshly projected
+// q|k|v rows -- q,k rotated in place, rotated k and v stored into the per-layer slab at
+// slot kv_base[b] + j.  HBM-bound: every element is read once and written once (k, v twice).
+#include "dl_common.h"
+
+namespace dl {
+
+constexpr int kRopeThreads = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
+    void* __restrict__ qkv_, const void* __restrict__ cos_, const void* __restrict__ sin_, int n_pos,
+    const int32_t* __restrict__ cu, const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_base,
+    const int32_t* __restrict__ kv_base, void* __restrict__ k_slab_, void* __restrict__ v_slab_, int64_t stride_b,
+    int64_t stride_h, int T_cap, int B, int nH, int nKV, int d) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  __shared__ int sh[3];
+  const int t = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = B;  // find b with cu[b] <= t < cu[b+1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int j = t - cu[lo];
+    int p = pos ? pos[t] : pos_base[lo] + j;
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    sh[0] = lo;
+    sh[1] = p;
+    sh[2] = kv_base[lo] + j;
+  }
+  __syncthreads();
+  const int b = sh[0], p = sh[1], slot = sh[2];
+  const int row_w = (nH + 2 * nKV) * d;
+  S* row = reinterpret_cast<S*>(qkv_) + (int64_t)t * row_w;
+  const S* cosr = reinterpret_cast<const S*>(cos_) + (int64_t)p * d;
+  const S* sinr = reinterpret_cast<const S*>(sin_) + (int64_t)p * d;
+  S* k_slab = reinterpret_cast<S*>(k_slab_);
+  S* v_slab = reinterpret_cast<S*>(v_slab_);
+  const bool store_ok = slot >= 0 && slot < T_cap;
+  const int half = d / 2;
+  const int cph = half / V;                 // rotation chunks per head
+  const int n_rot = (nH + nKV) * cph;       // q heads then k heads
+  const int cpv = d / V;
+  const int n_cpy = nKV * cpv;
+  const int items = n_rot + n_cpy;
+  for (int it = blockIdx.y * kRopeThreads + threadIdx.x; it < items; it += gridDim.y * kRopeThreads) {
+    if (it < n_rot) {
+      const int h = it / cph, c = (it - h * cph) * V;
+      S* x = row + h * d;
+      float x1[V], x2[V], cs[V], sn[V], o1[V], o2[V];
+      load16<T>(x + c, x1);
+      load16<T>(x + half + c, x2);
+      load16<T>(cosr + c, cs);  // table = cat(freqs, freqs): second half equals the first
+      load16<T>(sinr + c, sn);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        // q_embed = (q * cos) + (rotate_half(q) * sin), each op rounded to the model dtype (DML:283-284)
+        o1[i] = Elem<T>::round(Elem<T>::round(x1[i] * cs[i]) + Elem<T>::round(-x2[i] * sn[i]));
+        o2[i] = Elem<T>::round(Elem<T>::round(x2[i] * cs[i]) + Elem<T>::round(x1[i] * sn[i]));
+      }
+      const uint4 p1 = pack16<T>(o1), p2 = pack16<T>(o2);
+      *reinterpret_cast<uint4*>(x + c) = p1;
+      *reinterpret_cast<uint4*>(x + half + c) = p2;
+      if (h >= nH && store_ok) {
+        S* dst = k_slab + (int64_t)b * stride_b + (int64_t)(h - nH) * stride_h + (int64_t)slot * d;
+        *reinterpret_cast<uint4*>(dst + c) = p1;
+        *reinterpret_cast<uint4*>(dst + half + c) = p2;
+      }
+    } else if (store_ok) {
+      const int iv = it - n_rot;
+      const int h = iv / cpv, c = (iv - h * cpv) * V;
+      const uint4 val = *reinterpret_cast<const uint4*>(row + (nH + nKV + h) * d + c);
+      S* dst = v_slab + (int64_t)b * stride_b + (int64_t)h * stride_h + (int64_t)slot * d;
+      *reinterpret_cast<uint4*>(dst + c) = val;
+    }
+  }
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* cu_seqlens,
+                                const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base, void* k_slab, void* v_slab,
+                                int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, int B, int total, int n_heads,
+                                int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(qkv && cos_tab && sin_tab && cu_seqlens && kv_base && k_slab && v_slab, "dl_rope_kv_write: NULL pointer");
+  DL_REQUIRE(pos || pos_base, "dl_rope_kv_write: one of pos / pos_base is required");
+  DL_REQUIRE(B > 0 && total >= 0 && n_heads > 0 && n_kv_heads > 0 && n_pos > 0, "dl_rope_kv_write: bad shape");
+  if (total == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(head_dim > 0 && (head_dim / 2) % Elem<T>::kVec == 0, "dl_rope_kv_write: head_dim=%d unsupported", head_dim);
+    const int items = (n_heads + n_kv_heads) * (head_dim / 2 / Elem<T>::kVec) + n_kv_heads * (head_dim / Elem<T>::kVec);
+    int gy = 1;
+    if (total < 256) {  // decode: spread one token's heads over several workgroups
+      gy = (items + kRopeThreads - 1) / kRopeThreads;
+      if (gy > 8) gy = 8;
+    }
+    hipLaunchKernelGGL((rope_kv_write_kernel<T>), dim3((unsigned)total, (unsigned)gy), dim3(kRopeThreads), 0, as_stream(stream), qkv,
+                       cos_tab, sin_tab, n_pos, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, slab_stride_b, slab_stride_h,
+                       T_cap, B, n_heads, n_kv_heads, head_dim);
+  });
+  DL_CHECK_LAUNCH("dl_rope_kv_write");
+  return DL_OK;
+}

@@ -1,0 +1,122 @@
+// F2: order-preserving top-k select (DML:1898-1908) and F3/F4: token compaction + position ids
+// (DML:1917-1983).  Integer results -> bit-exact against the oracle.
+//
+// top-k: one workgroup per row.  Scores become order-preserving uint32 keys in LDS; each element's
+// rank under the pinned total order (score descending, then index ascending) is counted against all
+// keys (LDS broadcast reads); rank < k survives.  Survivors are emitted in index order with a
+// wavefront ballot + cross-wave prefix (no sort, no atomics => deterministic).
+#include "dl_common.h"
+
+namespace dl {
+
+constexpr int kTopkMaxN = 4096;
+
+__device__ __forceinline__ uint32_t order_key(float f) {
+  // monotone map float -> uint32 (larger float => larger key); NaN sorts as the largest (torch.sort rule)
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+  if (u == 0x80000000u) u = 0;  // -0.0 == +0.0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <typename T>
+__global__ void topk_select_kernel(const void* __restrict__ score_, int64_t* __restrict__ keep, int n, int k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);             // [n_pad]
+  int* wave_cnt = reinterpret_cast<int*>(keys + ((n + 3) & ~3));  // [n_waves]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  for (int i = tid; i < n; i += blockDim.x) keys[i] = order_key(load1<T>(score_, (int64_t)b * n + i));
+  __syncthreads();
+  int base = 0;  // survivors emitted by earlier passes
+  const int passes = (n + blockDim.x - 1) / blockDim.x;
+  for (int p = 0; p < passes; ++p) {
+    const int i = p * blockDim.x + tid;
+    bool kept = false;
+    if (i < n) {
+      const uint32_t me = keys[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const uint32_t o = keys[j];
+        rank += (o > me) || (o == me && j < i);
+      }
+      kept = rank < k;
+    }
+    const unsigned long long m = __ballot(kept);
+    if (lane == 0) wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = base, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+      const int c = wave_cnt[w];
+      if (w < wid) off += c;
+      tot += c;
+    }
+    if (kept) keep[(int64_t)b * k + off + __popcll(m & ((1ull << lane) - 1ull))] = (int64_t)i;
+    base += tot;
+    __syncthreads();
+  }
+}
+
+// one workgroup per OUTPUT token: binary-search its row, map to the source token, copy H elements.
+template <typename T>
+__global__ __launch_bounds__(256) void compact_tokens_kernel(const void* __restrict__ in_, void* __restrict__ out_,
+                                                              const int64_t* __restrict__ keep, const int32_t* __restrict__ cu_in,
+                                                              const int32_t* __restrict__ cu_out, const int32_t* __restrict__ img_start,
+                                                              int32_t* __restrict__ pos_out, int B, int n_img, int k, int H) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  __shared__ int64_t sh_src;
+  const int t = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cu_out[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int j = t - cu_out[lo];
+    const int s = img_start[lo];
+    int src;  // in-row index in the un-compacted sequence == the token's original position
+    if (j < s) src = j;
+    else if (j < s + k) src = s + (int)keep[(int64_t)lo * k + (j - s)];
+    else src = j + (n_img - k);
+    pos_out[t] = src;
+    sh_src = (int64_t)cu_in[lo] + src;
+  }
+  __syncthreads();
+  const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const S*>(in_) + sh_src * H);
+  uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<S*>(out_) + (int64_t)t * H);
+  for (int v = threadIdx.x; v < H / V; v += 256) dst[v] = src[v];
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" int dl_topk_select(const void* score, int64_t* keep_idx, int B, int n, int k, int dtype, void* stream) {
+  DL_REQUIRE(score && keep_idx, "dl_topk_select: NULL pointer");
+  DL_REQUIRE(B > 0 && n > 0 && n <= kTopkMaxN && k >= 0 && k <= n, "dl_topk_select: bad shape B=%d n=%d k=%d", B, n, k);
+  if (k == 0) return DL_OK;
+  int threads = n <= 64 ? 64 : (n <= 256 ? 256 : 1024);
+  const size_t smem = (size_t)((n + 3) & ~3) * 4 + 16 * 4;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((topk_select_kernel<T>), dim3((unsigned)B), dim3(threads), smem, as_stream(stream), score, keep_idx, n, k);
+  });
+  DL_CHECK_LAUNCH("dl_topk_select");
+  return DL_OK;
+}
+
+extern "C" int dl_compact_tokens(const void* h_in, void* h_out, const int64_t* keep_idx, const int32_t* cu_in, const int32_t* cu_out,
+                                 const int32_t* img_start, int32_t* pos_out, int B, int n_img, int k, int total_out, int H, int dtype,
+                                 void* stream) {
+  DL_REQUIRE(h_in && h_out && cu_in && cu_out && img_start && pos_out, "dl_compact_tokens: NULL pointer");
+  DL_REQUIRE(keep_idx || k == 0, "dl_compact_tokens: keep_idx is NULL");
+  DL_REQUIRE(B > 0 && n_img >= 0 && k >= 0 && k <= n_img && total_out >= 0 && H > 0, "dl_compact_tokens: bad shape");
+  if (total_out == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0, "dl_compact_tokens: H=%d must be a multiple of %d", H, Elem<T>::kVec);
+    hipLaunchKernelGGL((compact_tokens_kernel<T>), dim3((unsigned)total_out), dim3(256), 0, as_stream(stream), h_in, h_out, keep_idx,
+                       cu_in, cu_out, img_start, pos_out, B, n_img, k, H);
+  });
+  DL_CHECK_LAUNCH("dl_compact_tokens");
+  return DL_OK;
+}

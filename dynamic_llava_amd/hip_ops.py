@@ -1,0 +1,314 @@
+"""ctypes binding of libdynllava_hip.so (C ABI in include/dynllava.h) for torch tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every op below enqueues hand-written
+HIP kernels on `torch.cuda.current_stream()` through the C ABI with raw `data_ptr()`s.  There is NO
+fallback: if the library is missing or the device is not gfx950 the ops raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdynllava_hip.so")
+
+DL_F32, DL_F16, DL_BF16 = 0, 1, 2
+EPI_GELU, EPI_RESIDUAL = 1, 2
+_DTYPES = {torch.float32: DL_F32, torch.float16: DL_F16, torch.bfloat16: DL_BF16}
+
+
+class HipOpsError(RuntimeError):
+    pass
+
+
+class VpBlock(Structure):
+    _fields_ = [(n, c_void_p) for n in ("norm1_w", "norm1_b", "qkv_w", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VpWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_w", "ln_b", "down_w", "down_b", "out0_w", "out0_b", "out2_w", "out2_b", "out4_w", "out4_b")] + [
+        ("num_layers", c_int),
+        ("blocks", VpBlock * 4),
+    ]
+
+
+class TpWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_w", "ln_b", "l1_w", "l1_b", "l3_w", "l3_b", "l5_w", "l5_b", "l7_w", "l7_b")]
+
+
+# symbol -> (restype, argtypes); must list every function declared in include/dynllava.h
+SIGNATURES = {
+    "dl_version": (c_int, []),
+    "dl_last_error": (c_char_p, []),
+    "dl_device_check": (c_int, []),
+    "dl_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_silu_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dl_rope_kv_write": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    ),
+    "dl_attn_prefill": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    ),
+    "dl_attn_decode_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "dl_attn_decode": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    ),
+    "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_vision_predictor_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dl_vision_predictor": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(VpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    ),
+    "dl_text_predictor_decide": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, POINTER(TpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dl_decode_advance": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen + bind every symbol of the ABI.  Raises HipOpsError when the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise HipOpsError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback for the hot path."
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib():
+    return load_library()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipOpsError("no HIP device visible: dynamic_llava_amd's hot path only runs on an MI355X (gfx950)")
+    if lib().dl_device_check() != 0:
+        raise HipOpsError(lib().dl_last_error().decode())
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HipOpsError(f"{what} failed (rc={rc}): {lib().dl_last_error().decode()}")
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise HipOpsError(f"unsupported dtype {dt}")
+
+
+def _dev(t, *more):
+    if not t.is_cuda:
+        raise HipOpsError("tensor is not on the GPU: the HIP hot path has no CPU fallback")
+    for m in more:
+        if m is not None and not m.is_cuda:
+            raise HipOpsError("tensor is not on the GPU: the HIP hot path has no CPU fallback")
+
+
+# ------------------------------------------------------------------------------------------------
+# thin op wrappers (shapes documented in include/dynllava.h)
+# ------------------------------------------------------------------------------------------------
+def rmsnorm(x, w, eps, out=None):
+    _dev(x, w)
+    assert x.is_contiguous() and x.dtype == w.dtype
+    H = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().dl_rmsnorm(_p(x), _p(w), _p(out), x.numel() // H, H, eps, dtype_code(x.dtype), _stream()), "dl_rmsnorm")
+    return out
+
+
+def add_rmsnorm(h, delta, w, eps, out=None):
+    """h += delta (in place, rounded); returns rmsnorm(h) (or None when w is None)."""
+    _dev(h, delta, w)
+    assert h.is_contiguous() and delta.is_contiguous() and h.shape == delta.shape and h.dtype == delta.dtype
+    H = h.shape[-1]
+    if w is not None and out is None:
+        out = torch.empty_like(h)
+    _check(lib().dl_add_rmsnorm(_p(h), _p(delta), _p(w), _p(out) if w is not None else None, h.numel() // H, H, eps, dtype_code(h.dtype), _stream()), "dl_add_rmsnorm")
+    return out if w is not None else None
+
+
+def silu_mul(gate_up, out=None):
+    _dev(gate_up)
+    assert gate_up.is_contiguous()
+    I = gate_up.shape[-1] // 2
+    rows = gate_up.numel() // (2 * I)
+    out = torch.empty(*gate_up.shape[:-1], I, dtype=gate_up.dtype, device=gate_up.device) if out is None else out
+    _check(lib().dl_silu_mul(_p(gate_up), _p(out), rows, I, dtype_code(gate_up.dtype), _stream()), "dl_silu_mul")
+    return out
+
+
+def rope_kv_write(qkv, cos, sin, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, n_heads, n_kv_heads, head_dim):
+    """qkv [total, (nH+2nKV)*d] rotated in place; k_slab/v_slab [B, nKV, T_cap, d]."""
+    _dev(qkv, cos, sin, cu_seqlens, k_slab, v_slab)
+    assert qkv.is_contiguous() and cos.is_contiguous() and sin.is_contiguous()
+    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
+    B = cu_seqlens.numel() - 1
+    total = qkv.shape[0]
+    _check(
+        lib().dl_rope_kv_write(
+            _p(qkv), _p(cos), _p(sin), cos.shape[0], _p(cu_seqlens), _p(pos), _p(pos_base), _p(kv_base), _p(k_slab), _p(v_slab),
+            k_slab.stride(0), k_slab.stride(1), k_slab.shape[2], B, total, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
+        ),
+        "dl_rope_kv_write",
+    )
+
+
+def attn_prefill(q, k, v, out, cu_seqlens, max_seqlen, n_heads, n_kv_heads, head_dim, causal):
+    """q/k/v: 2-D strided views [total, *] whose row stride is .stride(0); out [total, n_heads*head_dim]."""
+    _dev(q, k, v, out, cu_seqlens)
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and out.stride(1) == 1
+    assert k.stride(0) == v.stride(0)
+    B = cu_seqlens.numel() - 1
+    _check(
+        lib().dl_attn_prefill(
+            _p(q), _p(k), _p(v), q.stride(0), k.stride(0), _p(out), out.stride(0), _p(cu_seqlens), B, int(max_seqlen), n_heads, n_kv_heads,
+            head_dim, 1 if causal else 0, dtype_code(q.dtype), _stream(),
+        ),
+        "dl_attn_prefill",
+    )
+    return out
+
+
+def attn_decode_workspace(B, n_heads, head_dim, n_splits, device):
+    nbytes = lib().dl_attn_decode_workspace_bytes(B, n_heads, head_dim, n_splits)
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
+
+
+def attn_decode(q, k_slab, v_slab, kv_len, extra, out, workspace, n_splits, n_heads, n_kv_heads, head_dim):
+    """q: [B, *] strided view (row stride q.stride(0)); k_slab/v_slab [B, nKV, T_cap, d]; kv_len int32 [B]."""
+    _dev(q, k_slab, v_slab, kv_len, out)
+    assert q.stride(1) == 1 and out.stride(1) == 1 and kv_len.dtype == torch.int32
+    B = q.shape[0]
+    _check(
+        lib().dl_attn_decode(
+            _p(q), q.stride(0), _p(k_slab), _p(v_slab), k_slab.stride(0), k_slab.stride(1), _p(kv_len), int(extra), _p(out), out.stride(0),
+            _p(workspace), int(n_splits), B, n_heads, n_kv_heads, head_dim, dtype_code(q.dtype), _stream(),
+        ),
+        "dl_attn_decode",
+    )
+    return out
+
+
+def topk_select(score, k):
+    _dev(score)
+    assert score.is_contiguous() and score.dim() == 2
+    B, n = score.shape
+    keep = torch.empty((B, k), dtype=torch.int64, device=score.device)
+    _check(lib().dl_topk_select(_p(score), _p(keep), B, n, k, dtype_code(score.dtype), _stream()), "dl_topk_select")
+    return keep
+
+
+def compact_tokens(h_in, keep_idx, cu_in, cu_out, img_start, n_img, k, total_out):
+    _dev(h_in, keep_idx, cu_in, cu_out, img_start)
+    assert h_in.is_contiguous()
+    H = h_in.shape[-1]
+    B = cu_in.numel() - 1
+    h_out = torch.empty((total_out, H), dtype=h_in.dtype, device=h_in.device)
+    pos = torch.empty((total_out,), dtype=torch.int32, device=h_in.device)
+    _check(
+        lib().dl_compact_tokens(_p(h_in), _p(h_out), _p(keep_idx), _p(cu_in), _p(cu_out), _p(img_start), _p(pos), B, n_img, k, total_out, H, dtype_code(h_in.dtype), _stream()),
+        "dl_compact_tokens",
+    )
+    return h_out, pos
+
+
+def linear(a, w, bias=None, flags=0, residual=None, out=None):
+    _dev(a, w, bias, residual)
+    assert a.dim() == 2 and a.stride(1) == 1 and w.is_contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=a.dtype, device=a.device) if out is None else out
+    _check(
+        lib().dl_linear(_p(a), a.stride(0), _p(w), _p(bias), _p(out), out.stride(0), _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, flags, dtype_code(a.dtype), _stream()),
+        "dl_linear",
+    )
+    return out
+
+
+def layernorm(x, w, b, eps=1e-5, row_index=None, rows=None):
+    _dev(x, w, b, row_index)
+    assert x.is_contiguous()
+    H = x.shape[-1]
+    rows = (x.numel() // H) if rows is None else rows
+    out = torch.empty((rows, H), dtype=x.dtype, device=x.device)
+    _check(lib().dl_layernorm(_p(x), _p(row_index), _p(w), _p(b), _p(out), rows, H, eps, dtype_code(x.dtype), _stream()), "dl_layernorm")
+    return out
+
+
+def vision_predictor(hidden, cu_seqlens, img_start, n_img, weights: VpWeights, d_model, nhead, dim_ff, workspace=None):
+    """hidden packed [total,H] -> (logits [B,n_img,2], score [B,n_img]) in the model dtype."""
+    _dev(hidden, cu_seqlens, img_start)
+    assert hidden.is_contiguous()
+    B = cu_seqlens.numel() - 1
+    H = hidden.shape[-1]
+    dc = dtype_code(hidden.dtype)
+    if workspace is None:
+        nbytes = lib().dl_vision_predictor_workspace_bytes(B, n_img, H, d_model, dim_ff, dc)
+        workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=hidden.device)
+    logits = torch.empty((B, n_img, 2), dtype=hidden.dtype, device=hidden.device)
+    score = torch.empty((B, n_img), dtype=hidden.dtype, device=hidden.device)
+    _check(
+        lib().dl_vision_predictor(_p(hidden), _p(cu_seqlens), _p(img_start), B, n_img, H, d_model, nhead, dim_ff, ctypes.byref(weights), _p(workspace), _p(logits), _p(score), dc, _stream()),
+        "dl_vision_predictor",
+    )
+    return logits, score
+
+
+def text_predictor_decide(x, weights: TpWeights, d_model, workspace, logits_out, decision):
+    """x [B,H] (row stride x.stride(0)) -> decision int32 [B] (1 = keep this token's KV), logits fp32 [B,2]."""
+    _dev(x, workspace, decision)
+    assert x.stride(1) == 1 and decision.dtype == torch.int32
+    B, H = x.shape
+    _check(
+        lib().dl_text_predictor_decide(_p(x), x.stride(0), B, H, d_model, ctypes.byref(weights), _p(workspace), _p(logits_out), _p(decision), dtype_code(x.dtype), _stream()),
+        "dl_text_predictor_decide",
+    )
+    return decision
+
+
+def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos_id=-1, pad_id=0, kv_len_full=None, kv_len_sparse=None, decision=None):
+    _dev(logits, next_ids)
+    assert logits.dim() == 2 and logits.stride(1) == 1 and next_ids.dtype == torch.int64
+    B, V = logits.shape
+    out_cap = out_ids.shape[1] if out_ids is not None else 0
+    _check(
+        lib().dl_decode_advance(
+            _p(logits), dtype_code(logits.dtype), logits.stride(0), V, B, _p(next_ids), _p(out_ids), out_cap, _p(step), _p(finished), int(eos_id), int(pad_id),
+            _p(kv_len_full), _p(kv_len_sparse), _p(decision), _stream(),
+        ),
+        "dl_decode_advance",
+    )
+    return next_ids

@@ -1,0 +1,756 @@
+"""Host side of the MI355X-native Dynamic-LLaVA hot path: same API surface as the reference's
+`DynamicLlavaLlamaForCausalLM` (llava/model/language_model/dynamic_llava_llama.py:50-169), different engine.
+
+What stays on PyTorch-ROCm (per BASELINE.json north_star): CLIP ViT-L/14-336 + mm_projector, the embedding
+lookup and the dense decoder GEMMs (fused QKV, O, fused gate|up, down, lm_head -> hipBLASLt/MFMA).
+Everything else on the path is a hand-written HIP kernel behind the C ABI (include/dynllava.h):
+RMSNorm(+residual), RoPE+KV append, varlen prefill attention, ragged split-KV decode attention, SiLU*up,
+vision predictor, top-k select, token compaction, text predictor + eviction decision, greedy/advance.
+
+Design (not a translation of the reference's op sequence):
+  * activations are PACKED varlen [total_tokens, H] + cu_seqlens, never padded [B, N, H];
+  * after layer `sparse_layer` the packed batch is physically compacted (k image tokens per row survive);
+  * KV lives in a pre-allocated slab with device-side per-row lengths (cache.py); eviction = "do not
+    advance the length"; the decode step has zero host syncs and is captured in a hipGraph;
+  * all prefill shapes are host-known (k is constant per row), so prefill has no device->host sync either
+    apart from reading `input_ids` (which the harness hands over on the GPU).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops as ops
+from .cache import KVSlabCache
+from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, DynamicLlavaConfig
+
+USER_IDS = [11889, 29901]  # "USER:" -- llava/model/dynamic_llava_arch.py:36
+
+
+@dataclass
+class CausalLMOutputWithPast:
+    """Mirror of transformers.modeling_outputs.CausalLMOutputWithPast (fields the harness reads)."""
+
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[KVSlabCache] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+
+    def __getitem__(self, i):
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values) if v is not None)[i]
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers: same module tree / state-dict keys as the reference, so checkpoints load
+# ------------------------------------------------------------------------------------------------
+class _Attn(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        H, d = cfg.hidden_size, cfg.head_dim
+        self.q_proj = nn.Linear(H, cfg.num_attention_heads * d, bias=False)
+        self.k_proj = nn.Linear(H, cfg.num_key_value_heads * d, bias=False)
+        self.v_proj = nn.Linear(H, cfg.num_key_value_heads * d, bias=False)
+        self.o_proj = nn.Linear(cfg.num_attention_heads * d, H, bias=False)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+
+class _Norm(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+
+
+class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-1234
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_attn = _Attn(cfg)
+        self.mlp = _Mlp(cfg)
+        self.input_layernorm = _Norm(cfg.hidden_size)
+        self.post_attention_layernorm = _Norm(cfg.hidden_size)
+        self.w_qkv = None  # fused [nH*d + 2*nKV*d, H]; q/k/v_proj.weight become views of it (no extra memory)
+        self.w_gu = None  # fused [2*I, H]
+
+    def pack(self):
+        a, m = self.self_attn, self.mlp
+        self.w_qkv = torch.cat([a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data], dim=0).contiguous()
+        nq, nk = a.q_proj.weight.shape[0], a.k_proj.weight.shape[0]
+        a.q_proj.weight.data = self.w_qkv[:nq]
+        a.k_proj.weight.data = self.w_qkv[nq : nq + nk]
+        a.v_proj.weight.data = self.w_qkv[nq + nk :]
+        self.w_gu = torch.cat([m.gate_proj.weight.data, m.up_proj.weight.data], dim=0).contiguous()
+        I = m.gate_proj.weight.shape[0]
+        m.gate_proj.weight.data = self.w_gu[:I]
+        m.up_proj.weight.data = self.w_gu[I:]
+
+
+class _TransformerBlock(nn.Module):  # custom_transformer_layer.py:276-318 (parameters only)
+    def __init__(self, dim, ff):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = nn.Module()
+        self.attn.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.attn.proj = nn.Linear(dim, dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(dim, ff)
+        self.mlp.fc2 = nn.Linear(ff, dim)
+
+
+class VisionPredictor(nn.Module):
+    """dynamic_modeling_llama.py:1308-1359.  forward(x [B,n,H], image_policy) -> logits [B,n,2], computed by
+    the HIP pipeline (dl_vision_predictor).  Hookable like the reference module (visualize.py:74)."""
+
+    def __init__(self, input_dim=4096, d_model=512, nhead=8, dim_feedforward=2048, num_layers=2):
+        super().__init__()
+        self.input_dim, self.d_model, self.nhead, self.dim_feedforward, self.num_layers = input_dim, d_model, nhead, dim_feedforward, num_layers
+        self.down_mlp = nn.Sequential(nn.LayerNorm(input_dim), nn.Linear(input_dim, d_model), nn.GELU())
+        self.transformer = nn.Sequential(*[_TransformerBlock(d_model, dim_feedforward) for _ in range(num_layers)])
+        self.output_mlp = nn.Sequential(
+            nn.Linear(d_model, d_model // 2), nn.GELU(), nn.Linear(d_model // 2, d_model // 4), nn.GELU(), nn.Linear(d_model // 4, 2)
+        )
+        self._w = None
+        self.last_score = None
+
+    def _weights(self):
+        key = self.down_mlp[1].weight.data_ptr()
+        if self._w is None or self._w[0] != key:
+            w = ops.VpWeights()
+            dp = lambda t: t.data_ptr()
+            w.ln_w, w.ln_b = dp(self.down_mlp[0].weight), dp(self.down_mlp[0].bias)
+            w.down_w, w.down_b = dp(self.down_mlp[1].weight), dp(self.down_mlp[1].bias)
+            w.out0_w, w.out0_b = dp(self.output_mlp[0].weight), dp(self.output_mlp[0].bias)
+            w.out2_w, w.out2_b = dp(self.output_mlp[2].weight), dp(self.output_mlp[2].bias)
+            w.out4_w, w.out4_b = dp(self.output_mlp[4].weight), dp(self.output_mlp[4].bias)
+            w.num_layers = self.num_layers
+            for j, blk in enumerate(self.transformer):
+                b = w.blocks[j]
+                b.norm1_w, b.norm1_b = dp(blk.norm1.weight), dp(blk.norm1.bias)
+                b.qkv_w = dp(blk.attn.qkv.weight)
+                b.proj_w, b.proj_b = dp(blk.attn.proj.weight), dp(blk.attn.proj.bias)
+                b.norm2_w, b.norm2_b = dp(blk.norm2.weight), dp(blk.norm2.bias)
+                b.fc1_w, b.fc1_b = dp(blk.mlp.fc1.weight), dp(blk.mlp.fc1.bias)
+                b.fc2_w, b.fc2_b = dp(blk.mlp.fc2.weight), dp(blk.mlp.fc2.bias)
+            self._w = (key, w)
+        return self._w[1]
+
+    def score_packed(self, hidden, cu_seqlens, img_start, n_img):
+        """packed hidden [total,H] -> (logits [B,n,2], score [B,n]); image rows gathered inside the LN kernel."""
+        return ops.vision_predictor(hidden, cu_seqlens, img_start, n_img, self._weights(), self.d_model, self.nhead, self.dim_feedforward)
+
+    def forward(self, x, image_policy=None):
+        B, n, H = x.shape
+        x = x.contiguous().view(B * n, H)
+        cu = torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device=x.device)
+        start = torch.zeros(B, dtype=torch.int32, device=x.device)
+        logits, self.last_score = self.score_packed(x, cu, start, n)
+        return logits
+
+
+class TextPredictor(nn.Module):
+    """dynamic_modeling_llama.py:1362-1387 (parameters) + the decision of DML:2388-2391 (dl_text_predictor_decide)."""
+
+    def __init__(self, input_dim=4096, d_model=512, **_):
+        super().__init__()
+        self.input_dim, self.d_model = input_dim, d_model
+        self.output_mlp = nn.Sequential(
+            nn.LayerNorm(input_dim), nn.Linear(input_dim, d_model), nn.GELU(), nn.Linear(d_model, d_model // 2), nn.GELU(),
+            nn.Linear(d_model // 2, d_model // 4), nn.GELU(), nn.Linear(d_model // 4, 2),
+        )
+        self._w = None
+
+    def _weights(self):
+        key = self.output_mlp[1].weight.data_ptr()
+        if self._w is None or self._w[0] != key:
+            w = ops.TpWeights()
+            m = self.output_mlp
+            w.ln_w, w.ln_b = m[0].weight.data_ptr(), m[0].bias.data_ptr()
+            w.l1_w, w.l1_b = m[1].weight.data_ptr(), m[1].bias.data_ptr()
+            w.l3_w, w.l3_b = m[3].weight.data_ptr(), m[3].bias.data_ptr()
+            w.l5_w, w.l5_b = m[5].weight.data_ptr(), m[5].bias.data_ptr()
+            w.l7_w, w.l7_b = m[7].weight.data_ptr(), m[7].bias.data_ptr()
+            self._w = (key, w)
+        return self._w[1]
+
+    def decide(self, x, workspace, logits_out, decision):
+        return ops.text_predictor_decide(x, self._weights(), self.d_model, workspace, logits_out, decision)
+
+    def forward(self, x):
+        """x [..., H] -> logits [..., 2] (fp32 values of the model-dtype logits)."""
+        shp = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        B = x2.shape[0]
+        ws = torch.empty(B * self.d_model, dtype=torch.float32, device=x.device)
+        lg = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+        dec = torch.empty(B, dtype=torch.int32, device=x.device)
+        self.decide(x2, ws, lg, dec)
+        return lg.to(x.dtype).reshape(*shp, 2)
+
+
+class CLIPVisionTower(nn.Module):
+    """llava/model/multimodal_encoder/clip_encoder.py:7-102 -- stays on PyTorch-ROCm (north_star)."""
+
+    def __init__(self, cfg: DynamicLlavaConfig):
+        super().__init__()
+        from transformers import CLIPVisionConfig, CLIPVisionModel
+
+        self.select_layer = cfg.mm_vision_select_layer
+        self.select_feature = cfg.mm_vision_select_feature
+        self.vision_tower_name = cfg.mm_vision_tower
+        c = cfg.clip
+        self.vision_tower = CLIPVisionModel(
+            CLIPVisionConfig(
+                hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
+                num_attention_heads=c["num_attention_heads"], image_size=c["image_size"], patch_size=c["patch_size"], projection_dim=c["hidden_size"],
+            )
+        )
+        self.vision_tower.requires_grad_(False)
+        self.is_loaded = True
+
+    @torch.no_grad()
+    def forward(self, images):
+        out = self.vision_tower(images.to(device=self.device, dtype=self.dtype), output_hidden_states=True)
+        f = out.hidden_states[self.select_layer]
+        if self.select_feature == "patch":
+            f = f[:, 1:]
+        elif self.select_feature != "cls_patch":
+            raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        return f.to(images.dtype) if images.is_floating_point() else f
+
+    @property
+    def dtype(self):
+        return next(self.vision_tower.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.vision_tower.parameters()).device
+
+    @property
+    def config(self):
+        return self.vision_tower.config
+
+    @property
+    def hidden_size(self):
+        return self.config.hidden_size
+
+    @property
+    def num_patches(self):
+        return (self.config.image_size // self.config.patch_size) ** 2
+
+
+class DynamicLlavaLlamaModel(nn.Module):
+    """Parameter tree of dynamic_modeling_llama.py:1586-1647 + dynamic_llava_arch.py:41-51."""
+
+    def __init__(self, cfg: DynamicLlavaConfig, with_vision_tower=True):
+        super().__init__()
+        self.config = cfg
+        sc = cfg.sparse_config
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([DynamicLlamaDecoderLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.norm = _Norm(cfg.hidden_size)
+        kw = dict(input_dim=cfg.hidden_size, d_model=sc["d_model"], nhead=sc["nhead"], dim_feedforward=sc["dim_feedforward"], num_layers=sc["num_layers"])
+        if sc["use_vision_predictor"]:
+            self.image_score_predictor = VisionPredictor(**kw)
+        if sc["use_text_predictor"]:
+            if sc["use_output_text_predictor"]:
+                self.output_text_score_predictor = TextPredictor(**kw)
+            if sc["use_instruct_predictor"]:
+                self.instruct_score_predictor = TextPredictor(**kw)
+        if with_vision_tower:
+            self.vision_tower = CLIPVisionTower(cfg)
+        if cfg.mm_projector_type != "mlp2x_gelu":
+            raise NotImplementedError("only the LLaVA-1.5 mlp2x_gelu projector is built (multimodal_projector/builder.py:172-179)")
+        self.mm_projector = nn.Sequential(nn.Linear(cfg.mm_hidden_size, cfg.hidden_size), nn.GELU(), nn.Linear(cfg.hidden_size, cfg.hidden_size))
+
+    def get_vision_tower(self):
+        return getattr(self, "vision_tower", None)
+
+
+# ------------------------------------------------------------------------------------------------
+# decode-step state (persistent device buffers: stable pointers for the hipGraph)
+# ------------------------------------------------------------------------------------------------
+class _DecodeState:
+    def __init__(self, model, B, device, dtype, out_cap):
+        cfg = model.config
+        H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.B = B
+        self.cur_ids = torch.zeros(B, dtype=torch.int64, device=device)
+        self.out_ids = torch.zeros((B, max(out_cap, 1)), dtype=torch.int64, device=device)
+        self.step = torch.zeros(B, dtype=torch.int32, device=device)
+        self.finished = torch.zeros(B, dtype=torch.int32, device=device)
+        self.decision = torch.ones(B, dtype=torch.int32, device=device)
+        self.tp_logits = torch.zeros((B, 2), dtype=torch.float32, device=device)
+        self.tp_ws = torch.empty(B * cfg.sparse_config["d_model"], dtype=torch.float32, device=device)
+        self.cu = torch.arange(0, B + 1, dtype=torch.int32, device=device)
+        self.h = torch.empty((B, H), dtype=dtype, device=device)
+        self.x = torch.empty((B, H), dtype=dtype, device=device)
+        self.attn = torch.empty((B, nH * d), dtype=dtype, device=device)
+        self.act = torch.empty((B, I), dtype=dtype, device=device)
+        self.logits = torch.empty((B, V), dtype=dtype, device=device)
+        # split-KV: enough workgroups to cover the chip (256 CUs) without drowning in partials
+        self.n_splits = max(1, min(32, 1024 // max(1, B * nH)))
+        self.attn_ws = ops.attn_decode_workspace(B, nH, d, self.n_splits, device)
+        self.graph = None
+        self.graph_key = None
+
+
+class DynamicLlavaLlamaForCausalLM(nn.Module):
+    """Drop-in for the reference class of the same name (dynamic_llava_llama.py:50-169)."""
+
+    def __init__(self, config: DynamicLlavaConfig, with_vision_tower=True):
+        super().__init__()
+        self.config = config
+        self.model = DynamicLlavaLlamaModel(config, with_vision_tower)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self._packed = False
+        self._rope = None
+        self._dstate = None
+        self.use_hip_graph = True
+        self.debug_records = None  # dict filled by forward passes when set to {} (tests)
+        self.eval()
+
+    # ---- reference surface -----------------------------------------------------------------
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.model.get_vision_tower()
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    @property
+    def dtype(self):
+        return self.lm_head.weight.dtype
+
+    def encode_images(self, images):  # dynamic_llava_arch.py:163-166
+        f = self.get_vision_tower()(images)
+        return self.model.mm_projector(f.to(self.dtype))
+
+    def finalize(self):
+        """Call once after weights are loaded / moved: fuses QKV and gate|up, builds the RoPE table."""
+        ops.require_gpu()
+        if self.device.type != "cuda":
+            raise ops.HipOpsError("the model must live on the GPU (no CPU path exists)")
+        for l in self.model.layers:
+            l.pack()
+        self._packed = True
+        self._build_rope(self.config.max_position_embeddings)
+        self._dstate = None
+        return self
+
+    def _build_rope(self, n_pos):
+        """dynamic_modeling_llama.py:152-174,181-184: fp32 cos/sin of cat(freqs, freqs), rounded to the model dtype."""
+        d, dev = self.config.head_dim, self.device
+        inv_freq = 1.0 / (self.config.rope_theta ** (torch.arange(0, d, 2, device=dev).float() / d))
+        t = torch.arange(n_pos, device=dev, dtype=torch.float32)
+        emb = torch.cat((torch.outer(t, inv_freq),) * 2, dim=-1)
+        self._rope = (emb.cos().to(self.dtype).contiguous(), emb.sin().to(self.dtype).contiguous())
+
+    def _rope_tables(self, need):
+        if self._rope is None or self._rope[0].shape[0] < need:
+            self._build_rope(max(need, self.config.max_position_embeddings))
+            self._dstate = None  # table pointers changed -> re-capture
+        return self._rope
+
+    # ---- multimodal glue (dynamic_llava_arch.py:169-601) ---------------------------------------
+    def _segments(self, ids_row: List[int], labels_row: Optional[List[int]], n_img_feat: int):
+        """Host-side restatement of ARCH:330-340, 418-489 for one row (exactly one image)."""
+        img_pos = ids_row.index(IMAGE_TOKEN_INDEX)
+        n = len(ids_row)
+        if labels_row is None:
+            ans0 = n
+        else:
+            ans0 = max(i for i, v in enumerate(labels_row) if v == IGNORE_INDEX) + 1
+        ins = ids_row[img_pos + 1 : ans0]
+        starts = [i for i in range(len(ins) - len(USER_IDS) + 1) if ins[i : i + len(USER_IDS)] == USER_IDS]
+        last = starts[-1] if starts else 0
+        s = img_pos
+        i0 = s + n_img_feat
+        a0 = i0 + (ans0 - img_pos - 1)
+        tot = a0 + (n - ans0)
+        return {"system": [0, s], "image": [s, i0], "instruct": [i0, a0], "answer": [a0, tot], "last_instruct": [i0 + last, a0]}
+
+    def _prepare_packed(self, input_ids, attention_mask, labels, images, image_features=None):
+        """-> (packed embeds [total,H], lens [B], indices list[dict] or None)."""
+        ids_host = input_ids.detach().to("cpu")
+        if attention_mask is not None:
+            am = attention_mask.detach().to("cpu").bool()
+            rows = [ids_host[b][am[b]].tolist() for b in range(ids_host.shape[0])]
+            lab_rows = None if labels is None else [labels[b].detach().to("cpu")[am[b]].tolist() for b in range(ids_host.shape[0])]
+        else:
+            rows = [r.tolist() for r in ids_host]
+            lab_rows = None if labels is None else [r.tolist() for r in labels.detach().to("cpu")]
+        B = len(rows)
+        if image_features is None:
+            if type(images) is list or images.ndim == 5:
+                raise NotImplementedError("anyres / multi-image lists are not on the LLaVA-1.5 Dynamic-LLaVA path")
+            image_features = self.encode_images(images)  # [n_images, n_img, H]
+        n_feat = image_features.shape[1]
+        dev = self.device
+        pieces, lens, indices = [], [], []
+        img_i = 0
+        for b in range(B):
+            r = rows[b]
+            n_images = r.count(IMAGE_TOKEN_INDEX)
+            if n_images == 0:  # ARCH:315-324: text-only row consumes (and ignores) one image feature
+                pieces.append(self.model.embed_tokens(torch.tensor(r, dtype=torch.long, device=dev)))
+                lens.append(len(r))
+                indices.append(None)
+                img_i += 1
+                continue
+            if n_images != 1:
+                raise NotImplementedError("exactly one <image> per row (ARCH:330-332 calls .item() on the position)")
+            seg = self._segments(r, None if lab_rows is None else lab_rows[b], n_feat)
+            p = seg["system"][1]
+            txt = self.model.embed_tokens(torch.tensor(r[:p] + r[p + 1 :], dtype=torch.long, device=dev))
+            pieces += [txt[:p], image_features[img_i].to(self.dtype), txt[p:]]
+            img_i += 1
+            lens.append(len(r) - 1 + n_feat)
+            indices.append(seg)
+        embeds = torch.cat(pieces, dim=0).contiguous()
+        maxlen = getattr(self.config, "tokenizer_model_max_length", None)
+        if maxlen is not None and max(lens) > maxlen:
+            raise NotImplementedError("truncation to tokenizer_model_max_length (ARCH:493-506) is not built")
+        if any(i is None for i in indices):
+            indices = None if all(i is None for i in indices) else indices
+        return embeds, lens, indices
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes=None):
+        """Reference-format wrapper (dynamic_llava_arch.py:169-178, 594-601): right-padded [B,N,H] embeds."""
+        if self.get_vision_tower() is None or images is None or input_ids.shape[1] == 1:
+            return (input_ids, position_ids, attention_mask, past_key_values, None, labels), (None,)
+        embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, labels, images)
+        B, N = len(lens), max(lens)
+        out = embeds.new_zeros((B, N, embeds.shape[-1]))
+        o = 0
+        for b, n in enumerate(lens):
+            out[b, :n] = embeds[o : o + n]
+            o += n
+        new_mask = None
+        if attention_mask is not None:
+            new_mask = torch.zeros((B, N), dtype=attention_mask.dtype, device=attention_mask.device)
+            for b, n in enumerate(lens):
+                new_mask[b, :n] = 1
+        new_pos = None
+        if position_ids is not None:
+            new_pos = torch.zeros((B, N), dtype=position_ids.dtype, device=position_ids.device)
+            for b, n in enumerate(lens):
+                new_pos[b, :n] = torch.arange(n, dtype=position_ids.dtype, device=position_ids.device)
+        new_labels = None
+        if labels is not None:
+            raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
+        return (None, new_pos, new_mask, past_key_values, out, new_labels), (indices,)
+
+    # ---- decoder engine -----------------------------------------------------------------------
+    def _check_ready(self):
+        if not self._packed:
+            raise ops.HipOpsError("call model.finalize() after loading weights (done by the builders)")
+        sc = self.config.sparse_config
+        if sc["use_text_predictor"] and sc["use_instruct_predictor"]:
+            raise NotImplementedError("instruct-predictor branches (DML:2261-2375, 2506-2521) are SURVEY 8f row N2, not built yet")
+
+    def _prefill(self, embeds, lens, indices, cache: Optional[KVSlabCache], reserve: int, last_only: bool):
+        """Packed prefill.  Returns (normed hidden of [last rows | all rows], cache, lens_after)."""
+        cfg, sc = self.config, self.config.sparse_config
+        dev, dt = self.device, self.dtype
+        B = len(lens)
+        nH, nKV, d, H, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
+        eps = cfg.rms_norm_eps
+        L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
+        vision_on = bool(sc["use_vision_predictor"]) and indices is not None and all(i is not None for i in indices)
+        n_img = k = 0
+        if vision_on:
+            n_img = indices[0]["image"][1] - indices[0]["image"][0]
+            if any(i["image"][1] - i["image"][0] != n_img for i in indices):
+                raise NotImplementedError("all images must have the same token count (DML:1774-1778 assumes it too)")
+            k = int(n_img * sc["vision_keep_rate"])  # DML:1899-1901
+        if cache is None:
+            cache = KVSlabCache(L, SL, B, nKV, d, max(lens) + reserve, dt, dev)
+        elif max(cache.full_len_host) != 0:
+            raise NotImplementedError("multi-token forward on a non-empty cache (new-instruct round, DML:2506-2521) is SURVEY 8f row N2")
+        cos, sin = self._rope_tables(max(lens) + reserve)
+        cu_list = [0]
+        for n in lens:
+            cu_list.append(cu_list[-1] + n)
+        cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
+        zeros_b = torch.zeros(B, dtype=torch.int32, device=dev)
+        total, max_len = cu_list[-1], max(lens)
+        pos = None  # layers < SL: position = in-row index
+        h = embeds.to(dt).contiguous()
+        if h.data_ptr() == embeds.data_ptr():
+            h = h.clone()  # the residual stream is updated in place; never touch the caller's tensor
+        rec = self.debug_records
+        x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps)
+        for i, layer in enumerate(self.model.layers):
+            if i == SL and vision_on:
+                # ---- F1..F5: predictor -> top-k -> compaction (DML:1826-1994) on the un-normed residual stream ----
+                img_start = torch.tensor([ix["image"][0] for ix in indices], dtype=torch.int32, device=dev)
+                vp = self.model.image_score_predictor
+                if len(vp._forward_hooks) or len(vp._forward_pre_hooks):  # keep the reference's hook point alive
+                    dense = torch.stack([h[cu_list[b] + indices[b]["image"][0] : cu_list[b] + indices[b]["image"][1]] for b in range(B)])
+                    logits = vp(dense, torch.ones(B, n_img, 1, dtype=dt, device=dev))
+                    score = vp.last_score
+                else:
+                    logits, score = vp.score_packed(h, cu, img_start, n_img)
+                keep = ops.topk_select(score, k)
+                new_lens = [n - (n_img - k) for n in lens]
+                cu2_list = [0]
+                for n in new_lens:
+                    cu2_list.append(cu2_list[-1] + n)
+                cu2 = torch.tensor(cu2_list, dtype=torch.int32, device=dev)
+                h, pos = ops.compact_tokens(h, keep, cu, cu2, img_start, n_img, k, cu2_list[-1])
+                if rec is not None:
+                    rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=cu2)
+                drop = n_img - k
+                for ix in indices:  # DML:1986-1994 -- the reference mutates the caller's dicts too
+                    ix["image"][1] -= drop
+                    for key in ("instruct", "last_instruct", "answer"):
+                        ix[key][0] -= drop
+                        ix[key][1] -= drop
+                lens, cu, cu_list, total, max_len = new_lens, cu2, cu2_list, cu2_list[-1], max(new_lens)
+                x = ops.rmsnorm(h, layer.input_layernorm.weight, eps)
+            qkv = F.linear(x, layer.w_qkv)
+            ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
+            attn = torch.empty((total, nH * d), dtype=dt, device=dev)
+            ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : (nH + nKV) * d], qkv[:, (nH + nKV) * d :], attn, cu, max_len, nH, nKV, d, True)
+            o = F.linear(attn, layer.self_attn.o_proj.weight)
+            x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
+            act = ops.silu_mul(F.linear(x, layer.w_gu))
+            dn = F.linear(act, layer.mlp.down_proj.weight)
+            if i + 1 == L:
+                x = ops.add_rmsnorm(h, dn, self.model.norm.weight, eps)
+            elif i + 1 == SL and vision_on:
+                ops.add_rmsnorm(h, dn, None, eps)  # residual add only: layer SL's norm runs after compaction
+            else:
+                x = ops.add_rmsnorm(h, dn, self.model.layers[i + 1].input_layernorm.weight, eps)
+        # lengths: layers < SL hold the full prompt, layers >= SL the compacted one
+        orig_lens = list(lens) if not vision_on else [n + (n_img - k) for n in lens]
+        cache.lens[0] = torch.tensor(orig_lens, dtype=torch.int32, device=dev)
+        cache.lens[1] = torch.tensor(lens if SL < L else orig_lens, dtype=torch.int32, device=dev)
+        cache.full_len_host = list(orig_lens)
+        cache.seen_tokens = max(orig_lens)
+        if last_only:
+            last_rows = torch.tensor([c - 1 for c in cu_list[1:]], dtype=torch.long, device=dev)
+            x = x.index_select(0, last_rows)
+        return x, cache, lens, cu_list
+
+    # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
+    def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
+        cfg, sc = self.config, self.config.sparse_config
+        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
+        cos, sin = self._rope
+        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
+        torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
+        ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x)
+        for i, layer in enumerate(self.model.layers):
+            if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
+                self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
+            lens = cache.len_of_layer(i)
+            qkv = F.linear(st.x, layer.w_qkv)
+            ops.rope_kv_write(qkv, cos, sin, st.cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
+            ops.attn_decode(qkv[:, : nH * d], cache.k[i], cache.v[i], lens, 1, st.attn, st.attn_ws, st.n_splits, nH, nKV, d)
+            o = F.linear(st.attn, layer.self_attn.o_proj.weight)
+            ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x)
+            ops.silu_mul(F.linear(st.x, layer.w_gu), out=st.act)
+            dn = F.linear(st.act, layer.mlp.down_proj.weight)
+            nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
+            ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
+        torch.matmul(st.x, self.lm_head.weight.t(), out=st.logits)
+        if advance:
+            ops.decode_advance(
+                st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, cache.len_full, cache.len_sparse,
+                st.decision if use_tp else None,
+            )
+
+    def _pooled_cache(self, B, t_need):
+        """generate() owns its cache, so the slab is reused across calls: stable pointers keep the captured hipGraph valid."""
+        cfg = self.config
+        c = getattr(self, "_cache_pool", None)
+        if c is None or c.batch != B or c.t_cap < t_need or c.dtype != self.dtype or c.sparse_layer != cfg.sparse_config["sparse_layer"]:
+            c = KVSlabCache(cfg.num_hidden_layers, cfg.sparse_config["sparse_layer"], B, cfg.num_key_value_heads, cfg.head_dim, t_need, self.dtype, self.device)
+            self._cache_pool = c
+        c.lens.zero_()
+        c.full_len_host = [0] * B
+        c.seen_tokens = 0
+        return c
+
+    def _get_dstate(self, B, out_cap):
+        st = self._dstate
+        if st is None or st.B != B or st.out_ids.shape[1] < out_cap:
+            st = self._dstate = _DecodeState(self, B, self.device, self.dtype, out_cap)
+        return st
+
+    def _run_decode_steps(self, st, cache, n_steps):
+        """Enqueue n greedy steps (graph replay when enabled)."""
+        key = (cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, repr(self.config.sparse_config))
+        if not self.use_hip_graph:
+            for _ in range(n_steps):
+                self._decode_step_kernels(st, cache, True)
+            return
+        if st.graph is None or st.graph_key != key:
+            # warm-up on a side stream (hipBLASLt workspaces, lazy init), restoring the state it clobbers
+            snap = (st.cur_ids.clone(), st.out_ids.clone(), st.step.clone(), st.finished.clone(), cache.lens.clone(), st.decision.clone())
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._decode_step_kernels(st, cache, True)
+            torch.cuda.current_stream().wait_stream(s)
+            st.cur_ids.copy_(snap[0]); st.out_ids.copy_(snap[1]); st.step.copy_(snap[2]); st.finished.copy_(snap[3]); cache.lens.copy_(snap[4]); st.decision.copy_(snap[5])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_step_kernels(st, cache, True)
+            # capture does not execute; state is intact
+            st.graph, st.graph_key = g, key
+        for _ in range(n_steps):
+            st.graph.replay()
+
+    # ---- public API -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+        self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
+        output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None, input_embeds_indices=None,
+        image_features=None,
+    ):
+        """dynamic_llava_llama.py:68-115 + dynamic_modeling_llama.py:2631-2813 (inference; no labels / loss).
+        logits: fp32 [B, N', V] for ALL positions like the reference (DML:2709-2710); rows are right-padded with
+        zeros when their lengths differ."""
+        self._check_ready()
+        if labels is not None:
+            raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused path")
+        if use_cache is False:
+            raise NotImplementedError("use_cache=False (no-KV-cache decode, DML:2393-2504) is SURVEY 8f row N3, not built yet")
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You have to specify either input_ids or inputs_embeds")  # DML:1686-1695
+        cache = past_key_values
+        if cache is not None and not isinstance(cache, KVSlabCache):
+            cache = KVSlabCache.from_legacy_cache(cache, self.config.sparse_config["sparse_layer"], device=self.device)
+        decode = cache is not None and max(cache.full_len_host) > 0
+        if decode:
+            if input_ids is None or input_ids.shape[1] != 1:
+                raise NotImplementedError("multi-token forward on a non-empty cache (DML:2506-2521) is SURVEY 8f row N2")
+            B = input_ids.shape[0]
+            st = self._get_dstate(B, 0)
+            grew = cache.ensure_capacity(2)
+            self._rope_tables(max(cache.full_len_host) + 2)
+            st.cur_ids.copy_(input_ids[:, 0])
+            self._eos, self._pad = -1, 0
+            self._decode_step_kernels(st, cache, False)
+            use_tp = self.config.sparse_config["use_text_predictor"] and self.config.sparse_config["use_output_text_predictor"]
+            cache.lens[0] += 1
+            cache.lens[1] += st.decision if use_tp else 1
+            cache.full_len_host = [n + 1 for n in cache.full_len_host]
+            cache.seen_tokens += 1
+            if self.debug_records is not None:
+                self.debug_records.update(text_decision=st.decision.clone() if use_tp else None, text_logit=st.tp_logits.clone())
+            logits = st.logits.to(torch.float32, copy=True).unsqueeze(1)  # never alias the persistent step buffer
+            return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
+        # ---- prefill ----
+        if inputs_embeds is not None:
+            B, N = inputs_embeds.shape[:2]
+            if attention_mask is not None:
+                lens = attention_mask.sum(dim=1).tolist()
+            else:
+                lens = [N] * B
+            embeds = torch.cat([inputs_embeds[b, : lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
+            indices = input_embeds_indices
+        elif images is None and image_features is None:
+            B = input_ids.shape[0]
+            if attention_mask is not None:
+                lens = attention_mask.sum(dim=1).tolist()
+                embeds = torch.cat([self.model.embed_tokens(input_ids[b, : lens[b]]) for b in range(B)], dim=0)
+            else:
+                lens = [input_ids.shape[1]] * B
+                embeds = self.model.embed_tokens(input_ids.reshape(-1))
+            indices = None
+        else:
+            embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
+        x, cache, lens2, cu_list = self._prefill(embeds, lens, indices, cache, reserve=256, last_only=False)
+        logits_packed = F.linear(x, self.lm_head.weight).float()
+        B = len(lens2)
+        if len(set(lens2)) == 1:
+            logits = logits_packed.view(B, lens2[0], -1)
+        else:
+            logits = logits_packed.new_zeros((B, max(lens2), logits_packed.shape[-1]))
+            for b in range(B):
+                logits[b, : lens2[b]] = logits_packed[cu_list[b] : cu_list[b + 1]]
+        return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
+
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, image_sizes=None, **kwargs):
+        """dynamic_llava_llama.py:117-152: greedy decoding; returns the NEW tokens only [B, T_new] (HF behaviour when
+        generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens, min_new_tokens, do_sample(False),
+        num_beams(1), use_cache(True), eos_token_id, pad_token_id, attention_mask, return_dict_in_generate,
+        image_features (pre-computed projector output, testing)."""
+        self._check_ready()
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
+        if kwargs.get("do_sample", False) or (kwargs.get("temperature") or 0) > 0 and kwargs.get("do_sample", False):
+            raise NotImplementedError("sampling is not built; the eval harness uses temperature 0 / greedy (model_vqa_loader.py:162-175)")
+        if kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is not built (harness default num_beams=1)")
+        max_new = kwargs.get("max_new_tokens")
+        if max_new is None:
+            max_new = 20 if kwargs.get("max_length") is None else None
+        min_new = kwargs.get("min_new_tokens", 0) or 0
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        pad = kwargs.get("pad_token_id", self.config.pad_token_id)
+        attention_mask = kwargs.get("attention_mask")
+        sync_every = int(kwargs.get("sync_every", 16))
+        if images is not None or kwargs.get("image_features") is not None:
+            embeds, lens, indices = self._prepare_packed(inputs, attention_mask, None, images, kwargs.get("image_features"))
+        else:
+            B = inputs.shape[0]
+            lens = [inputs.shape[1]] * B if attention_mask is None else attention_mask.sum(dim=1).tolist()
+            embeds = torch.cat([self.model.embed_tokens(inputs[b, : lens[b]]) for b in range(B)], dim=0)
+            indices = None
+        if max_new is None:
+            max_new = kwargs["max_length"] - max(lens)
+        B = len(lens)
+        x, cache, _, _ = self._prefill(embeds, lens, indices, self._pooled_cache(B, max(lens) + max_new + 1), reserve=max_new + 1, last_only=True)
+        st = self._get_dstate(B, max_new)
+        st.step.zero_(); st.finished.zero_(); st.decision.fill_(1)
+        self._eos = -1 if eos is None else int(eos)
+        self._pad = 0 if pad is None else int(pad)
+        torch.matmul(x, self.lm_head.weight.t(), out=st.logits)
+        self.last_prefill_logits = st.logits.to(torch.float32, copy=True)
+        # first token: argmax only (the prompt's KV lengths are already in place)
+        eos_first = self._eos if min_new <= 0 else -1
+        ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, eos_first, self._pad, None, None, None)
+        produced = 1
+        while produced < max_new:
+            n = min(sync_every, max_new - produced)
+            self._run_decode_steps(st, cache, n)
+            produced += n
+            if self._eos >= 0 and produced < max_new and bool(st.finished.min().item()):
+                break
+        out = st.out_ids[:, :produced].clone()
+        if self._eos >= 0:  # HF stops as soon as every row has emitted EOS: trim the columns produced after that
+            fin = (out == self._eos).int().cumsum(dim=1).clamp(max=1)
+            all_done = fin.min(dim=0).values
+            if bool(all_done.any().item()):
+                first = int(torch.argmax(all_done).item())
+                out = out[:, : first + 1]
+        self.last_cache = cache
+        if kwargs.get("return_dict_in_generate"):
+            return {"sequences": out, "past_key_values": cache}
+        return out

@@ -1,0 +1,159 @@
+/*
+ * dynllava.h -- C ABI of libdynllava_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (Osilly/dynamic_llava) has NO native code: every entry point below replaces a sequence
+ * of eager PyTorch ops on the reference's sparsified prefill+decode hot path.  The reference interface
+ * each one replaces is cited as file:line relative to the reference root, with
+ *   DML  = llava/model/language_model/dynamic_modeling_llama.py
+ *   CU   = llava/model/language_model/cache_utils.py
+ *   CTL  = llava/model/language_model/custom_transformer_layer.py
+ *
+ * Conventions
+ *   - plain device pointers + explicit sizes; no torch / HIP types in signatures (stream is a void*
+ *     holding a hipStream_t; NULL = the default stream).
+ *   - `dtype`: DL_F32 / DL_F16 / DL_BF16 = element type of all "model dtype" buffers of that call.
+ *   - every call only ENQUEUES work on `stream`; it never synchronises, allocates or frees, so all
+ *     calls are hipGraph-capturable.  The caller owns every buffer including workspaces.
+ *   - return value: 0 = enqueued, <0 = DL_ERR_* (nothing was enqueued); dl_last_error() returns a
+ *     thread-local message for the last failing call on this host thread.
+ *   - "packed varlen": B sequences concatenated along the token axis, row b = tokens
+ *     [cu_seqlens[b], cu_seqlens[b+1]); cu_seqlens is int32[B+1] on the device.
+ *   - KV slab layout (one K and one V slab per layer): [B][n_kv_heads][T_cap][head_dim], element
+ *     strides given explicitly (slab_stride_b, slab_stride_h; the key-row stride is head_dim).
+ */
+#ifndef DYNLLAVA_H_
+#define DYNLLAVA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL_F32 0
+#define DL_F16 1
+#define DL_BF16 2
+
+#define DL_OK 0
+#define DL_ERR_ARG (-1)     /* bad argument (NULL pointer, unsupported size / dtype) */
+#define DL_ERR_LAUNCH (-2)  /* hipLaunchKernel failed; see dl_last_error() */
+
+int dl_version(void);               /* ABI version, currently 1 */
+const char* dl_last_error(void);    /* thread-local, never NULL */
+int dl_device_check(void);          /* 0 if the current HIP device is gfx950, else DL_ERR_ARG */
+
+/* ---- F7: LlamaRMSNorm.forward, DML:134-139 ------------------------------------------------
+ * out[r,:] = w * cast(x[r,:] * rsqrt(mean(x[r,:]^2) + eps))   (fp32 statistics; the cast to the
+ * model dtype happens BEFORE the weight multiply, as in the reference).  x,out: [rows, H]. */
+int dl_rmsnorm(const void* x, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream);
+
+/* residual add (DML:1289 / DML:1295) fused with the following RMSNorm (DML:1273 / DML:1293):
+ *   h[r,:] = cast(h[r,:] + delta[r,:])  (written back);  out = rmsnorm(h).  `w`/`out` may be NULL
+ *   to perform only the residual add (last layer). */
+int dl_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream);
+
+/* LlamaMLP activation, DML:328: out[r,i] = cast(cast(silu(g)) * u), g = gate_up[r,i], u = gate_up[r,I+i]. */
+int dl_silu_mul(const void* gate_up, void* out, int64_t rows, int I, int dtype, void* stream);
+
+/* ---- F8 + F10: apply_rotary_pos_emb DML:260-285 (+rotate_half DML:253-257) fused with the KV-cache
+ * append of DynamicCachePlus.update / get_cache, CU:109-268.
+ * qkv: packed [total, (n_heads + 2*n_kv_heads) * head_dim]; q and k are rotated IN PLACE, the rotated
+ * k and the v row are also written into the slab at key index kv_base[b] + j (j = token offset in row b).
+ * Position of token j of row b: pos[cu_seqlens[b] + j] if pos != NULL else pos_base[b] + j.
+ * cos/sin: [n_pos, head_dim] tables in the model dtype (DML:181-184 rounds them to the model dtype).
+ * Writes beyond T_cap are dropped.  Eviction never copies: a decode token is always written at slot
+ * kv_len[b]; whether it stays is decided later by dl_decode_advance (the length simply does not grow). */
+int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_tab, int n_pos,
+                     const int32_t* cu_seqlens, const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base,
+                     void* k_slab, void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap,
+                     int B, int total, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
+
+/* ---- F9 (prefill): F.scaled_dot_product_attention as called at DML:1114-1122 with is_causal=True, and
+ * CTL:164-169 (non-causal, inside VisionPredictor).  Packed varlen self-attention:
+ * q/k/v element (token t, head h, dim e) at base[t*row_stride + h*head_dim + e] (k/v use kv head
+ * h / (n_heads/n_kv_heads)); out[t*out_row_stride + h*head_dim + e].  scale = 1/sqrt(head_dim).
+ * head_dim in {64, 128} (f16/bf16: MFMA path) or any multiple of 4 <= 256 (f32). */
+int dl_attn_prefill(const void* q, const void* k, const void* v, int64_t q_row_stride, int64_t kv_row_stride,
+                    void* out, int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen,
+                    int n_heads, int n_kv_heads, int head_dim, int causal, int dtype, void* stream);
+
+/* ---- F9 (decode) + F11: one query token per row against the ragged KV slab (DML:1061-1122 with
+ * CU:256-268).  Row b attends keys [0, kv_len[b] + extra) of its slab; q: [B, q_row_stride].
+ * Split-KV: `n_splits` workgroups per (row, head); partials in `workspace` (float), merged by a
+ * second kernel.  dl_attn_decode_workspace_bytes gives the required size. */
+int64_t dl_attn_decode_workspace_bytes(int B, int n_heads, int head_dim, int n_splits);
+int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab,
+                   int64_t slab_stride_b, int64_t slab_stride_h, const int32_t* kv_len, int extra,
+                   void* out, int64_t out_row_stride, void* workspace, int n_splits,
+                   int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
+
+/* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
+ * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
+ * (= stable descending sort; the reference's argsort is non-stable).  n <= 4096. */
+int dl_topk_select(const void* score, int64_t* keep_idx, int B, int n, int k, int dtype, void* stream);
+
+/* ---- F3 + F4: token compaction, DML:1917-1983.  Row b of the packed input has an image span
+ * [img_start[b], img_start[b] + n_img); the output row keeps everything outside the span and the
+ * k rows keep_idx[b,:] of it, in order.  pos_out[t] = original in-row index of output token t
+ * (what the reference builds as position_ids).  h_in [total_in,H] -> h_out [total_out,H]. */
+int dl_compact_tokens(const void* h_in, void* h_out, const int64_t* keep_idx, const int32_t* cu_in,
+                      const int32_t* cu_out, const int32_t* img_start, int32_t* pos_out, int B, int n_img, int k,
+                      int total_out, int H, int dtype, void* stream);
+
+/* ---- generic small linear layer used by the predictors: C = epilogue(A @ W^T + bias)
+ * A [M,K] (row stride lda), W [N,K] (nn.Linear layout), bias [N] or NULL, C [M,N] (row stride ldc).
+ * flags: DL_EPI_GELU -> C = gelu_erf(cast(A W^T + b)); DL_EPI_RESIDUAL -> C = cast(R + cast(A W^T + b))
+ * with R [M,N] (row stride ldr; may alias C).  Roundings to the model dtype happen exactly where the
+ * eager reference rounds (after the Linear, after the GELU, after the residual add). K % 8 == 0. */
+#define DL_EPI_GELU 1
+#define DL_EPI_RESIDUAL 2
+int dl_linear(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc,
+              const void* R, int64_t ldr, int M, int N, int K, int flags, int dtype, void* stream);
+
+/* nn.LayerNorm(eps=1e-5) over the last dim, rows gathered through an optional index:
+ * out[r,:] = LN(x[row_index ? row_index[r] : r, :]) * w + b */
+int dl_layernorm(const void* x, const int32_t* row_index, const void* w, const void* b, void* out,
+                 int64_t rows, int H, float eps, int dtype, void* stream);
+
+/* ---- F1: VisionPredictor.forward DML:1348-1359 (+ CTL:153-180, 320-323) followed by
+ * log_softmax(...)[:, :, 0] DML:1867,1898.  All pointers are device pointers to nn.Module parameters
+ * with the reference's state-dict layout (model.image_score_predictor.*). */
+typedef struct dl_vp_block {
+  const void *norm1_w, *norm1_b, *qkv_w, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} dl_vp_block;
+typedef struct dl_vp_weights {
+  const void *ln_w, *ln_b, *down_w, *down_b;      /* down_mlp.0 / down_mlp.1 */
+  const void *out0_w, *out0_b, *out2_w, *out2_b, *out4_w, *out4_b; /* output_mlp.0/.2/.4 */
+  int num_layers;                                  /* <= 4 */
+  dl_vp_block blocks[4];
+} dl_vp_weights;
+int64_t dl_vision_predictor_workspace_bytes(int B, int n_img, int H, int d_model, int dim_ff, int dtype);
+/* hidden: packed [total,H]; image rows of sequence b = cu_seqlens[b] + img_start[b] + [0,n_img).
+ * logits_out [B,n_img,2] and score_out [B,n_img] in the model dtype. */
+int dl_vision_predictor(const void* hidden, const int32_t* cu_seqlens, const int32_t* img_start, int B, int n_img,
+                        int H, int d_model, int nhead, int dim_ff, const dl_vp_weights* w, void* workspace,
+                        void* logits_out, void* score_out, int dtype, void* stream);
+
+/* ---- F6: TextPredictor.forward DML:1385-1387 + decision DML:2388-2391.
+ * x [B,H] (hidden state entering layer `sparse_layer`); logits_out [B,2] float (may be NULL);
+ * decision[b] = logit0 > logit1 (strict, raw logits).  workspace: B*d_model floats. */
+typedef struct dl_tp_weights {
+  const void *ln_w, *ln_b, *l1_w, *l1_b, *l3_w, *l3_b, *l5_w, *l5_b, *l7_w, *l7_b; /* output_mlp.0/1/3/5/7 */
+} dl_tp_weights;
+int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, int d_model, const dl_tp_weights* w,
+                             void* workspace, float* logits_out, int32_t* decision, int dtype, void* stream);
+
+/* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
+ * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;
+ * out_ids[b, step[b]] = next[b]; ++step[b]; kv_len_full[b] += 1; kv_len_sparse[b] += decision ? decision[b] : 1.
+ * logits: [B,V] in `logits_dtype` (DL_F32 or the model dtype).  step/finished: int32[B].  All state lives on
+ * the device; out_ids / step / finished / kv_len_* / decision may be NULL to skip that piece of bookkeeping. */
+int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_stride, int V, int B,
+                      int64_t* next_ids, int64_t* out_ids, int out_cap, int32_t* step, int32_t* finished,
+                      int eos_id, int pad_id, int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNLLAVA_H_ */

@@ -1,0 +1,104 @@
+"""CPU: host logic, C-ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/dynllava.h is exported by the .so and bound in hip_ops.SIGNATURES."""
+    from dynamic_llava_amd import hip_ops
+
+    hdr = open(os.path.join(ROOT, "include", "dynllava.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dl_[a-z0-9_]+)\s*\(", hdr)) - {"dl_vp_block", "dl_vp_weights", "dl_tp_weights"}
+    assert declared == set(hip_ops.SIGNATURES), declared ^ set(hip_ops.SIGNATURES)
+    lib = hip_ops.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.dl_version() == 1
+    assert isinstance(lib.dl_last_error(), bytes)
+    # workspace-size queries are pure host functions
+    assert lib.dl_attn_decode_workspace_bytes(2, 32, 128, 8) == 2 * 32 * 8 * 130 * 4
+    assert lib.dl_attn_decode_workspace_bytes(2, 32, 128, 1) == 0
+    assert lib.dl_vision_predictor_workspace_bytes(1, 576, 4096, 512, 2048, 2) > 576 * 4096 * 2
+
+
+def test_struct_layouts_match_header():
+    from dynamic_llava_amd import hip_ops
+
+    assert ctypes.sizeof(hip_ops.VpBlock) == 11 * 8
+    assert ctypes.sizeof(hip_ops.VpWeights) == 10 * 8 + 8 + 4 * 11 * 8
+    assert ctypes.sizeof(hip_ops.TpWeights) == 10 * 8
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_hot_path_fails_loudly_without_gpu():
+    from dynamic_llava_amd import hip_ops
+    from dynamic_llava_amd.builder import build_random_model, load_pretrained_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    with pytest.raises(hip_ops.HipOpsError):
+        hip_ops.require_gpu()
+    with pytest.raises(hip_ops.HipOpsError):
+        hip_ops.rmsnorm(torch.zeros(2, 128), torch.ones(128), 1e-5)
+    with pytest.raises(hip_ops.HipOpsError):
+        build_random_model(DynamicLlavaConfig(num_hidden_layers=1), device="cuda")
+    with pytest.raises(hip_ops.HipOpsError):
+        load_pretrained_model("/nonexistent", None, "x", device="cpu")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under dynamic_llava_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "dynamic_llava_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_config_roundtrip_and_state_dict_keys(tmp_path):
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+    from dynamic_llava_amd.model import DynamicLlavaLlamaForCausalLM
+    from oracle import fixtures as fx
+
+    ns = fx.tiny_config()
+    cfg = DynamicLlavaConfig.from_namespace(ns)
+    cfg.save_pretrained(str(tmp_path))
+    cfg2 = DynamicLlavaConfig.from_pretrained(str(tmp_path))
+    assert cfg2.to_dict() == cfg.to_dict() and cfg2.sparse_config["sparse_layer"] == 2 and cfg2.n_image_tokens == 36
+    m = DynamicLlavaLlamaForCausalLM(cfg)
+    own = {k for k in m.state_dict() if "vision_tower" not in k}
+    ref = set(fx.make_state_dict(ns, seed=0))  # the reference's key names (checked against the reference in oracle/make_golden.py)
+    assert own == ref
+    # fused QKV / gate|up must stay views of the original parameters (state_dict round-trips, no extra memory)
+    l = m.model.layers[0]
+    l.pack()
+    assert l.self_attn.k_proj.weight.data_ptr() == l.w_qkv[256:].data_ptr()
+    assert torch.equal(m.state_dict()["model.layers.0.mlp.up_proj.weight"], l.w_gu[512:])
+
+
+def test_segment_indices_match_oracle():
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+    from dynamic_llava_amd.model import DynamicLlavaLlamaForCausalLM
+    from oracle import fixtures as fx
+    from oracle.ref_cpu import Oracle
+
+    ns = fx.tiny_config()
+    ns.vocab_size = 30000  # "USER:" = ids 11889, 29901 (dynamic_llava_arch.py:36)
+    m = DynamicLlavaLlamaForCausalLM(DynamicLlavaConfig.from_namespace(ns), with_vision_tower=False)
+    o = Oracle(ns, fx.make_state_dict(ns, seed=0), torch.float32)
+    ids = [1, 5, 6, -200, 9, 11889, 29901, 7, 8, 11889, 29901, 4, 3]
+    feats = torch.zeros(1, 36, 256)
+    (_, _, _, _, emb, _), (idx,) = o.prepare_inputs_labels_for_multimodal(torch.tensor([ids]), None, None, None, None, None, image_features=feats)
+    seg = m._segments(ids, None, 36)
+    assert seg == idx[0] and emb.shape[1] == seg["answer"][1]
+    labels = [-100] * 9 + [5] * 4
+    (_, _, _, _, _, _), (idx2,) = o.prepare_inputs_labels_for_multimodal(torch.tensor([ids]), None, None, None, torch.tensor([labels]), None, image_features=feats)
+    assert m._segments(ids, labels, 36) == idx2[0]

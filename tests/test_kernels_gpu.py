@@ -1,0 +1,367 @@
+"""GPU parity tests, kernel level: every C-ABI entry point (through ctypes, on a real MI355X) against the
+oracle's primitive of the same name or a plain fp32 PyTorch evaluation of the same formula.
+
+Tolerances: integer / index / copy results are bit-exact.  Element-wise kernels that reproduce the eager
+reference's rounding points are required to match the oracle evaluated in the SAME dtype to within one
+unit in the last place of that dtype (fp32 statistics may differ in the last bit).  Attention / GEMM
+kernels are compared against an fp32 evaluation of the same rounded inputs with an absolute+relative bound
+stated at each test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as fx  # noqa: E402
+from oracle import ref_cpu as orc  # noqa: E402
+
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+ULP = {torch.float32: 2.0**-23, torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dynamic_llava_amd import hip_ops
+
+    hip_ops.require_gpu()
+    return hip_ops
+
+
+def _close_ulp(a, b, dtype, n_ulp=1.0, atol=0.0):
+    if dtype == torch.float32:
+        n_ulp = max(n_ulp, 8.0)  # fp32: rsqrt / summation-order differences of a few ulp; 16-bit results absorb them
+    a, b = a.float().cpu(), b.float().cpu()
+    tol = n_ulp * ULP[dtype] * torch.maximum(a.abs(), b.abs()) + atol
+    bad = (a - b).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} / {a.numel()} elements differ by more than {n_ulp} ulp; max abs diff {float((a - b).abs().max())}"
+
+
+def _frac_exact(a, b, dtype=None):
+    if dtype == torch.float32:
+        return 1.0  # exact-match fractions are only meaningful after rounding to a 16-bit dtype
+    return float((a.float().cpu() == b.float().cpu()).float().mean())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,H", [(1, 4096), (37, 4096), (5, 256), (3, 5120)])
+def test_rmsnorm(ops, dtype, rows, H):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(rows, H, generator=g) * 3).to(dtype)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
+    ref = orc.rmsnorm(x, w, 1e-5)
+    out = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5)
+    _close_ulp(out, ref, dtype, 1.0)
+    assert _frac_exact(out, ref, dtype) > 0.99
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_rmsnorm(ops, dtype):
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(19, 4096, generator=g).to(dtype)
+    d = torch.randn(19, 4096, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(4096, generator=g)).to(dtype)
+    hh = h.cuda().clone()
+    out = ops.add_rmsnorm(hh, d.cuda(), w.cuda(), 1e-5)
+    ref_h = h + d
+    assert torch.equal(hh.cpu(), ref_h), "residual add must be bit-exact"
+    _close_ulp(out, orc.rmsnorm(ref_h, w, 1e-5), dtype, 1.0)
+    hh2 = h.cuda().clone()
+    assert ops.add_rmsnorm(hh2, d.cuda(), None, 1e-5) is None
+    assert torch.equal(hh2.cpu(), ref_h)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_silu_mul(ops, dtype):
+    g = torch.Generator().manual_seed(2)
+    gu = (torch.randn(7, 2 * 11008, generator=g) * 2).to(dtype)
+    ref = F.silu(gu[:, :11008]) * gu[:, 11008:]
+    out = ops.silu_mul(gu.cuda())
+    _close_ulp(out, ref, dtype, 1.0, atol=1e-30)
+    assert _frac_exact(out, ref, dtype) > 0.98
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_gather(ops, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(50, 4096, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(4096, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(4096, generator=g)).to(dtype)
+    idx = torch.tensor([3, 49, 0, 17, 17], dtype=torch.int32)
+    ref = F.layer_norm(x[idx.long()], (4096,), w, b, 1e-5)
+    out = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5, row_index=idx.cuda(), rows=5)
+    _close_ulp(out, ref, dtype, 1.0, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nH,nKV,d", [(32, 32, 128), (8, 2, 128), (2, 2, 64)])
+def test_rope_kv_write_bit_exact(ops, dtype, nH, nKV, d):
+    """RoPE reproduces the eager op's three roundings (DML:283-284) => bit-exact vs the oracle in every dtype."""
+    g = torch.Generator().manual_seed(4)
+    lens = [5, 1, 9]
+    B, total, T_cap = len(lens), sum(lens), 16
+    cu = torch.tensor([0, 5, 6, 15], dtype=torch.int32)
+    qkv = torch.randn(total, (nH + 2 * nKV) * d, generator=g).to(dtype)
+    pos = torch.randint(0, 700, (total,), generator=g, dtype=torch.int32)
+    kv_base = torch.tensor([2, 0, 4], dtype=torch.int32)
+    cos, sin = orc.rope_table(d, 1024, 10000.0, dtype)
+    k_slab = torch.zeros(B, nKV, T_cap, d, dtype=dtype, device="cuda")
+    v_slab = torch.zeros_like(k_slab)
+    q_dev = qkv.cuda().clone()
+    ops.rope_kv_write(q_dev, cos.cuda(), sin.cuda(), cu.cuda(), pos.cuda(), None, kv_base.cuda(), k_slab, v_slab, nH, nKV, d)
+    out = q_dev.cpu()
+    q = qkv[:, : nH * d].view(total, nH, d).transpose(0, 1)[None]
+    k = qkv[:, nH * d : (nH + nKV) * d].view(total, nKV, d).transpose(0, 1)[None]
+    v = qkv[:, (nH + nKV) * d :].view(total, nKV, d)
+    qr, kr = orc.apply_rope(q, k, cos, sin, pos.long()[None])
+    assert torch.equal(out[:, : nH * d], qr[0].transpose(0, 1).reshape(total, nH * d))
+    assert torch.equal(out[:, nH * d : (nH + nKV) * d], kr[0].transpose(0, 1).reshape(total, nKV * d))
+    assert torch.equal(out[:, (nH + nKV) * d :], qkv[:, (nH + nKV) * d :])
+    ks, vs = k_slab.cpu(), v_slab.cpu()
+    for b in range(B):
+        for j in range(lens[b]):
+            t = int(cu[b]) + j
+            assert torch.equal(ks[b, :, int(kv_base[b]) + j], kr[0][:, t])
+            assert torch.equal(vs[b, :, int(kv_base[b]) + j], v[t])
+    # pos_base form (decode): position = pos_base[b] + j
+    q2 = qkv.cuda().clone()
+    base = torch.tensor([10, 20, 30], dtype=torch.int32)
+    ops.rope_kv_write(q2, cos.cuda(), sin.cuda(), cu.cuda(), None, base.cuda(), kv_base.cuda(), k_slab, v_slab, nH, nKV, d)
+    pos2 = torch.cat([base[b] + torch.arange(lens[b]) for b in range(B)]).long()
+    qr2, _ = orc.apply_rope(q, k, cos, sin, pos2[None])
+    assert torch.equal(q2.cpu()[:, : nH * d], qr2[0].transpose(0, 1).reshape(total, nH * d))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,n,k", [(1, 576, 115), (4, 576, 115), (3, 36, 7), (2, 1500, 300), (2, 64, 64), (1, 65, 1)])
+def test_topk_select_bit_exact(ops, dtype, B, n, k):
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(B, n, generator=g)
+    s = (s * 4).round() / 4  # few distinct values -> heavy ties, incl. at the k-th boundary
+    s = F.log_softmax(torch.stack([s, -s], -1), -1)[..., 0].to(dtype)
+    keep = ops.topk_select(s.cuda(), k).cpu()
+    ref = orc.topk_keep_index(s, k, "stable")
+    assert torch.equal(keep, ref)
+    kth = torch.sort(s.float(), dim=1, descending=True).values[:, k - 1 : k]
+    if 1 < k < n:
+        assert int((s.float() == kth).sum()) > B, "test must exercise ties at the boundary"
+
+
+def test_topk_select_no_ties_matches_reference_argsort(ops):
+    g = torch.Generator().manual_seed(6)
+    s = torch.randn(8, 576, generator=g)
+    keep = ops.topk_select(s.cuda(), 115).cpu()
+    assert torch.equal(keep, orc.topk_keep_index(s, 115, "torch"))  # the reference's own (non-stable) call
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_compact_tokens_bit_exact(ops, dtype):
+    g = torch.Generator().manual_seed(7)
+    H, n_img, k = 512, 36, 7
+    starts = [5, 1, 12]
+    lens = [5 + 36 + 7, 1 + 36 + 1, 12 + 36 + 30]
+    B = len(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    h = torch.randn(sum(lens), H, generator=g).to(dtype)
+    keep = torch.stack([torch.sort(torch.randperm(n_img, generator=g)[:k]).values for _ in range(B)])
+    new_lens = [n - (n_img - k) for n in lens]
+    cu2 = torch.tensor([0] + list(torch.tensor(new_lens).cumsum(0)), dtype=torch.int32)
+    out, pos = ops.compact_tokens(h.cuda(), keep.cuda(), cu.cuda(), cu2.cuda(), torch.tensor(starts, dtype=torch.int32).cuda(), n_img, k, sum(new_lens))
+    for b in range(B):
+        row = h[int(cu[b]) : int(cu[b + 1])]
+        s = starts[b]
+        ref = torch.cat([row[:s], row[s : s + n_img][keep[b]], row[s + n_img :]])
+        ref_pos = torch.cat([torch.arange(0, s), keep[b] + s, torch.arange(s + n_img, lens[b])])  # DML:1963-1983
+        assert torch.equal(out.cpu()[int(cu2[b]) : int(cu2[b + 1])], ref)
+        assert torch.equal(pos.cpu()[int(cu2[b]) : int(cu2[b + 1])].long(), ref_pos)
+
+
+def _sdpa_ref(q, k, v, causal):
+    """q [T,nH,d], k/v [T,nKV,d] -> [T,nH,d] in fp32 from the (already rounded) inputs."""
+    nH, nKV = q.shape[1], k.shape[1]
+    qf, kf, vf = q.float().transpose(0, 1), k.float().transpose(0, 1), v.float().transpose(0, 1)
+    if nKV != nH:
+        kf = kf.repeat_interleave(nH // nKV, dim=0)
+        vf = vf.repeat_interleave(nH // nKV, dim=0)
+    return F.scaled_dot_product_attention(qf[None], kf[None], vf[None], is_causal=causal)[0].transpose(0, 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (4, 2, 128, [129])])
+def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
+    g = torch.Generator().manual_seed(8)
+    total = sum(lens)
+    W = (nH + 2 * nKV) * d
+    qkv = torch.randn(total, W, generator=g).to(dtype)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    dev = qkv.cuda()
+    out = torch.full((total, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_prefill(dev[:, : nH * d], dev[:, nH * d : (nH + nKV) * d], dev[:, (nH + nKV) * d :], out, cu.cuda(), max(lens), nH, nKV, d, causal)
+    out = out.cpu().float().view(total, nH, d)
+    assert torch.isfinite(out).all()
+    for b in range(len(lens)):
+        a, e = int(cu[b]), int(cu[b + 1])
+        ref = _sdpa_ref(qkv[a:e, : nH * d].view(-1, nH, d), qkv[a:e, nH * d : (nH + nKV) * d].view(-1, nKV, d), qkv[a:e, (nH + nKV) * d :].view(-1, nKV, d), causal)
+        # fp32 path: pure rounding noise.  16-bit paths: P is rounded to the 16-bit dtype before P@V (as flash /
+        # the reference's SDPA backends do) and the output is rounded once: bound = 2 ulp of |max V| ~ 4.
+        tol = 2e-5 if dtype == torch.float32 else 6 * ULP[dtype]
+        err = float((out[a:e] - ref).abs().max())
+        assert err < tol, f"row {b} len {lens[b]}: max err {err} > {tol}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nH,nKV,d", [(32, 32, 128), (8, 2, 128), (4, 4, 64)])
+@pytest.mark.parametrize("n_splits", [1, 4, 32])
+def test_attn_decode_ragged(ops, dtype, nH, nKV, d, n_splits):
+    g = torch.Generator().manual_seed(9)
+    kv_len = [0, 16, 170, 631, 65]  # + extra(1): the current token's slot
+    B, T_cap = len(kv_len), 700
+    k_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    v_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    q = torch.randn(B, nH * d, generator=g).to(dtype)
+    out = torch.full((B, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ws = ops.attn_decode_workspace(B, nH, d, n_splits, "cuda")
+    ops.attn_decode(q.cuda(), k_slab.cuda(), v_slab.cuda(), torch.tensor(kv_len, dtype=torch.int32).cuda(), 1, out, ws, n_splits, nH, nKV, d)
+    out = out.cpu().float().view(B, nH, d)
+    assert torch.isfinite(out).all()
+    for b in range(B):
+        T = kv_len[b] + 1
+        ref = _sdpa_ref(q[b].view(1, nH, d), k_slab[b, :, :T].transpose(0, 1), v_slab[b, :, :T].transpose(0, 1), False)[0]
+        tol = 2e-5 if dtype == torch.float32 else 3 * ULP[dtype]
+        err = float((out[b] - ref).abs().max())
+        assert err < tol, f"row {b} T={T}: max err {err} > {tol}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(576, 512, 4096), (36, 128, 256), (100, 1536, 512), (70, 32, 64), (1, 2048, 512)])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_linear_epilogues(ops, dtype, M, N, K, flags):
+    g = torch.Generator().manual_seed(10)
+    a = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    bias = (0.1 * torch.randn(N, generator=g)).to(dtype)
+    r = torch.randn(M, N, generator=g).to(dtype)
+    ref = F.linear(a.float(), w.float(), bias.float()).to(dtype)
+    if flags & 1:
+        ref = F.gelu(ref.float()).to(dtype)
+    if flags & 2:
+        ref = (r.float() + ref.float()).to(dtype)
+    rd = r.cuda().clone()
+    out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), flags, residual=rd if flags & 2 else None, out=rd if flags & 2 else None)
+    # fp32 accumulate in a different order than the fp32 reference: <= 1 ulp of the output dtype after rounding
+    # (the residual epilogue rounds twice, so a 1-ulp flip before the add can surface as 2 ulp after it)
+    _close_ulp(out, ref, dtype, 2.0 if flags & 2 else 1.0, atol=1e-4 if dtype == torch.float32 else 1e-3)
+    assert _frac_exact(out, ref, dtype) > 0.97
+
+
+def _vp_sd(cfg, seed, gain):
+    sd = fx.make_state_dict(cfg, seed=seed, predictor_gain=gain, with_projector=False)
+    return {k: v for k, v in sd.items() if k.startswith("model.image_score_predictor.") or k.startswith("model.output_text_score_predictor.")}
+
+
+def _tiny_pred_cfg(H, D, nhead, FF):
+    return fx.make_config(hidden_size=H, intermediate_size=64, num_hidden_layers=0, num_attention_heads=H // 128, vocab_size=8, d_model=D, nhead=nhead, dim_feedforward=FF)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,D,nhead,FF,n_img,B", [(4096, 512, 8, 2048, 576, 2), (256, 128, 2, 256, 36, 3)])
+def test_vision_predictor_vs_oracle(ops, dtype, H, D, nhead, FF, n_img, B):
+    from dynamic_llava_amd.model import VisionPredictor
+
+    cfg = _tiny_pred_cfg(H, D, nhead, FF)
+    sd = _vp_sd(cfg, 11, 50.0)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, n_img, H, generator=g).to(dtype)
+    sdt = {k: v.to(dtype) for k, v in sd.items()}
+    ref_logit = orc.vision_predictor(sdt, "model.image_score_predictor.", x, torch.ones(B, n_img, 1, dtype=dtype), nhead, 2)
+    ref32 = orc.vision_predictor({k: v.to(dtype).float() for k, v in sd.items()}, "model.image_score_predictor.", x.float(), torch.ones(B, n_img, 1), nhead, 2)
+    vp = VisionPredictor(H, D, nhead, FF, 2)
+    vp.load_state_dict({k[len("model.image_score_predictor.") :]: v for k, v in sd.items() if "image_score" in k})
+    vp = vp.to(device="cuda", dtype=dtype)
+    # packed form with leading/trailing text rows, as the model calls it
+    pad_a, pad_b = 3, 5
+    rows = torch.cat([torch.cat([torch.randn(pad_a, H, generator=g).to(dtype), x[b], torch.randn(pad_b, H, generator=g).to(dtype)]) for b in range(B)])
+    L = pad_a + n_img + pad_b
+    cu = torch.arange(0, (B + 1) * L, L, dtype=torch.int32).cuda()
+    logits, score = vp.score_packed(rows.cuda(), cu, torch.full((B,), pad_a, dtype=torch.int32).cuda(), n_img)
+    logits2 = vp(x.cuda())  # dense / hookable form must agree bit-for-bit
+    assert torch.equal(logits, logits2)
+    err = float((logits.float().cpu() - ref32).abs().max())
+    noise = float((ref_logit.float() - ref32).abs().max())
+    scale = float(ref32.abs().max())
+    if dtype == torch.float32:
+        assert err < 2e-4 * max(1.0, scale), (err, scale)
+    else:
+        # same noise class as the eager reference evaluated in the same dtype (vs. fp32 ground truth)
+        assert err <= 2.0 * noise + 4 * ULP[dtype] * scale, (err, noise, scale)
+    ref_score = F.log_softmax(logits.float().cpu(), dim=-1)[..., 0].to(dtype)
+    _close_ulp(score, ref_score, dtype, 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,D,B", [(4096, 512, 1), (4096, 512, 32), (256, 128, 3), (5120, 512, 2)])
+def test_text_predictor_vs_oracle(ops, dtype, H, D, B):
+    from dynamic_llava_amd.model import TextPredictor
+
+    cfg = _tiny_pred_cfg(H, D, 2, 256)
+    sd = _vp_sd(cfg, 13, 50.0)
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, H, generator=g).to(dtype)
+    ref = orc.text_predictor({k: v.to(dtype) for k, v in sd.items()}, "model.output_text_score_predictor.", x[:, None])[:, 0]
+    ref32 = orc.text_predictor({k: v.to(dtype).float() for k, v in sd.items()}, "model.output_text_score_predictor.", x.float()[:, None])[:, 0]
+    tp = TextPredictor(H, D)
+    tp.load_state_dict({k[len("model.output_text_score_predictor.") :]: v for k, v in sd.items() if "output_text" in k})
+    tp = tp.to(device="cuda", dtype=dtype)
+    ws = torch.empty(B * D, dtype=torch.float32, device="cuda")
+    lg = torch.empty(B, 2, dtype=torch.float32, device="cuda")
+    dec = torch.empty(B, dtype=torch.int32, device="cuda")
+    tp.decide(x.cuda(), ws, lg, dec)
+    lg, dec = lg.cpu(), dec.cpu()
+    err = float((lg - ref32).abs().max())
+    noise = float((ref.float() - ref32).abs().max())
+    scale = float(ref32.abs().max())
+    if dtype == torch.float32:
+        assert err < 2e-4 * max(1.0, scale)
+    else:
+        assert err <= 2.0 * noise + 4 * ULP[dtype] * scale, (err, noise, scale)
+    assert torch.equal(dec.bool(), lg[:, 0] > lg[:, 1])
+    gap = (ref32[:, 0] - ref32[:, 1]).abs()
+    sure = gap > 4 * (err + noise)
+    assert torch.equal(dec.bool()[sure], (ref[:, 0] > ref[:, 1])[sure]), "decision differs from the oracle away from the boundary"
+
+
+@pytest.mark.parametrize("ldt", [torch.float32, torch.bfloat16])
+def test_decode_advance(ops, ldt):
+    g = torch.Generator().manual_seed(15)
+    B, V = 5, 32000
+    logits = torch.randn(B, V, generator=g).to(ldt)
+    logits[1, 777] = logits[1, 12345] = 50.0  # tie -> lowest index
+    logits[3, 2] = 60.0  # EOS
+    nxt = torch.zeros(B, dtype=torch.int64, device="cuda")
+    out = torch.zeros(B, 4, dtype=torch.int64, device="cuda")
+    step = torch.tensor([0, 1, 2, 3, 0], dtype=torch.int32, device="cuda")
+    fin = torch.tensor([0, 0, 0, 0, 1], dtype=torch.int32, device="cuda")
+    lf = torch.tensor([10, 20, 30, 40, 50], dtype=torch.int32, device="cuda")
+    ls = torch.tensor([5, 6, 7, 8, 9], dtype=torch.int32, device="cuda")
+    dec = torch.tensor([1, 0, 1, 0, 1], dtype=torch.int32, device="cuda")
+    ops.decode_advance(logits.cuda(), nxt, out, step, fin, 2, 0, lf, ls, dec)
+    ref = logits.float().argmax(-1)
+    assert nxt.cpu().tolist() == [int(ref[0]), 777, int(ref[2]), 2, 0]
+    assert fin.cpu().tolist() == [0, 0, 0, 1, 1]
+    assert step.cpu().tolist() == [1, 2, 3, 4, 1]
+    assert lf.cpu().tolist() == [11, 21, 31, 41, 51] and ls.cpu().tolist() == [6, 6, 8, 8, 10]
+    o = out.cpu()
+    assert o[0, 0] == ref[0] and o[1, 1] == 777 and o[2, 2] == ref[2] and o[3, 3] == 2 and o[4, 0] == 0
+
+
+def test_c_abi_rejects_bad_arguments(ops):
+    lib = ops.lib()
+    assert lib.dl_rmsnorm(None, None, None, 1, 4096, 1e-5, 2, None) == -1
+    assert b"NULL" in lib.dl_last_error()
+    x = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ops.HipOpsError):
+        ops.rmsnorm(x, torch.ones(100, dtype=torch.bfloat16, device="cuda"), 1e-5)  # H % 8 != 0
+    with pytest.raises(ops.HipOpsError):
+        ops.rmsnorm(torch.zeros(4, 128), torch.ones(128), 1e-5)  # CPU tensor: no fallback
