@@ -1,0 +1,301 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric "prefill+decode tokens/s/GPU, LLaVA-1.5-7B @ vision_keep_rate=0.2, 1 img".
+
+One "step" = one full `generate()` of the hot path on one request batch, inputs already resident in HBM:
+CLIP ViT-L/14-336 + projector -> 32-layer LLaVA-1.5-7B sparsified prefill (576 image tokens -> 115 after layer 2)
+-> T_new greedy decode tokens with output-text KV eviction.  Workload = BASELINE.json configs[1]: random-init
+LLaVA-1.5-7B, bf16, B=1, one synthetic 336x336 image, prompt = 35 system tokens + <image> + 20 question tokens
+(N = 631 -> N' = 170), vision_keep_rate=0.2.  tokens/step = N + T_new (the reference's own accounting counts all
+576 image tokens: llava/dynamic_eval/bench_test/dynamic_llava_long_text_mem.py:317-323).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: weak scaling, one identical request per rank (weights replicated), one RCCL all-gather of the last-token
+logits + generated ids per step, no collective in the decode loop.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+N_SYS, N_Q, N_IMG = 35, 20, 576
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--new-tokens", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=32, help="debug only: fewer decoder layers => the JSON is marked INVALID")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-gpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--predictor-gain", type=float, default=50.0, help="'trained-like' predictor scaling (no score ties); 1.0 = plain random init")
+    return ap.parse_args()
+
+
+def make_inputs(cfg, device, dtype):
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, cfg.vocab_size, (N_SYS + N_Q,), generator=g)
+    prompt = torch.cat([torch.tensor([1]), ids[: N_SYS - 1], torch.tensor([-200]), ids[N_SYS:]]).long()[None]
+    images = torch.randn((1, 3, 336, 336), generator=g).to(dtype)
+    return prompt.to(device), images.to(device)
+
+
+def event_time_ms(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def graph_time_ms(fn, reps=40, replays=8):
+    """Device-side time of one `fn()` launch: `reps` launches captured into ONE hipGraph (no Python / ctypes / launch-API
+    time inside the timed region), graph replayed `replays` times between HIP events on the launch stream.  Includes the
+    ~1-2 us dependent-launch gap between consecutive kernels, so it is an upper bound on the pure kernel duration that
+    rocprofv3 reports."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(replays):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (reps * replays)
+
+
+def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim, iters=300):
+    """dl_attn_decode (split-KV kernel + combine kernel) on a [B, nH, T_cap, d] slab with per-row lengths T_list.
+    Algorithmic bytes per launch: sum_b [2*T_b*H*E + 2*H*E], E = 2."""
+    from dynamic_llava_amd import hip_ops as ops
+
+    dev, dt = model.device, model.dtype
+    H = n_heads * head_dim
+    T_cap = max(T_list) + 1
+    k = torch.randn((B, n_heads, T_cap, head_dim), device=dev, dtype=dt)
+    v = torch.randn_like(k)
+    q = torch.randn((B, H), device=dev, dtype=dt)
+    out = torch.empty_like(q)
+    lens = torch.tensor([t - 1 for t in T_list], dtype=torch.int32, device=dev)
+    n_splits = max(1, min(32, 1024 // max(1, B * n_heads)))
+    ws = ops.attn_decode_workspace(B, n_heads, head_dim, n_splits, dev)
+    ms = graph_time_ms(lambda: ops.attn_decode(q, k, v, lens, 1, out, ws, n_splits, n_heads, n_heads, head_dim))
+    nbytes = sum(2 * t * H * 2 + 2 * H * 2 for t in T_list)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "dl_attn_decode (attn_decode_split_kernel + attn_decode_combine_kernel)", "shape": label, "bytes": nbytes,
+            "us": round(ms * 1e3, 3), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def other_kernel_rooflines(model, n_tokens):
+    """HBM-bound row kernels on the workload's prefill shape (algorithmic bytes per SURVEY 8d)."""
+    from dynamic_llava_amd import hip_ops as ops
+
+    dev, dt, H = model.device, model.dtype, model.config.hidden_size
+    res = []
+    x = torch.randn((n_tokens, H), device=dev, dtype=dt)
+    w = torch.ones(H, device=dev, dtype=dt)
+    out = torch.empty_like(x)
+    ms = graph_time_ms(lambda: ops.rmsnorm(x, w, 1e-5, out=out))
+    nb = 2 * n_tokens * H * 2 + H * 2
+    res.append({"kernel": "dl_rmsnorm", "shape": f"[{n_tokens},{H}]", "bytes": nb, "us": round(ms * 1e3, 3), "achieved": round(nb / ms / 1e6, 1), "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)})
+    return res
+
+
+def cpu_baseline(new_tokens):
+    """The oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
+    LLaVA-1.5-7B layer width, bf16, the bench prompt, with 4 and 6 decoder layers (+ full-size predictors),
+    linearly extrapolated to 32 layers; CLIP ViT-L/14-336 + projector timed once and added."""
+    import torch.nn.functional as F  # noqa: F401
+
+    from oracle import fixtures as fx
+    from oracle.ref_cpu import Oracle
+
+    torch.manual_seed(0)
+    threads = torch.get_num_threads()
+    dt = torch.bfloat16
+    times = {}
+    base_cfg = fx.llava7b_config(num_hidden_layers=1)
+    layer_sd = fx.make_state_dict(base_cfg, seed=0, dtype=dt, init="hf")
+    clip = fx.build_clip(base_cfg, seed=1, dtype=dt)
+    images = torch.randn(1, 3, 336, 336).to(dt)
+    prompt = fx.make_prompt(base_cfg, N_SYS, N_Q)[None]
+    for L in (4, 6):
+        cfg = fx.llava7b_config(num_hidden_layers=L)
+        sd = {k: v for k, v in layer_sd.items() if ".layers." not in k}
+        for i in range(L):  # all layers alias layer 0's tensors: timing does not depend on the values
+            for k, v in layer_sd.items():
+                if ".layers.0." in k:
+                    sd[k.replace(".layers.0.", f".layers.{i}.")] = v
+        o = Oracle(cfg, sd, dt, clip=clip)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            feats = o.encode_images(images)
+            t1 = time.perf_counter()
+            logits, pkv = o.forward(prompt, image_features=feats)
+            t2 = time.perf_counter()
+            n_dec = 3
+            for _ in range(n_dec):
+                logits, pkv = o.forward(logits[:, -1:].argmax(-1), past_key_values=pkv)
+            t3 = time.perf_counter()
+        times[L] = (t1 - t0, t2 - t1, (t3 - t2) / n_dec)
+    clip_s = min(times[4][0], times[6][0])
+    prefill = times[4][1] + 14 * (times[6][1] - times[4][1])
+    decode = times[4][2] + 14 * (times[6][2] - times[4][2])
+    n_prompt = N_SYS + N_IMG + N_Q
+    total = clip_s + prefill + (new_tokens - 1) * decode
+    return {
+        "value": round((n_prompt + new_tokens) / total, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/ref_cpu.py bf16, 7B width, bench prompt N={n_prompt}: measured with 4 and 6 layers (prefill {times[4][1]:.2f}s/{times[6][1]:.2f}s, "
+                  f"decode {times[4][2]*1e3:.0f}/{times[6][2]*1e3:.0f} ms/token over 3 tokens), extrapolated linearly to 32 layers "
+                  f"(prefill {prefill:.2f}s, decode {decode*1e3:.0f} ms/token x {new_tokens - 1}) + CLIP+projector {clip_s:.2f}s measured once",
+        "prefill_tokens_per_s": round(n_prompt / (clip_s + prefill), 2), "decode_tokens_per_s": round(1.0 / decode, 3),
+    }
+
+
+def ref_gpu_path(model, prompt, images, new_tokens):
+    """Stand-in for "the reference GPU path" (the reference's Python cannot travel to this box): the oracle -- the same
+    eager op sequence as the reference (padded batch, torch.cat KV cache, per-layer host sync on the eviction
+    decision, SDPA) -- run by PyTorch-ROCm on this GPU with this model's weights.  Reported baseline only."""
+    from oracle.ref_cpu import Oracle
+
+    sd = {k: v for k, v in model.state_dict().items() if "vision_tower" not in k}
+    cfg = model.config
+    o = Oracle(cfg, sd, model.dtype, device=str(model.device), clip=model.model.vision_tower.vision_tower)
+    n_prompt = N_SYS + N_IMG + N_Q
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o.greedy(prompt, images=images, max_new_tokens=n, eos_token_id=None)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(2)
+    t_full = min(run(new_tokens) for _ in range(2))
+    t_pre = min(run(1) for _ in range(3))
+    return {"value": round((n_prompt + new_tokens) / t_full, 1), "unit": "tokens/s", "kind": "oracle op sequence on PyTorch-ROCm eager (reference GPU-path stand-in)",
+            "prefill_tokens_per_s": round(n_prompt / t_pre, 1), "decode_tokens_per_s": round((new_tokens - 1) / max(t_full - t_pre, 1e-9), 2), "ms_per_step": round(t_full * 1e3, 2)}
+
+
+def main():
+    args = parse()
+    from dynamic_llava_amd import dist as dd
+    from dynamic_llava_amd.builder import build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    rank, world, local = dd.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dtype = torch.bfloat16
+    cfg = DynamicLlavaConfig(num_hidden_layers=args.layers)  # LLaVA-1.5-7B defaults, sparse_layer=2, keep 0.2
+    model = build_random_model(cfg, dtype=dtype, device=device, seed=0, predictor_gain=args.predictor_gain)
+    model.use_hip_graph = not args.no_graph
+    prompt, images = make_inputs(cfg, device, dtype)
+    n_prompt = N_SYS + N_IMG + N_Q
+    T_new = args.new_tokens
+    gathered = {}
+
+    def step():
+        out = model.generate(prompt, images=images, max_new_tokens=T_new, do_sample=False, num_beams=1, use_cache=True, eos_token_id=None)
+        if world > 1:  # DP result = concatenation over ranks (logits of the prefill's last token + generated ids)
+            gathered["logits"] = dd.all_gather_rows(model.last_prefill_logits)
+            gathered["ids"] = dd.all_gather_rows(out)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    dd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dd.barrier()
+    elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
+    if world > 1:
+        assert gathered["ids"].shape[0] == world and torch.equal(gathered["ids"][0], gathered["ids"][-1]), "DP ranks disagree on identical requests"
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * (n_prompt + T_new) * args.steps / elapsed
+    # ---- phase split (outside the timed region) ----
+    pre_ms = min(event_time_ms(lambda: model.generate(prompt, images=images, max_new_tokens=1, eos_token_id=None), 3, 1) for _ in range(2))
+    dec_ms = (ms_per_step - pre_ms) / max(T_new - 1, 1)
+    clip_ms = event_time_ms(lambda: model.encode_images(images), 5, 2)
+    cache = model.last_cache
+    lens = cache.lens.cpu().tolist()
+    t_full, t_sparse = lens[0][0], lens[1][0]
+    nH, d = cfg.num_attention_heads, cfg.head_dim
+    roof_main = decode_attn_roofline(model, f"bench workload, layers>=2: B=1, T={t_sparse} (170 prompt + kept decode tokens)", 1, [t_sparse], nH, d)
+    extra = [
+        decode_attn_roofline(model, f"bench workload, layers 0-1: B=1, T={t_full}", 1, [t_full], nH, d),
+        decode_attn_roofline(model, "configs[2]-like: B=32 ragged T~U[200,900]", 32, [200 + (i * 701) % 700 for i in range(32)], nH, d),
+        decode_attn_roofline(model, "configs[4]-like: 13B heads (40x128), B=1, T=2048", 1, [2048], 40, d),
+        decode_attn_roofline(model, "B=32, T=2048", 32, [2048] * 32, nH, d),
+    ] + other_kernel_rooflines(model, n_prompt)
+    res = {
+        "metric": "prefill+decode tokens/s/GPU, LLaVA-1.5-7B @ vision_keep_rate=0.2, 1 img",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init LLaVA-1.5-7B + CLIP ViT-L/14-336 weights, randn 336x336 image, random token ids)",
+        "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
+                               f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
+                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "hip_graph_decode": model.use_hip_graph,
+                   "predictor_gain": args.predictor_gain},
+        "phases": {"prefill_ms": round(pre_ms, 3), "clip_projector_ms": round(clip_ms, 3), "decode_ms_per_token": round(dec_ms, 4),
+                   "prefill_tokens_per_s": round(n_prompt / pre_ms * 1e3, 1), "decode_tokens_per_s": round(1e3 / dec_ms, 1),
+                   "kv_len_full": t_full, "kv_len_sparse": t_sparse,
+                   "decode_weight_stream_GBps": round(sum(p.numel() * p.element_size() for n, p in model.named_parameters() if ".layers." in n or n.startswith("lm_head")) / dec_ms / 1e6, 1)},
+        "roofline": {"bound": "hbm", "achieved": roof_main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_main["frac"], "traffic": None,
+                     "kernel": roof_main["kernel"], "shape": roof_main["shape"], "bytes_per_launch": roof_main["bytes"], "us_per_launch": roof_main["us"]},
+        "roofline_kernels": extra,
+    }
+    if args.layers != 32:
+        res["INVALID"] = f"debug run with {args.layers} layers"
+    if world == 1 and not args.no_ref_gpu:
+        try:
+            res["ref_gpu_path"] = ref_gpu_path(model, prompt, images, T_new)
+            res["ref_gpu_path"]["speedup_total"] = round(value / res["ref_gpu_path"]["value"], 2)
+            res["ref_gpu_path"]["speedup_prefill"] = round(res["phases"]["prefill_tokens_per_s"] / res["ref_gpu_path"]["prefill_tokens_per_s"], 2)
+        except Exception as e:  # the baseline leg must never take the measurement down
+            res["ref_gpu_path"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(T_new)
+        except Exception as e:
+            res["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -125,18 +125,42 @@ __global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
   }
 }
 
+constexpr int kMaxSplits = 128;
+
+// Merge the split partials of one (row, head).  All (m, l) pairs are fetched in parallel into LDS first, and the
+// O-partials are read with independent (unrolled) loads: the partials were written by other CUs a few hundred
+// nanoseconds ago, so every dependent load here is a full L2/fabric round trip.
 template <typename T, int D>
 __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ ws, void* __restrict__ out_,
                                                                 int64_t out_row_stride, int n_splits) {
+  __shared__ float sw[kMaxSplits];
+  __shared__ float sl[kMaxSplits];
   const int h = blockIdx.x, b = blockIdx.y, n_heads = gridDim.x, d = threadIdx.x;
   const float* p = ws + ((int64_t)b * n_heads + h) * n_splits * (D + 2);
+  for (int s = d; s < n_splits; s += D) {
+    sw[s] = p[s * (D + 2)];
+    sl[s] = p[s * (D + 2) + 1];
+  }
+  __syncthreads();
   float M = -INFINITY;
-  for (int s = 0; s < n_splits; ++s) M = fmaxf(M, p[s * (D + 2)]);
+  for (int s = 0; s < n_splits; ++s) M = fmaxf(M, sw[s]);
   float L = 0.f, O = 0.f;
   if (M > -INFINITY) {
-    for (int s = 0; s < n_splits; ++s) {
-      const float w = __expf(p[s * (D + 2)] - M);
-      L += p[s * (D + 2) + 1] * w;
+    int s = 0;
+    for (; s + 8 <= n_splits; s += 8) {
+      float o8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o8[u] = p[(s + u) * (D + 2) + 2 + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = __expf(sw[s + u] - M);
+        L += sl[s + u] * w;
+        O += o8[u] * w;
+      }
+    }
+    for (; s < n_splits; ++s) {
+      const float w = __expf(sw[s] - M);
+      L += sl[s] * w;
       O += p[s * (D + 2) + 2 + d] * w;
     }
   }
@@ -172,7 +196,7 @@ extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k
                               void* stream) {
   DL_REQUIRE(q && k_slab && v_slab && kv_len && out, "dl_attn_decode: NULL pointer");
   DL_REQUIRE(B > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "dl_attn_decode: bad head counts");
-  DL_REQUIRE(n_splits >= 1 && n_splits <= 65535, "dl_attn_decode: bad n_splits=%d", n_splits);
+  DL_REQUIRE(n_splits >= 1 && n_splits <= kMaxSplits, "dl_attn_decode: n_splits=%d must be in [1, %d]", n_splits, kMaxSplits);
   DL_REQUIRE(n_splits == 1 || workspace, "dl_attn_decode: workspace required when n_splits > 1");
   DL_REQUIRE(head_dim == 128 || head_dim == 64, "dl_attn_decode: head_dim=%d unsupported (64 or 128)", head_dim);
   hipStream_t st = as_stream(stream);

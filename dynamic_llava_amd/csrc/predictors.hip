@@ -25,20 +25,32 @@ __global__ void vp_build_index_kernel(const int32_t* __restrict__ cu, const int3
 }
 
 // z[m, :C/2] = x[m, :C/2];  z[m, C/2:] = mean over the image's n tokens of x[., C/2:]   (DML:1353-1357, policy == 1)
+// grid (B, ceil(C/2 / 64)); block 1024 = 64 channels x 16 token groups (coalesced 128-byte channel runs).
 template <typename T>
-__global__ __launch_bounds__(256) void vp_pool_concat_kernel(const void* __restrict__ x_, void* __restrict__ z_, int n, int C) {
+__global__ __launch_bounds__(1024) void vp_pool_concat_kernel(const void* __restrict__ x_, void* __restrict__ z_, int n, int C) {
+  __shared__ float part[16][65];
   const int b = blockIdx.x;
   const int half = C / 2;
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const bool ok = c < half;
+  float s = 0.f;
+  if (ok) {
+#pragma unroll 4
+    for (int i = g; i < n; i += 16) s += load1<T>(x_, ((int64_t)b * n + i) * C + half + c);
+  }
+  part[g][cl] = s;
+  __syncthreads();
+  if (!ok) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += part[k][cl];
   const float denom = Elem<T>::round((float)n);  // torch.sum(image_policy) is itself a model-dtype tensor
-  for (int c = threadIdx.x; c < half; c += blockDim.x) {
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += load1<T>(x_, ((int64_t)b * n + i) * C + half + c);
-    const float g = Elem<T>::round(Elem<T>::round(s) / denom);
-    for (int i = 0; i < n; ++i) {
-      const int64_t r = ((int64_t)b * n + i) * C;
-      store1<T>(z_, r + half + c, g);
-      store1<T>(z_, r + c, load1<T>(x_, r + c));
-    }
+  const float gm = Elem<T>::round(Elem<T>::round(tot) / denom);
+  for (int i = g; i < n; i += 16) {
+    const int64_t r = ((int64_t)b * n + i) * C;
+    store1<T>(z_, r + half + c, gm);
+    store1<T>(z_, r + c, load1<T>(x_, r + c));
   }
 }
 
@@ -93,19 +105,27 @@ __global__ __launch_bounds__(256) void tp_stage1_kernel(const void* __restrict__
   for (int i = tid; i < H; i += 256) xs[i] = Elem<T>::round((xs[i] - mean) * rstd * load1<T>(ln_w, i) + load1<T>(ln_b, i));
   __syncthreads();
   const S* W = reinterpret_cast<const S*>(w1);
-#pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
-    const int n = blockIdx.x * 16 + wid * 4 + j;
-    if (n >= D) break;
-    float acc = 0.f;
-    for (int v = lane; v < H / V; v += 64) {
-      float wv[V];
-      load16<T>(W + (int64_t)n * H + v * V, wv);
+  const int nb = blockIdx.x * 16 + wid * 4;  // this wave's 4 neurons, all streamed together (4+ loads in flight)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nvec = H / V;
+#pragma unroll 2
+  for (int v = lane; v < nvec; v += 64) {
+    float wv[4][V];
 #pragma unroll
-      for (int e = 0; e < V; ++e) acc = fmaf(wv[e], xs[v * V + e], acc);
+    for (int j = 0; j < 4; ++j) {
+      const int n = nb + j < D ? nb + j : D - 1;
+      load16<T>(W + (int64_t)n * H + v * V, wv[j]);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) h1[(int64_t)b * D + n] = Elem<T>::round(gelu_erf(Elem<T>::round(acc + load1<T>(b1, n))));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[j] = fmaf(wv[j][e], xs[v * V + e], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = wave_sum(acc[j]);
+    const int n = nb + j;
+    if (lane == 0 && n < D) h1[(int64_t)b * D + n] = Elem<T>::round(gelu_erf(Elem<T>::round(a + load1<T>(b1, n))));
   }
 }
 
@@ -114,19 +134,26 @@ __device__ __forceinline__ void tp_dense(const float* in, float* out, const void
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   const S* W = reinterpret_cast<const S*>(w_);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int n = wid; n < N; n += 4) {
-    float acc = 0.f;
-    for (int v = lane; v < K / V; v += 64) {
-      float wv[V];
-      load16<T>(W + (int64_t)n * K + v * V, wv);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int nvec = K / V;
+  for (int n0 = wid * 4; n0 < N; n0 += nw * 4) {  // 4 output neurons per wave per pass: 4 weight rows in flight
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int v = lane; v < nvec; v += 64) {
+      float wv[4][V];
 #pragma unroll
-      for (int e = 0; e < V; ++e) acc = fmaf(wv[e], in[v * V + e], acc);
+      for (int j = 0; j < 4; ++j) load16<T>(W + (int64_t)(n0 + j < N ? n0 + j : N - 1) * K + v * V, wv[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[j] = fmaf(wv[j][e], in[v * V + e], acc[j]);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float y = Elem<T>::round(acc + load1<T>(b_, n));
-      out[n] = gelu ? Elem<T>::round(gelu_erf(y)) : y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = wave_sum(acc[j]);
+      if (lane == 0 && n0 + j < N) {
+        const float y = Elem<T>::round(a + load1<T>(b_, n0 + j));
+        out[n0 + j] = gelu ? Elem<T>::round(gelu_erf(y)) : y;
+      }
     }
   }
   __syncthreads();
@@ -134,7 +161,7 @@ __device__ __forceinline__ void tp_dense(const float* in, float* out, const void
 
 // ---- text predictor, stage 2: D -> D/2 -> D/4 -> 2 and the keep/evict decision.  grid (B) ----
 template <typename T>
-__global__ __launch_bounds__(256) void tp_stage2_kernel(const float* __restrict__ h1, const void* w3, const void* b3, const void* w5,
+__global__ __launch_bounds__(1024) void tp_stage2_kernel(const float* __restrict__ h1, const void* w3, const void* b3, const void* w5,
                                                          const void* b5, const void* w7, const void* b7, float* __restrict__ logits,
                                                          int32_t* __restrict__ decision, int D) {
   extern __shared__ float sm[];  // [D] + [D/2] + [D/4] + [2]
@@ -143,7 +170,7 @@ __global__ __launch_bounds__(256) void tp_stage2_kernel(const float* __restrict_
   float* a2 = a1 + D / 2;
   float* a3 = a2 + D / 4;
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < D; i += 256) a0[i] = h1[(int64_t)b * D + i];
+  for (int i = threadIdx.x; i < D; i += blockDim.x) a0[i] = h1[(int64_t)b * D + i];
   __syncthreads();
   tp_dense<T>(a0, a1, w3, b3, D, D / 2, true);
   tp_dense<T>(a1, a2, w5, b5, D / 2, D / 4, true);
@@ -169,11 +196,20 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const void* __rest
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int v = tid; v < V; v += blockDim.x) {
-    const float x = load1<T>(logits, (int64_t)b * row_stride + v);
-    if (x > best || (x == best && v < bi)) {
-      best = x;
-      bi = v;
+  for (int v0 = tid; v0 < V; v0 += 8 * blockDim.x) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = v0 + u * blockDim.x;
+      x[u] = v < V ? load1<T>(logits, (int64_t)b * row_stride + v) : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = v0 + u * blockDim.x;
+      if (x[u] > best || (x[u] == best && v < bi && v < V)) {
+        best = x[u];
+        bi = v;
+      }
     }
   }
 #pragma unroll
@@ -290,7 +326,7 @@ extern "C" int dl_vision_predictor(const void* hidden, const int32_t* cu_seqlens
     linear_launch(ff, dim_ff, k.fc2_w, k.fc2_b, hs, D, hs, D, M, D, dim_ff, DL_EPI_RESIDUAL, dtype, st);
   }
   DL_DISPATCH_DTYPE(dtype, T, {
-    hipLaunchKernelGGL((vp_pool_concat_kernel<T>), dim3((unsigned)B), dim3(256), 0, st, hs, z, n_img, D);
+    hipLaunchKernelGGL((vp_pool_concat_kernel<T>), dim3((unsigned)B, (unsigned)((D / 2 + 63) / 64)), dim3(1024), 0, st, hs, z, n_img, D);
   });
   linear_launch(z, D, w->out0_w, w->out0_b, z1, D / 2, nullptr, 0, M, D / 2, D, DL_EPI_GELU, dtype, st);
   linear_launch(z1, D / 2, w->out2_w, w->out2_b, z2, D / 4, nullptr, 0, M, D / 4, D / 2, DL_EPI_GELU, dtype, st);
@@ -313,7 +349,7 @@ extern "C" int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int
   DL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((tp_stage1_kernel<T>), dim3((unsigned)((D + 15) / 16), (unsigned)B), dim3(256), (size_t)H * sizeof(float), st, x,
                        x_row_stride, w->ln_w, w->ln_b, w->l1_w, w->l1_b, h1, H, D);
-    hipLaunchKernelGGL((tp_stage2_kernel<T>), dim3((unsigned)B), dim3(256), (size_t)(D + D / 2 + D / 4 + 2) * sizeof(float), st, h1,
+    hipLaunchKernelGGL((tp_stage2_kernel<T>), dim3((unsigned)B), dim3(1024), (size_t)(D + D / 2 + D / 4 + 2) * sizeof(float), st, h1,
                        w->l3_w, w->l3_b, w->l5_w, w->l5_b, w->l7_w, w->l7_b, logits_out, decision, D);
   });
   DL_CHECK_LAUNCH("dl_text_predictor_decide");

@@ -70,6 +70,8 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(VpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     ),
     "dl_text_predictor_decide": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, POINTER(TpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dl_gemv_max_batch": (c_int, [c_int, c_int]),
+    "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -297,6 +299,32 @@ def text_predictor_decide(x, weights: TpWeights, d_model, workspace, logits_out,
         "dl_text_predictor_decide",
     )
     return decision
+
+
+GEMV_PLAIN, GEMV_ADDNORM, GEMV_SILUMUL = 0, 1, 2
+
+
+def gemv_max_batch(K, dtype):
+    return int(lib().dl_gemv_max_batch(int(K), dtype_code(dtype)))
+
+
+def gemv(w, y, x=None, mode=GEMV_PLAIN, h_in=None, h_out=None, delta=None, norm_w=None, eps=0.0):
+    """y[b,:] = W @ prologue(x)[b,:] (see include/dynllava.h).  w [N,K]; y [B,N] (row stride y.stride(0))."""
+    _dev(w, y, x, h_in, h_out, delta, norm_w)
+    assert w.is_contiguous() and y.stride(1) == 1
+    N, K = w.shape
+    B = y.shape[0]
+    if mode == GEMV_ADDNORM:
+        assert h_in.is_contiguous() and h_in.shape == (B, K) and (delta is None or (delta.is_contiguous() and h_out.is_contiguous()))
+        xs = 0
+    else:
+        assert x.stride(1) == 1 and x.shape[0] == B
+        xs = x.stride(0)
+    _check(
+        lib().dl_gemv(mode, _p(w), N, K, _p(x), xs, _p(h_in), _p(h_out), _p(delta), _p(norm_w), eps, _p(y), y.stride(0), B, dtype_code(w.dtype), _stream()),
+        "dl_gemv",
+    )
+    return y
 
 
 def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos_id=-1, pad_id=0, kv_len_full=None, kv_len_sparse=None, decision=None):

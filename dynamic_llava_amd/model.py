@@ -219,6 +219,24 @@ class CLIPVisionTower(nn.Module):
         )
         self.vision_tower.requires_grad_(False)
         self.is_loaded = True
+        self._patch_embed_as_gemm()
+
+    def _patch_embed_as_gemm(self):
+        """The ViT patch embedding is a stride-14 14x14 conv == one GEMM over unfolded patches.  MIOpen serves it with a
+        ~330 us naive fallback kernel in bf16; the same weights through F.linear take ~20 us.  Still plain PyTorch."""
+        import types
+
+        conv = next(m for n, m in self.vision_tower.named_modules() if n.endswith("patch_embedding"))  # module path differs across HF versions
+        ps = conv.kernel_size[0]
+
+        def gemm_forward(mod, x):
+            B, C, Hh, Ww = x.shape
+            gh, gw = Hh // ps, Ww // ps
+            patches = x.reshape(B, C, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ps * ps)
+            y = F.linear(patches, mod.weight.reshape(mod.weight.shape[0], -1), mod.bias)
+            return y.transpose(1, 2).reshape(B, -1, gh, gw)
+
+        conv.forward = types.MethodType(gemm_forward, conv)
 
     @torch.no_grad()
     def forward(self, images):
@@ -297,7 +315,14 @@ class _DecodeState:
         self.tp_ws = torch.empty(B * cfg.sparse_config["d_model"], dtype=torch.float32, device=device)
         self.cu = torch.arange(0, B + 1, dtype=torch.int32, device=device)
         self.h = torch.empty((B, H), dtype=dtype, device=device)
+        self.h2 = torch.empty((B, H), dtype=dtype, device=device)  # residual ping-pong partner (dl_gemv ADDNORM)
         self.x = torch.empty((B, H), dtype=dtype, device=device)
+        self.qkv = torch.empty((B, (nH + 2 * nKV) * d), dtype=dtype, device=device)
+        self.o = torch.empty((B, H), dtype=dtype, device=device)
+        self.gu = torch.empty((B, 2 * I), dtype=dtype, device=device)
+        self.dn = torch.empty((B, H), dtype=dtype, device=device)
+        # weight-streaming GEMV path for small decode batches (else torch/hipBLASLt GEMMs)
+        self.use_gemv = B <= min(model.gemv_max_decode_batch, ops.gemv_max_batch(I, dtype), ops.gemv_max_batch(H, dtype))
         self.attn = torch.empty((B, nH * d), dtype=dtype, device=device)
         self.act = torch.empty((B, I), dtype=dtype, device=device)
         self.logits = torch.empty((B, V), dtype=dtype, device=device)
@@ -320,7 +345,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._packed = False
         self._rope = None
         self._dstate = None
+        self._prefill_graphs = {}
         self.use_hip_graph = True
+        self.gemv_max_decode_batch = 4  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
         self.eval()
 
@@ -387,55 +414,91 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         tot = a0 + (n - ans0)
         return {"system": [0, s], "image": [s, i0], "instruct": [i0, a0], "answer": [a0, tot], "last_instruct": [i0 + last, a0]}
 
-    def _prepare_packed(self, input_ids, attention_mask, labels, images, image_features=None):
-        """-> (packed embeds [total,H], lens [B], indices list[dict] or None)."""
+    def _layout(self, input_ids, attention_mask, labels, n_feat):
+        """Host pass over the prompt(s): where the text tokens and the image features land in the PACKED batch.
+        Returns a dict with `sig` (hashable shape signature -- token VALUES do not enter it), per-row lengths, segment
+        dicts, and index lists.  Costs one small device->host copy of input_ids (the reference does several .item()s)."""
         ids_host = input_ids.detach().to("cpu")
-        if attention_mask is not None:
-            am = attention_mask.detach().to("cpu").bool()
-            rows = [ids_host[b][am[b]].tolist() for b in range(ids_host.shape[0])]
-            lab_rows = None if labels is None else [labels[b].detach().to("cpu")[am[b]].tolist() for b in range(ids_host.shape[0])]
-        else:
-            rows = [r.tolist() for r in ids_host]
-            lab_rows = None if labels is None else [r.tolist() for r in labels.detach().to("cpu")]
-        B = len(rows)
-        if image_features is None:
-            if type(images) is list or images.ndim == 5:
-                raise NotImplementedError("anyres / multi-image lists are not on the LLaVA-1.5 Dynamic-LLaVA path")
-            image_features = self.encode_images(images)  # [n_images, n_img, H]
-        n_feat = image_features.shape[1]
-        dev = self.device
-        pieces, lens, indices = [], [], []
-        img_i = 0
+        B, W = ids_host.shape
+        am = None if attention_mask is None else attention_mask.detach().to("cpu").bool()
+        lab = None if labels is None else labels.detach().to("cpu")
+        lens, indices, text_src, text_dst, img_dst, img_rows = [], [], [], [], [], []
+        base, img_i = 0, 0
         for b in range(B):
-            r = rows[b]
+            cols = list(range(W)) if am is None else torch.nonzero(am[b]).flatten().tolist()
+            r = [int(ids_host[b, c]) for c in cols]
+            lr = None if lab is None else [int(lab[b, c]) for c in cols]
             n_images = r.count(IMAGE_TOKEN_INDEX)
-            if n_images == 0:  # ARCH:315-324: text-only row consumes (and ignores) one image feature
-                pieces.append(self.model.embed_tokens(torch.tensor(r, dtype=torch.long, device=dev)))
+            if n_feat == 0 or n_images == 0:  # ARCH:315-324: a text-only row consumes (and ignores) one image feature
+                text_src += [b * W + c for c in cols]
+                text_dst += list(range(base, base + len(r)))
                 lens.append(len(r))
                 indices.append(None)
+                base += len(r)
                 img_i += 1
                 continue
             if n_images != 1:
                 raise NotImplementedError("exactly one <image> per row (ARCH:330-332 calls .item() on the position)")
-            seg = self._segments(r, None if lab_rows is None else lab_rows[b], n_feat)
+            seg = self._segments(r, lr, n_feat)
             p = seg["system"][1]
-            txt = self.model.embed_tokens(torch.tensor(r[:p] + r[p + 1 :], dtype=torch.long, device=dev))
-            pieces += [txt[:p], image_features[img_i].to(self.dtype), txt[p:]]
+            text_src += [b * W + c for j, c in enumerate(cols) if j != p]
+            text_dst += list(range(base, base + p)) + list(range(base + p + n_feat, base + len(r) - 1 + n_feat))
+            img_dst += list(range(base + p, base + p + n_feat))
+            img_rows.append(img_i)
             img_i += 1
-            lens.append(len(r) - 1 + n_feat)
+            n = len(r) - 1 + n_feat
+            lens.append(n)
             indices.append(seg)
-        embeds = torch.cat(pieces, dim=0).contiguous()
+            base += n
         maxlen = getattr(self.config, "tokenizer_model_max_length", None)
         if maxlen is not None and max(lens) > maxlen:
             raise NotImplementedError("truncation to tokenizer_model_max_length (ARCH:493-506) is not built")
-        if any(i is None for i in indices):
-            indices = None if all(i is None for i in indices) else indices
-        return embeds, lens, indices
+        if all(i is None for i in indices):
+            indices = None
+        sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, tuple(text_src[:1] + text_src[-1:]), len(text_src))
+        return dict(sig=sig, B=B, lens=lens, indices=indices, text_src=text_src, text_dst=text_dst, img_dst=img_dst, img_rows=img_rows, total=base, n_feat=n_feat)
+
+    def _assemble(self, lay, dev_idx, input_ids, image_features):
+        """Device-only: packed embeds [total,H] from token ids + projector output (index_copy, no host sync)."""
+        H = self.config.hidden_size
+        embeds = torch.empty((lay["total"], H), dtype=self.dtype, device=self.device)
+        ids = input_ids.reshape(-1).index_select(0, dev_idx["text_src"])
+        embeds.index_copy_(0, dev_idx["text_dst"], self.model.embed_tokens(ids))
+        if lay["img_dst"]:
+            f = image_features.to(self.dtype)
+            if len(lay["img_rows"]) != f.shape[0] or lay["img_rows"] != list(range(f.shape[0])):
+                f = f.index_select(0, dev_idx["img_rows"])
+            embeds.index_copy_(0, dev_idx["img_dst"], f.reshape(-1, H))
+        return embeds
+
+    def _dev_idx(self, lay):
+        dev = self.device
+        t = lambda x: torch.tensor(x, dtype=torch.long, device=dev)
+        return {"text_src": t(lay["text_src"]), "text_dst": t(lay["text_dst"]), "img_dst": t(lay["img_dst"]), "img_rows": t(lay["img_rows"])}
+
+    def _n_feat(self, images, image_features):
+        if image_features is not None:
+            return image_features.shape[1]
+        if images is None:
+            return 0
+        if type(images) is list or images.ndim == 5:
+            raise NotImplementedError("anyres / multi-image lists are not on the LLaVA-1.5 Dynamic-LLaVA path")
+        return self.get_vision_tower().num_patches
+
+    def _prepare_packed(self, input_ids, attention_mask, labels, images, image_features=None):
+        """-> (packed embeds [total,H], lens [B], indices list[dict] or None)."""
+        lay = self._layout(input_ids.to(self.device), attention_mask, labels, self._n_feat(images, image_features))
+        if image_features is None and images is not None:
+            image_features = self.encode_images(images)
+        embeds = self._assemble(lay, self._dev_idx(lay), input_ids.to(self.device), image_features)
+        return embeds, lay["lens"], lay["indices"]
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes=None):
         """Reference-format wrapper (dynamic_llava_arch.py:169-178, 594-601): right-padded [B,N,H] embeds."""
         if self.get_vision_tower() is None or images is None or input_ids.shape[1] == 1:
             return (input_ids, position_ids, attention_mask, past_key_values, None, labels), (None,)
+        if labels is not None:
+            raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
         embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, labels, images)
         B, N = len(lens), max(lens)
         out = embeds.new_zeros((B, N, embeds.shape[-1]))
@@ -453,10 +516,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             new_pos = torch.zeros((B, N), dtype=position_ids.dtype, device=position_ids.device)
             for b, n in enumerate(lens):
                 new_pos[b, :n] = torch.arange(n, dtype=position_ids.dtype, device=position_ids.device)
-        new_labels = None
-        if labels is not None:
-            raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
-        return (None, new_pos, new_mask, past_key_values, out, new_labels), (indices,)
+        return (None, new_pos, new_mask, past_key_values, out, None), (indices,)
 
     # ---- decoder engine -----------------------------------------------------------------------
     def _check_ready(self):
@@ -466,32 +526,51 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if sc["use_text_predictor"] and sc["use_instruct_predictor"]:
             raise NotImplementedError("instruct-predictor branches (DML:2261-2375, 2506-2521) are SURVEY 8f row N2, not built yet")
 
-    def _prefill(self, embeds, lens, indices, cache: Optional[KVSlabCache], reserve: int, last_only: bool):
-        """Packed prefill.  Returns (normed hidden of [last rows | all rows], cache, lens_after)."""
+    def _plan_prefill(self, lens, indices):
+        """Everything about a prefill that the host knows up front (all shapes: k is the same for every row), plus the
+        device-side metadata tensors.  Built OUTSIDE hipGraph capture; `_prefill_run` is then pure device work."""
         cfg, sc = self.config, self.config.sparse_config
-        dev, dt = self.device, self.dtype
+        dev = self.device
         B = len(lens)
-        nH, nKV, d, H, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
-        eps = cfg.rms_norm_eps
-        L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
-        vision_on = bool(sc["use_vision_predictor"]) and indices is not None and all(i is not None for i in indices)
+        vision_on = bool(sc["use_vision_predictor"]) and indices is not None and all(i is not None for i in indices) and len(indices) == B
         n_img = k = 0
         if vision_on:
             n_img = indices[0]["image"][1] - indices[0]["image"][0]
             if any(i["image"][1] - i["image"][0] != n_img for i in indices):
                 raise NotImplementedError("all images must have the same token count (DML:1774-1778 assumes it too)")
             k = int(n_img * sc["vision_keep_rate"])  # DML:1899-1901
-        if cache is None:
-            cache = KVSlabCache(L, SL, B, nKV, d, max(lens) + reserve, dt, dev)
-        elif max(cache.full_len_host) != 0:
-            raise NotImplementedError("multi-token forward on a non-empty cache (new-instruct round, DML:2506-2521) is SURVEY 8f row N2")
-        cos, sin = self._rope_tables(max(lens) + reserve)
+        i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=dev)
         cu_list = [0]
         for n in lens:
             cu_list.append(cu_list[-1] + n)
-        cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
-        zeros_b = torch.zeros(B, dtype=torch.int32, device=dev)
-        total, max_len = cu_list[-1], max(lens)
+        p = dict(B=B, lens=list(lens), vision_on=vision_on, n_img=n_img, k=k, cu_list=cu_list, cu=i32(cu_list), zeros=i32([0] * B), max_len=max(lens))
+        lens2 = list(lens)
+        if vision_on:
+            lens2 = [n - (n_img - k) for n in lens]
+            cu2 = [0]
+            for n in lens2:
+                cu2.append(cu2[-1] + n)
+            p.update(cu2_list=cu2, cu2=i32(cu2), img_start=i32([ix["image"][0] for ix in indices]), max_len2=max(lens2))
+        else:
+            p.update(cu2_list=cu_list, cu2=p["cu"], max_len2=p["max_len"])
+        SL, L = sc["sparse_layer"], cfg.num_hidden_layers
+        p["lens2"] = lens2
+        p["lens_dev"] = i32([list(lens), lens2 if (SL < L) else list(lens)])
+        p["last_rows"] = torch.tensor([c - 1 for c in p["cu2_list"][1:]], dtype=torch.long, device=dev)
+        return p
+
+    def _prefill_run(self, p, embeds, cache: KVSlabCache, indices, last_only: bool):
+        """Packed prefill, device work only.  Returns the normed hidden state (all rows, or the last row of each sequence)."""
+        cfg, sc = self.config, self.config.sparse_config
+        dev, dt = self.device, self.dtype
+        B = p["B"]
+        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        eps = cfg.rms_norm_eps
+        L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
+        vision_on, n_img, k = p["vision_on"], p["n_img"], p["k"]
+        cos, sin = self._rope
+        cu, cu_list, max_len, total = p["cu"], p["cu_list"], p["max_len"], p["cu_list"][-1]
+        zeros_b = p["zeros"]
         pos = None  # layers < SL: position = in-row index
         h = embeds.to(dt).contiguous()
         if h.data_ptr() == embeds.data_ptr():
@@ -501,30 +580,18 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         for i, layer in enumerate(self.model.layers):
             if i == SL and vision_on:
                 # ---- F1..F5: predictor -> top-k -> compaction (DML:1826-1994) on the un-normed residual stream ----
-                img_start = torch.tensor([ix["image"][0] for ix in indices], dtype=torch.int32, device=dev)
                 vp = self.model.image_score_predictor
                 if len(vp._forward_hooks) or len(vp._forward_pre_hooks):  # keep the reference's hook point alive
                     dense = torch.stack([h[cu_list[b] + indices[b]["image"][0] : cu_list[b] + indices[b]["image"][1]] for b in range(B)])
                     logits = vp(dense, torch.ones(B, n_img, 1, dtype=dt, device=dev))
                     score = vp.last_score
                 else:
-                    logits, score = vp.score_packed(h, cu, img_start, n_img)
+                    logits, score = vp.score_packed(h, cu, p["img_start"], n_img)
                 keep = ops.topk_select(score, k)
-                new_lens = [n - (n_img - k) for n in lens]
-                cu2_list = [0]
-                for n in new_lens:
-                    cu2_list.append(cu2_list[-1] + n)
-                cu2 = torch.tensor(cu2_list, dtype=torch.int32, device=dev)
-                h, pos = ops.compact_tokens(h, keep, cu, cu2, img_start, n_img, k, cu2_list[-1])
+                h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, p["cu2_list"][-1])
                 if rec is not None:
-                    rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=cu2)
-                drop = n_img - k
-                for ix in indices:  # DML:1986-1994 -- the reference mutates the caller's dicts too
-                    ix["image"][1] -= drop
-                    for key in ("instruct", "last_instruct", "answer"):
-                        ix[key][0] -= drop
-                        ix[key][1] -= drop
-                lens, cu, cu_list, total, max_len = new_lens, cu2, cu2_list, cu2_list[-1], max(new_lens)
+                    rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=p["cu2"])
+                cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], p["cu2_list"][-1]
                 x = ops.rmsnorm(h, layer.input_layernorm.weight, eps)
             qkv = F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
@@ -540,19 +607,78 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 ops.add_rmsnorm(h, dn, None, eps)  # residual add only: layer SL's norm runs after compaction
             else:
                 x = ops.add_rmsnorm(h, dn, self.model.layers[i + 1].input_layernorm.weight, eps)
-        # lengths: layers < SL hold the full prompt, layers >= SL the compacted one
-        orig_lens = list(lens) if not vision_on else [n + (n_img - k) for n in lens]
-        cache.lens[0] = torch.tensor(orig_lens, dtype=torch.int32, device=dev)
-        cache.lens[1] = torch.tensor(lens if SL < L else orig_lens, dtype=torch.int32, device=dev)
-        cache.full_len_host = list(orig_lens)
-        cache.seen_tokens = max(orig_lens)
+        cache.lens.copy_(p["lens_dev"])  # layers < SL hold the full prompt, layers >= SL the compacted one
         if last_only:
-            last_rows = torch.tensor([c - 1 for c in cu_list[1:]], dtype=torch.long, device=dev)
-            x = x.index_select(0, last_rows)
-        return x, cache, lens, cu_list
+            x = x.index_select(0, p["last_rows"])
+        return x
+
+    def _prefill_host_update(self, p, cache, indices):
+        """Host mirrors of what `_prefill_run` did on the device (also the reference's in-place index shift, DML:1986-1994)."""
+        cache.full_len_host = list(p["lens"])
+        cache.seen_tokens = max(p["lens"])
+        if p["vision_on"]:
+            drop = p["n_img"] - p["k"]
+            for ix in indices:
+                ix["image"][1] -= drop
+                for key in ("instruct", "last_instruct", "answer"):
+                    ix[key][0] -= drop
+                    ix[key][1] -= drop
+
+    def _prefill(self, embeds, lens, indices, cache: Optional[KVSlabCache], reserve: int, last_only: bool):
+        """Eager packed prefill (forward() API and first-time shapes).  Returns (x, cache, lens_after, cu_after)."""
+        cfg, sc = self.config, self.config.sparse_config
+        p = self._plan_prefill(lens, indices)
+        if cache is None:
+            cache = KVSlabCache(cfg.num_hidden_layers, sc["sparse_layer"], p["B"], cfg.num_key_value_heads, cfg.head_dim, max(lens) + reserve, self.dtype, self.device)
+        elif max(cache.full_len_host) != 0:
+            raise NotImplementedError("multi-token forward on a non-empty cache (new-instruct round, DML:2506-2521) is SURVEY 8f row N2")
+        self._rope_tables(max(lens) + reserve)
+        x = self._prefill_run(p, embeds, cache, indices, last_only)
+        self._prefill_host_update(p, cache, indices)
+        return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
     def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
+        if st.use_gemv:
+            self._decode_step_gemv(st, cache)
+        else:
+            self._decode_step_gemm(st, cache)
+        if advance:
+            sc = self.config.sparse_config
+            use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and sc["sparse_layer"] < self.config.num_hidden_layers
+            ops.decode_advance(
+                st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, cache.len_full, cache.len_sparse,
+                st.decision if use_tp else None,
+            )
+
+    def _decode_step_gemv(self, st: _DecodeState, cache: KVSlabCache):
+        """Small-batch decode step: 5 weight-streaming launches per layer (dl_gemv with fused residual-add+RMSNorm /
+        SiLU*up prologues) + RoPE/KV append + split-KV attention.  The residual stream ping-pongs between st.h / st.h2."""
+        cfg, sc = self.config, self.config.sparse_config
+        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
+        cos, sin = self._rope
+        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
+        torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
+        h_cur, h_alt, delta = st.h, st.h2, None
+        A = ops.GEMV_ADDNORM
+        for i, layer in enumerate(self.model.layers):
+            ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
+            if delta is not None:
+                h_cur, h_alt = h_alt, h_cur
+            if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
+                self.model.output_text_score_predictor.decide(h_cur, st.tp_ws, st.tp_logits, st.decision)
+            lens = cache.len_of_layer(i)
+            ops.rope_kv_write(st.qkv, cos, sin, st.cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
+            ops.attn_decode(st.qkv[:, : nH * d], cache.k[i], cache.v[i], lens, 1, st.attn, st.attn_ws, st.n_splits, nH, nKV, d)
+            ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
+            ops.gemv(layer.w_gu, st.gu, mode=A, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
+            h_cur, h_alt = h_alt, h_cur
+            ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu, mode=ops.GEMV_SILUMUL)
+            delta = st.dn
+        ops.gemv(self.lm_head.weight, st.logits, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=self.model.norm.weight, eps=eps)
+
+    def _decode_step_gemm(self, st: _DecodeState, cache: KVSlabCache):
         cfg, sc = self.config, self.config.sparse_config
         nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
@@ -574,14 +700,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
         torch.matmul(st.x, self.lm_head.weight.t(), out=st.logits)
-        if advance:
-            ops.decode_advance(
-                st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, cache.len_full, cache.len_sparse,
-                st.decision if use_tp else None,
-            )
 
     def _pooled_cache(self, B, t_need):
-        """generate() owns its cache, so the slab is reused across calls: stable pointers keep the captured hipGraph valid."""
+        """generate() owns its cache, so the slab is reused across calls: stable pointers keep the captured hipGraphs valid."""
         cfg = self.config
         c = getattr(self, "_cache_pool", None)
         if c is None or c.batch != B or c.t_cap < t_need or c.dtype != self.dtype or c.sparse_layer != cfg.sparse_config["sparse_layer"]:
@@ -596,7 +717,21 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         st = self._dstate
         if st is None or st.B != B or st.out_ids.shape[1] < out_cap:
             st = self._dstate = _DecodeState(self, B, self.device, self.dtype, out_cap)
+            self._prefill_graphs = {}
         return st
+
+    @staticmethod
+    def _capture(fn, warm):
+        """Warm `fn` up on a side stream (lazy hipBLASLt / allocator state), then capture it into a hipGraph."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            warm()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
 
     def _run_decode_steps(self, st, cache, n_steps):
         """Enqueue n greedy steps (graph replay when enabled)."""
@@ -606,18 +741,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 self._decode_step_kernels(st, cache, True)
             return
         if st.graph is None or st.graph_key != key:
-            # warm-up on a side stream (hipBLASLt workspaces, lazy init), restoring the state it clobbers
+            # the warm-up executes one real step: snapshot / restore the state it advances
             snap = (st.cur_ids.clone(), st.out_ids.clone(), st.step.clone(), st.finished.clone(), cache.lens.clone(), st.decision.clone())
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
+
+            def warm():
                 self._decode_step_kernels(st, cache, True)
-            torch.cuda.current_stream().wait_stream(s)
+
+            g, _ = self._capture(lambda: self._decode_step_kernels(st, cache, True), warm)
             st.cur_ids.copy_(snap[0]); st.out_ids.copy_(snap[1]); st.step.copy_(snap[2]); st.finished.copy_(snap[3]); cache.lens.copy_(snap[4]); st.decision.copy_(snap[5])
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._decode_step_kernels(st, cache, True)
-            # capture does not execute; state is intact
             st.graph, st.graph_key = g, key
         for _ in range(n_steps):
             st.graph.replay()
@@ -650,7 +781,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 raise NotImplementedError("multi-token forward on a non-empty cache (DML:2506-2521) is SURVEY 8f row N2")
             B = input_ids.shape[0]
             st = self._get_dstate(B, 0)
-            grew = cache.ensure_capacity(2)
+            cache.ensure_capacity(2)
             self._rope_tables(max(cache.full_len_host) + 2)
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
@@ -667,21 +798,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # ---- prefill ----
         if inputs_embeds is not None:
             B, N = inputs_embeds.shape[:2]
-            if attention_mask is not None:
-                lens = attention_mask.sum(dim=1).tolist()
-            else:
-                lens = [N] * B
+            lens = [N] * B if attention_mask is None else attention_mask.sum(dim=1).tolist()
             embeds = torch.cat([inputs_embeds[b, : lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
             indices = input_embeds_indices
-        elif images is None and image_features is None:
-            B = input_ids.shape[0]
-            if attention_mask is not None:
-                lens = attention_mask.sum(dim=1).tolist()
-                embeds = torch.cat([self.model.embed_tokens(input_ids[b, : lens[b]]) for b in range(B)], dim=0)
-            else:
-                lens = [input_ids.shape[1]] * B
-                embeds = self.model.embed_tokens(input_ids.reshape(-1))
-            indices = None
         else:
             embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
         x, cache, lens2, cu_list = self._prefill(embeds, lens, indices, cache, reserve=256, last_only=False)
@@ -695,47 +814,86 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 logits[b, : lens2[b]] = logits_packed[cu_list[b] : cu_list[b + 1]]
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
 
+    def _first_token(self, st, x_last, min_new):
+        torch.matmul(x_last, self.lm_head.weight.t(), out=st.logits)
+        self._prefill_logits_buf.copy_(st.logits)
+        # first token: argmax only (the prompt's KV lengths are already in place)
+        eos_first = self._eos if min_new <= 0 else -1
+        ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, eos_first, self._pad, None, None, None)
+
     @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, **kwargs):
         """dynamic_llava_llama.py:117-152: greedy decoding; returns the NEW tokens only [B, T_new] (HF behaviour when
         generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens, min_new_tokens, do_sample(False),
         num_beams(1), use_cache(True), eos_token_id, pad_token_id, attention_mask, return_dict_in_generate,
-        image_features (pre-computed projector output, testing)."""
+        image_features (pre-computed projector output, testing).
+        Steady state (same prompt SHAPE as a previous call): the whole prefill -- CLIP, projector, embedding assembly,
+        32 layers, first-token argmax -- is one hipGraph replay and every decode step is another; the host only copies
+        the new token ids / pixels into static buffers."""
         self._check_ready()
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
-        if kwargs.get("do_sample", False) or (kwargs.get("temperature") or 0) > 0 and kwargs.get("do_sample", False):
+        if kwargs.get("do_sample", False):
             raise NotImplementedError("sampling is not built; the eval harness uses temperature 0 / greedy (model_vqa_loader.py:162-175)")
         if kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is not built (harness default num_beams=1)")
         max_new = kwargs.get("max_new_tokens")
-        if max_new is None:
-            max_new = 20 if kwargs.get("max_length") is None else None
         min_new = kwargs.get("min_new_tokens", 0) or 0
         eos = kwargs.get("eos_token_id", self.config.eos_token_id)
         pad = kwargs.get("pad_token_id", self.config.pad_token_id)
         attention_mask = kwargs.get("attention_mask")
+        image_features = kwargs.get("image_features")
         sync_every = int(kwargs.get("sync_every", 16))
-        if images is not None or kwargs.get("image_features") is not None:
-            embeds, lens, indices = self._prepare_packed(inputs, attention_mask, None, images, kwargs.get("image_features"))
-        else:
-            B = inputs.shape[0]
-            lens = [inputs.shape[1]] * B if attention_mask is None else attention_mask.sum(dim=1).tolist()
-            embeds = torch.cat([self.model.embed_tokens(inputs[b, : lens[b]]) for b in range(B)], dim=0)
-            indices = None
+        inputs = inputs.to(self.device)
+        lay = self._layout(inputs, attention_mask, None, self._n_feat(images, image_features))
+        lens, indices, B = lay["lens"], lay["indices"], lay["B"]
         if max_new is None:
-            max_new = kwargs["max_length"] - max(lens)
-        B = len(lens)
-        x, cache, _, _ = self._prefill(embeds, lens, indices, self._pooled_cache(B, max(lens) + max_new + 1), reserve=max_new + 1, last_only=True)
+            max_new = 20 if kwargs.get("max_length") is None else kwargs["max_length"] - max(lens)
+        cache = self._pooled_cache(B, max(lens) + max_new + 1)
+        self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)
         st.step.zero_(); st.finished.zero_(); st.decision.fill_(1)
         self._eos = -1 if eos is None else int(eos)
         self._pad = 0 if pad is None else int(pad)
-        torch.matmul(x, self.lm_head.weight.t(), out=st.logits)
-        self.last_prefill_logits = st.logits.to(torch.float32, copy=True)
-        # first token: argmax only (the prompt's KV lengths are already in place)
-        eos_first = self._eos if min_new <= 0 else -1
-        ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, eos_first, self._pad, None, None, None)
+        if getattr(self, "_prefill_logits_buf", None) is None or self._prefill_logits_buf.shape != st.logits.shape:
+            self._prefill_logits_buf = torch.empty(st.logits.shape, dtype=torch.float32, device=self.device)
+        vp = getattr(self.model, "image_score_predictor", None)
+        hooked = vp is not None and (len(vp._forward_hooks) or len(vp._forward_pre_hooks))
+        graphable = self.use_hip_graph and self.debug_records is None and not hooked
+        if graphable:
+            key = (lay["sig"], None if images is None else tuple(images.shape), None if image_features is None else tuple(image_features.shape),
+                   cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new > 0, repr(self.config.sparse_config), lay["text_src"][0] if lay["text_src"] else -1)
+            ent = self._prefill_graphs.get(key)
+            if ent is None:
+                if len(self._prefill_graphs) >= 8:
+                    self._prefill_graphs.pop(next(iter(self._prefill_graphs)))
+                ent = dict(ids=inputs.clone(), images=None if images is None else images.to(self.device).clone(),
+                           feats=None if image_features is None else image_features.to(self.device).clone(),
+                           plan=self._plan_prefill(lens, indices), didx=self._dev_idx(lay), indices=copy.deepcopy(indices))
+
+                def run():
+                    f = ent["feats"] if ent["feats"] is not None else (self.encode_images(ent["images"]) if ent["images"] is not None else None)
+                    emb = self._assemble(lay, ent["didx"], ent["ids"], f)
+                    x = self._prefill_run(ent["plan"], emb, cache, copy.deepcopy(ent["indices"]), True)
+                    self._first_token(st, x, min_new)
+
+                ent["graph"], _ = self._capture(run, run)
+                self._prefill_graphs[key] = ent
+            else:
+                ent["ids"].copy_(inputs)
+                if images is not None:
+                    ent["images"].copy_(images)
+                if image_features is not None:
+                    ent["feats"].copy_(image_features)
+            st.step.zero_(); st.finished.zero_()
+            ent["graph"].replay()
+            self._prefill_host_update(ent["plan"], cache, indices)
+        else:
+            f = image_features if image_features is not None else (self.encode_images(images) if images is not None else None)
+            embeds = self._assemble(lay, self._dev_idx(lay), inputs, f)
+            x, cache, _, _ = self._prefill(embeds, lens, indices, cache, reserve=max_new + 1, last_only=True)
+            self._first_token(st, x, min_new)
+        self.last_prefill_logits = self._prefill_logits_buf
         produced = 1
         while produced < max_new:
             n = min(sync_every, max_new - produced)

@@ -143,6 +143,22 @@ typedef struct dl_tp_weights {
 int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, int d_model, const dl_tp_weights* w,
                              void* workspace, float* logits_out, int32_t* decision, int dtype, void* stream);
 
+/* ---- decode-time weight streaming (B <= dl_gemv_max_batch rows): y[b,:] = cast(W @ x[b,:]), W [N,K] nn.Linear layout.
+ * Replaces, for small B, the torch GEMMs of DML:1011-1013 (q/k/v_proj, fused), DML:1127 (o_proj), DML:328
+ * (gate|up fused, down_proj) and DML:2709 (lm_head); the element-wise op in front of each becomes its prologue:
+ *   DL_GEMV_PLAIN   x [B, x_row_stride] as given
+ *   DL_GEMV_ADDNORM x = norm_w * cast(hn * rsqrt(mean(hn^2) + eps)), hn = cast(h_in + delta)  (DML:1289/1295 + 134-139);
+ *                   hn is written to h_out (a buffer distinct from h_in; h_in, h_out: [B,K] contiguous).
+ *                   delta == NULL: hn = h_in, h_out is not written.
+ *   DL_GEMV_SILUMUL x = cast(cast(silu(g)) * u), g = x[b, 0:K], u = x[b, K:2K]   (DML:328)
+ * y: [B, y_row_stride].  K % 8 == 0. */
+#define DL_GEMV_PLAIN 0
+#define DL_GEMV_ADDNORM 1
+#define DL_GEMV_SILUMUL 2
+int dl_gemv_max_batch(int K, int dtype);
+int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_stride, const void* h_in, void* h_out,
+            const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, void* stream);
+
 /* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
  * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;
  * out_ids[b, step[b]] = next[b]; ++step[b]; kv_len_full[b] += 1; kv_len_sparse[b] += decision ? decision[b] : 1.

@@ -305,7 +305,7 @@ class Oracle:
             e = torch.cat([sys_e, img_e, ins_e, ans_e])
             new_embeds.append(e)
             new_labels.append(
-                torch.cat([cl[:img_pos], torch.full((img_e.shape[0],), IGNORE_INDEX, dtype=cl.dtype), cl[ins0:ans0], cl[ans0:]])
+                torch.cat([cl[:img_pos], torch.full((img_e.shape[0],), IGNORE_INDEX, dtype=cl.dtype, device=cl.device), cl[ins0:ans0], cl[ans0:]])
             )
             # ARCH:418-454 -- last "USER:" occurrence inside the instruct span
             ins_list = ins_ids.tolist()
@@ -320,16 +320,17 @@ class Oracle:
         max_len = max(x.shape[0] for x in new_embeds)
         B = len(new_embeds)
         padded = []
-        lab_p = torch.full((B, max_len), IGNORE_INDEX, dtype=new_labels[0].dtype)
-        am = torch.zeros((B, max_len), dtype=attention_mask.dtype)
-        pid = torch.zeros((B, max_len), dtype=position_ids.dtype)
+        dev = new_labels[0].device
+        lab_p = torch.full((B, max_len), IGNORE_INDEX, dtype=new_labels[0].dtype, device=dev)
+        am = torch.zeros((B, max_len), dtype=attention_mask.dtype, device=dev)
+        pid = torch.zeros((B, max_len), dtype=position_ids.dtype, device=dev)
         for i, (e, l) in enumerate(zip(new_embeds, new_labels)):  # right padding (ARCH:558-577)
             n = e.shape[0]
             padded.append(torch.cat((e, torch.zeros((max_len - n, e.shape[1]), dtype=e.dtype, device=e.device)), dim=0))
             if n > 0:
                 lab_p[i, :n] = l
                 am[i, :n] = True
-                pid[i, :n] = torch.arange(0, n, dtype=pid.dtype)
+                pid[i, :n] = torch.arange(0, n, dtype=pid.dtype, device=dev)
         embeds = torch.stack(padded, dim=0)
         return (
             None,
@@ -476,7 +477,7 @@ class Oracle:
         if trace is not None:
             trace.append(dict(logits=logits[:, -1].clone(), **{k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.records.items()}))
         out = []
-        unfinished = torch.ones(B, dtype=torch.long)
+        unfinished = torch.ones(B, dtype=torch.long, device=logits.device)
         for step in range(max_new_tokens):
             nxt = logits[:, -1, :].argmax(dim=-1)
             if eos_token_id is not None:

@@ -29,11 +29,16 @@ def ops():
     return hip_ops
 
 
-def _close_ulp(a, b, dtype, n_ulp=1.0, atol=0.0):
+def _close_ulp(a, b, dtype, n_ulp=1.0, atol=0.0, mag=None):
+    """|a-b| <= n_ulp * ulp(dtype) * max(|a|,|b|[,mag]) + atol.  `mag`: magnitude of the operands of a final add
+    (after cancellation the result's own magnitude is not the relevant scale)."""
     if dtype == torch.float32:
         n_ulp = max(n_ulp, 8.0)  # fp32: rsqrt / summation-order differences of a few ulp; 16-bit results absorb them
     a, b = a.float().cpu(), b.float().cpu()
-    tol = n_ulp * ULP[dtype] * torch.maximum(a.abs(), b.abs()) + atol
+    scale = torch.maximum(a.abs(), b.abs())
+    if mag is not None:
+        scale = torch.maximum(scale, mag.float().cpu().abs())
+    tol = n_ulp * ULP[dtype] * scale + atol
     bad = (a - b).abs() > tol
     assert not bad.any(), f"{int(bad.sum())} / {a.numel()} elements differ by more than {n_ulp} ulp; max abs diff {float((a - b).abs().max())}"
 
@@ -252,8 +257,45 @@ def test_linear_epilogues(ops, dtype, M, N, K, flags):
     out = ops.linear(a.cuda(), w.cuda(), bias.cuda(), flags, residual=rd if flags & 2 else None, out=rd if flags & 2 else None)
     # fp32 accumulate in a different order than the fp32 reference: <= 1 ulp of the output dtype after rounding
     # (the residual epilogue rounds twice, so a 1-ulp flip before the add can surface as 2 ulp after it)
-    _close_ulp(out, ref, dtype, 2.0 if flags & 2 else 1.0, atol=1e-4 if dtype == torch.float32 else 1e-3)
+    _close_ulp(out, ref, dtype, 2.0 if flags & 2 else 1.0, atol=1e-4 if dtype == torch.float32 else 1e-3, mag=r if flags & 2 else None)
     assert _frac_exact(out, ref, dtype) > 0.97
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B", [1, 3])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (22016, 4096), (4096, 11008), (1000, 256), (37, 512)])
+def test_gemv_modes(ops, dtype, B, N, K):
+    """dl_gemv against the eager op sequence it replaces (fp32 evaluation of the same rounded operands)."""
+    g = torch.Generator().manual_seed(16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    wd = w.cuda()
+    # PLAIN
+    x = torch.randn(B, K, generator=g).to(dtype)
+    y = torch.empty(B, N, dtype=dtype, device="cuda")
+    ops.gemv(wd, y, x=x.cuda())
+    ref = F.linear(x.float(), w.float()).to(dtype)
+    _close_ulp(y, ref, dtype, 1.0, atol=1e-4 if dtype == torch.float32 else 2e-3)
+    # ADDNORM (+ residual write-back to a distinct buffer)
+    h = torch.randn(B, K, generator=g).to(dtype)
+    dl = torch.randn(B, K, generator=g).to(dtype)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(dtype)
+    h_out = torch.zeros(B, K, dtype=dtype, device="cuda")
+    ops.gemv(wd, y, mode=ops.GEMV_ADDNORM, h_in=h.cuda(), h_out=h_out, delta=dl.cuda(), norm_w=nw.cuda(), eps=1e-5)
+    hn = h + dl
+    assert torch.equal(h_out.cpu(), hn)
+    ref = F.linear(orc.rmsnorm(hn, nw, 1e-5).float(), w.float()).to(dtype)
+    _close_ulp(y, ref, dtype, 2.0, atol=2e-4 if dtype == torch.float32 else 2e-2)  # a 1-ulp flip in x moves a K-term dot by ~ulp*|w||x|
+    ops.gemv(wd, y, mode=ops.GEMV_ADDNORM, h_in=h.cuda(), h_out=None, delta=None, norm_w=nw.cuda(), eps=1e-5)
+    ref = F.linear(orc.rmsnorm(h, nw, 1e-5).float(), w.float()).to(dtype)
+    _close_ulp(y, ref, dtype, 2.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
+    # SILUMUL
+    gu = torch.randn(B, 2 * K, generator=g).to(dtype)
+    ops.gemv(wd, y, x=gu.cuda(), mode=ops.GEMV_SILUMUL)
+    act = F.silu(gu[:, :K]) * gu[:, K:]
+    ref = F.linear(act.float(), w.float()).to(dtype)
+    _close_ulp(y, ref, dtype, 2.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
+    with pytest.raises(ops.HipOpsError):
+        ops.gemv(wd, y, mode=ops.GEMV_ADDNORM, h_in=h_out, h_out=h_out, delta=dl.cuda(), norm_w=nw.cuda())  # in-place residual is a race
 
 
 def _vp_sd(cfg, seed, gain):
