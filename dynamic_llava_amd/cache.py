@@ -65,6 +65,13 @@ class KVSlabCache:
         # exact host mirror of lens[0] (advances by one per token for every row) -> capacity checks without a sync
         self.full_len_host: List[int] = [0] * batch
         self.seen_tokens = 0
+        self.sparse_cap = self.t_cap  # host-known upper bound of lens[1] (set by the prefill: t_cap minus the dropped image tokens)
+
+    def n_splits(self, layer_idx: int, rows_times_heads: int, keys_per_wg: int = 512, max_splits: int = 32) -> int:
+        """Split-KV factor for the fused decode attention: one 1024-thread workgroup digests ~512 keys in two passes, so a
+        row only needs splitting when its (host-known upper bound) length exceeds that."""
+        cap = self.t_cap if self.group(layer_idx) == 0 else min(self.sparse_cap, self.t_cap)
+        return max(1, min(max_splits, -(-cap // keys_per_wg)))
 
     # ---- which length vector a layer uses ----
     def group(self, layer_idx: int) -> int:
@@ -90,6 +97,7 @@ class KVSlabCache:
         new = torch.empty((self.n_layers, 2, self.batch, self.n_kv_heads, new_cap, self.head_dim), dtype=self.dtype, device=self.device)
         new[:, :, :, :, : self.t_cap, :] = self.slab
         self.slab = new
+        self.sparse_cap += new_cap - self.t_cap
         self.t_cap = new_cap
         self.k = [self.slab[i, 0] for i in range(self.n_layers)]
         self.v = [self.slab[i, 1] for i in range(self.n_layers)]

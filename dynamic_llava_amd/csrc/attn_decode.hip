@@ -12,18 +12,29 @@
 
 namespace dl {
 
-constexpr int kDecThreads = 256;
 constexpr int kDecUnroll = 4;
 
-template <typename T, int D>
-__global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
-    const void* __restrict__ q_, int64_t q_row_stride, const void* __restrict__ k_slab_, const void* __restrict__ v_slab_,
-    int64_t stride_b, int64_t stride_h, const int32_t* __restrict__ kv_len, int extra, float* __restrict__ ws,
-    void* __restrict__ out_, int64_t out_row_stride, int n_rep, float scale) {
+// FUSED: the RoPE of q and of the new key (DML:260-285) and the KV-slab append (CU:109-268) happen inside the attention
+// kernel: q|k|v are read un-rotated from the projection output, the new token's rotated key / value are used from
+// registers by the one lane group that owns key index kv_len[b] and written to slab slot kv_len[b] for later steps.
+template <typename T, bool UPPER>
+__device__ __forceinline__ void rope16(const float (&own)[Elem<T>::kVec], const float (&par)[Elem<T>::kVec], const float (&cs)[Elem<T>::kVec],
+                                       const float (&sn)[Elem<T>::kVec], float (&out)[Elem<T>::kVec]) {
+#pragma unroll
+  for (int i = 0; i < Elem<T>::kVec; ++i)  // x*cos + rotate_half(x)*sin, each op rounded (DML:283-284); rotate_half = cat(-x2, x1)
+    out[i] = Elem<T>::round(Elem<T>::round(own[i] * cs[i]) + Elem<T>::round((UPPER ? par[i] : -par[i]) * sn[i]));
+}
+
+template <typename T, int D, int NW, bool FUSED>
+__global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
+    const void* __restrict__ q_, int64_t q_row_stride, const void* k_slab_, const void* v_slab_, int64_t stride_b, int64_t stride_h,
+    const int32_t* __restrict__ kv_len, int extra, float* __restrict__ ws, void* __restrict__ out_, int64_t out_row_stride, int n_rep,
+    float scale, const void* __restrict__ cos_, const void* __restrict__ sin_, int n_pos, const int32_t* __restrict__ pos_base, int T_cap,
+    int n_kv_heads) {
   constexpr int V = Elem<T>::kVec;
   constexpr int LPK = D / V;          // lanes per key
   constexpr int KPW = 64 / LPK;       // keys per wave per load instruction
-  constexpr int NG = 4 * KPW;         // lane groups per workgroup
+  constexpr int NG = NW * KPW;        // lane groups per workgroup
   constexpr int U = kDecUnroll;
   using S = typename Elem<T>::storage;
   __shared__ float sm_m[NG], sm_l[NG];
@@ -33,15 +44,32 @@ __global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
   const int n_heads = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane / LPK, c = (lane % LPK) * V;
-  const int Tn = kv_len[b] + extra;
+  const int kvh = h / n_rep;
+  const int T_old = kv_len[b];
+  const int Tn = T_old + (FUSED ? 1 : extra);
   int chunk = (Tn + n_splits - 1) / n_splits;
   chunk = (chunk + NG - 1) / NG * NG;
   const int k0 = split * chunk;
-  const int k1 = min(Tn, k0 + chunk);
+  const int k1s = min(Tn, k0 + chunk);               // this split's keys [k0, k1s)
+  const int k1 = FUSED ? min(k1s, T_old) : k1s;      // ... of which [k0, k1) are read from the slab
 
   float qv[V];
-  load16<T>(reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride + (int64_t)h * D + c, qv);
-  const int kvh = h / n_rep;
+  float cs[V], sn[V];
+  const S* row = reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride;
+  constexpr int HALF = D / 2;
+  const int cpar = c < HALF ? c + HALF : c - HALF;
+  if constexpr (FUSED) {
+    int p = pos_base[b];
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
+    load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
+    float own[V], par[V];
+    load16<T>(row + (int64_t)h * D + c, own);
+    load16<T>(row + (int64_t)h * D + cpar, par);
+    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
+  } else {
+    load16<T>(row + (int64_t)h * D + c, qv);
+  }
   const S* kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
   const S* vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
 
@@ -49,13 +77,13 @@ __global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
 #pragma unroll
   for (int i = 0; i < V; ++i) o[i] = 0.f;
 
-  // keys of this workgroup are dealt round-robin: key = base + (u * 4 + wid) * KPW + g
+  // keys of this workgroup are dealt round-robin: key = base + (u * NW + wid) * KPW + g
   for (int base = k0; base < k1; base += NG * U) {
     float kx[U][V], vx[U][V];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int key = base + (u * 4 + wid) * KPW + g;
+      const int key = base + (u * NW + wid) * KPW + g;
       ok[u] = key < k1;
       const int64_t off = (int64_t)(ok[u] ? key : k0) * D;
       load16<T>(kb + off, kx[u]);
@@ -90,6 +118,37 @@ __global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
     }
   }
 
+  if constexpr (FUSED) {
+    // the new token (key index T_old): owned by lane group (wave 0, g 0) of the split whose range contains it
+    if (T_old >= k0 && T_old < k1s && wid == 0 && g == 0) {
+      float own[V], par[V], kn[V], vn[V];
+      const S* krow = row + (int64_t)(n_heads + kvh) * D;
+      load16<T>(krow + c, own);
+      load16<T>(krow + cpar, par);
+      if (c < HALF) rope16<T, false>(own, par, cs, sn, kn); else rope16<T, true>(own, par, cs, sn, kn);
+      load16<T>(row + (int64_t)(n_heads + n_kv_heads + kvh) * D + c, vn);
+      if (h % n_rep == 0 && T_old < T_cap) {  // one writer per kv head; eviction = the length is simply not advanced later
+        S* kd = const_cast<S*>(kb) + (int64_t)T_old * D;
+        S* vd = const_cast<S*>(vb) + (int64_t)T_old * D;
+        store16<T>(kd, kn);
+        store16<T>(vd, vn);
+      }
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) a += qv[i] * kn[i];
+#pragma unroll
+      for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
+      const float sc_ = a * scale;
+      const float mn = fmaxf(m, sc_);
+      const float alpha = __expf(m - mn);
+      const float p = __expf(sc_ - mn);
+      l = l * alpha + p;
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = o[i] * alpha + p * vn[i];
+      m = mn;
+    }
+  }
+
   // merge the NG lane groups of this workgroup
   const int gg = wid * KPW + g;
   if ((lane % LPK) == 0) {
@@ -101,11 +160,11 @@ __global__ __launch_bounds__(kDecThreads) void attn_decode_split_kernel(
   __syncthreads();
   if (tid < D) {
     float M = -INFINITY;
-#pragma unroll
+#pragma unroll 8
     for (int i = 0; i < NG; ++i) M = fmaxf(M, sm_m[i]);
     float L = 0.f, O = 0.f;
     if (M > -INFINITY) {
-#pragma unroll
+#pragma unroll 8
       for (int i = 0; i < NG; ++i) {
         const float w = __expf(sm_m[i] - M);  // empty group: exp(-inf) = 0
         L += sm_l[i] * w;
@@ -167,18 +226,18 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
   store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + d, L > 0.f ? O / L : 0.f);
 }
 
-template <typename T, int D>
-static int launch_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t stride_b,
-                         int64_t stride_h, const int32_t* kv_len, int extra, void* out, int64_t out_row_stride, void* workspace,
-                         int n_splits, int B, int n_heads, int n_kv_heads, hipStream_t st) {
+template <typename T, int D, int NW, bool FUSED>
+static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t stride_b, int64_t stride_h,
+                         const int32_t* kv_len, int extra, void* out, int64_t out_row_stride, void* workspace, int n_splits, int B,
+                         int n_heads, int n_kv_heads, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base,
+                         int T_cap, hipStream_t st) {
   const float scale = 1.0f / sqrtf((float)D);
-  hipLaunchKernelGGL((attn_decode_split_kernel<T, D>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(kDecThreads), 0,
+  hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, FUSED>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64), 0,
                      st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,
-                     out_row_stride, n_heads / n_kv_heads, scale);
+                     out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads);
   if (n_splits > 1)
     hipLaunchKernelGGL((attn_decode_combine_kernel<T, D>), dim3((unsigned)n_heads, (unsigned)B), dim3(D), 0, st,
                        reinterpret_cast<const float*>(workspace), out, out_row_stride, n_splits);
-  return 0;
 }
 
 }  // namespace dl
@@ -202,12 +261,34 @@ extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k
   hipStream_t st = as_stream(stream);
   DL_DISPATCH_DTYPE(dtype, T, {
     if (head_dim == 128)
-      launch_decode<T, 128>(q, q_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, extra, out, out_row_stride,
-                            workspace, n_splits, B, n_heads, n_kv_heads, st);
+      launch_split<T, 128, 4, false>(q, q_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, extra, out, out_row_stride,
+                                     workspace, n_splits, B, n_heads, n_kv_heads, nullptr, nullptr, 0, nullptr, 0, st);
     else
-      launch_decode<T, 64>(q, q_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, extra, out, out_row_stride,
-                           workspace, n_splits, B, n_heads, n_kv_heads, st);
+      launch_split<T, 64, 4, false>(q, q_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, extra, out, out_row_stride,
+                                    workspace, n_splits, B, n_heads, n_kv_heads, nullptr, nullptr, 0, nullptr, 0, st);
   });
   DL_CHECK_LAUNCH("dl_attn_decode");
+  return DL_OK;
+}
+
+extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
+                                   const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
+                                   int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
+                                   int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && out, "dl_attn_decode_rope: NULL pointer");
+  DL_REQUIRE(B > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && n_pos > 0, "dl_attn_decode_rope: bad shape");
+  DL_REQUIRE(n_splits >= 1 && n_splits <= kMaxSplits, "dl_attn_decode_rope: n_splits=%d must be in [1, %d]", n_splits, kMaxSplits);
+  DL_REQUIRE(n_splits == 1 || workspace, "dl_attn_decode_rope: workspace required when n_splits > 1");
+  DL_REQUIRE(head_dim == 128 || head_dim == 64, "dl_attn_decode_rope: head_dim=%d unsupported (64 or 128)", head_dim);
+  hipStream_t st = as_stream(stream);
+  DL_DISPATCH_DTYPE(dtype, T, {
+    if (head_dim == 128)
+      launch_split<T, 128, 16, true>(qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride,
+                                     workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, st);
+    else
+      launch_split<T, 64, 16, true>(qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride,
+                                    workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, st);
+  });
+  DL_CHECK_LAUNCH("dl_attn_decode_rope");
   return DL_OK;
 }

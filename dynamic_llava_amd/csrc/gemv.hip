@@ -19,10 +19,9 @@ constexpr int kGemvThreads = 256;
 constexpr int kGemvR = 2;       // neurons per wave per pass
 constexpr int kGemvMaxB = 8;
 
+// raw 16-byte chunk -> kVec floats
 template <typename T>
-__device__ __forceinline__ void load16_nt(const void* p, float (&f)[Elem<T>::kVec]) {
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  const u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));  // global_load_dwordx4 ... nt
+__device__ __forceinline__ void unpack16(const uint4& r, float (&f)[Elem<T>::kVec]) {
   if constexpr (Elem<T>::kVec == 4) {
     f[0] = __uint_as_float(r.x);
     f[1] = __uint_as_float(r.y);
@@ -37,8 +36,16 @@ __device__ __forceinline__ void load16_nt(const void* p, float (&f)[Elem<T>::kVe
     }
   }
 }
+__device__ __forceinline__ uint4 ldg_nt(const void* p) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));  // global_load_dwordx4 ... nt
+  return make_uint4(r.x, r.y, r.z, r.w);
+}
 
-template <typename T, int B, int MODE>
+// MODE: prologue (0 plain, 1 add+rmsnorm, 2 silu*up).  PAIR: the wave's R=2 neurons are (n, n + N/2) and the output is
+// cast(cast(silu(y_n)) * y_{n+N/2}) -> y [B, N/2]  (gate|up fused weight: DML:328 computed in the epilogue).
+// R neurons per wave per pass, U 16-byte chunks per neuron in flight  =>  R*U independent loads per lane.
+template <typename T, int B, int MODE, bool PAIR, int R, int U>
 __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restrict__ W_, int N, int K, const void* x_, int64_t x_rs,
                                                             const void* __restrict__ h_, void* __restrict__ h_out_,
                                                             const void* __restrict__ delta_, const void* __restrict__ nw_,
@@ -108,94 +115,150 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
 
   // ---- stream the weights ----
   const S* W = reinterpret_cast<const S*>(W_);
-  const int groups = (N + 4 * kGemvR - 1) / (4 * kGemvR);
+  const int n_out = PAIR ? N / 2 : N;                 // neurons indexed by the wave
+  constexpr int RW = PAIR ? 1 : R;                    // wave-owned output neurons per pass (PAIR: one act = two rows)
+  const int groups = (n_out + 4 * RW - 1) / (4 * RW);
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    const int n0 = grp * 4 * kGemvR + wid * kGemvR;
-    float acc[kGemvR][B];
+    const int n0 = grp * 4 * RW + wid * RW;
+    float acc[R][B];
+    const S* wp[R];
 #pragma unroll
-    for (int r = 0; r < kGemvR; ++r)
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
-    const S* w0 = W + (int64_t)(n0 < N ? n0 : N - 1) * K;
-    const S* w1 = W + (int64_t)(n0 + 1 < N ? n0 + 1 : N - 1) * K;
+      int n = PAIR ? (n0 + r * n_out) : (n0 + r);
+      n = n < N ? n : N - 1;
+      if (PAIR && n0 >= n_out) n = r * n_out;
+      wp[r] = W + (int64_t)n * K;
+    }
     int v = lane;
-    for (; v + 192 < nvec; v += 256) {  // 4 chunks x 2 rows = 8 independent 16-byte loads in flight per lane
-      float wa[4][V], wb[4][V];
+    for (; v + 64 * (U - 1) < nvec; v += 64 * U) {
+      uint4 raw[R][U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        load16_nt<T>(w0 + (v + 64 * u) * V, wa[u]);
-        load16_nt<T>(w1 + (v + 64 * u) * V, wb[u]);
-      }
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int r = 0; r < R; ++r) raw[r][u] = ldg_nt(wp[r] + (v + 64 * u) * V);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float wf[R][V];
+#pragma unroll
+        for (int r = 0; r < R; ++r) unpack16<T>(raw[r][u], wf[r]);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
           float xv[V];
           load16<T>(xs + b * K + (v + 64 * u) * V, xv);
 #pragma unroll
-          for (int e = 0; e < V; ++e) {
-            acc[0][b] = fmaf(wa[u][e], xv[e], acc[0][b]);
-            acc[1][b] = fmaf(wb[u][e], xv[e], acc[1][b]);
-          }
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[r][b] = fmaf(wf[r][e], xv[e], acc[r][b]);
         }
+      }
     }
     for (; v < nvec; v += 64) {
-      float wa[V], wb[V];
-      load16_nt<T>(w0 + v * V, wa);
-      load16_nt<T>(w1 + v * V, wb);
+      uint4 raw[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) raw[r] = ldg_nt(wp[r] + v * V);
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         float xv[V];
         load16<T>(xs + b * K + v * V, xv);
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          acc[0][b] = fmaf(wa[e], xv[e], acc[0][b]);
-          acc[1][b] = fmaf(wb[e], xv[e], acc[1][b]);
+        for (int r = 0; r < R; ++r) {
+          float wf[V];
+          unpack16<T>(raw[r], wf);
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[r][b] = fmaf(wf[e], xv[e], acc[r][b]);
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < kGemvR; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const float a = wave_sum(acc[r][b]);
-        if (lane == 0 && n0 + r < N) store1<T>(y_, (int64_t)b * y_rs + n0 + r, a);
+      for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+    if (lane == 0) {
+      if constexpr (PAIR) {
+        if (n0 < n_out) {
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            const float g = Elem<T>::round(acc[0][b]), u = Elem<T>::round(acc[1][b]);
+            store1<T>(y_, (int64_t)b * y_rs + n0, Elem<T>::round(g / (1.0f + expf(-g))) * u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int b = 0; b < B; ++b)
+            if (n0 + r < N) store1<T>(y_, (int64_t)b * y_rs + n0 + r, acc[r][b]);
       }
+    }
   }
+}
+
+// tuning knobs (dl_gemv_set_tuning): variant = 0:(R2,U4) 1:(R4,U2) 2:(R2,U8) 3:(R1,U8) 4:(R4,U4); PAIR kernels always use R=2.
+static int g_gemv_grid_cap = 512;  // tools/bench_gemv.py sweep: 2 workgroups per CU is at or near the optimum for every decode shape
+static int g_gemv_variant = 0;
+
+template <typename T, int B, int MODE, bool PAIR, int R, int U>
+static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
+                   const void* nw, float eps, void* y, int64_t y_rs, hipStream_t st) {
+  const size_t smem = (size_t)B * K * Elem<T>::kBytes;
+  const int n_out = PAIR ? N / 2 : N;
+  const int per = 4 * (PAIR ? 1 : R);
+  const int groups = (n_out + per - 1) / per;
+  const int grid = groups < g_gemv_grid_cap ? groups : g_gemv_grid_cap;
+  auto kfn = gemv_kernel<T, B, MODE, PAIR, R, U>;
+  if (smem > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
+        (void)hipGetLastError();  // do not leave a sticky error behind
+        set_error("dl_gemv: cannot raise the dynamic LDS limit to 152 KiB");
+        return DL_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kGemvThreads), smem, st, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs);
+  return DL_OK;
+}
+
+template <typename T, int B, int MODE>
+static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
+                        const void* nw, float eps, void* y, int64_t y_rs, hipStream_t st) {
+#define DL_ARGS W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st
+  if (pair) return g_gemv_variant == 2 ? gemv_go<T, B, MODE, true, 2, 8>(DL_ARGS) : gemv_go<T, B, MODE, true, 2, 4>(DL_ARGS);
+  if (B > 4) return gemv_go<T, B, MODE, false, 2, 4>(DL_ARGS);  // keep the instantiation count (and VGPRs) bounded for larger B
+  switch (g_gemv_variant) {
+    case 1: return gemv_go<T, B, MODE, false, 4, 2>(DL_ARGS);
+    case 2: return gemv_go<T, B, MODE, false, 2, 8>(DL_ARGS);
+    case 3: return gemv_go<T, B, MODE, false, 1, 8>(DL_ARGS);
+    case 4: return gemv_go<T, B, MODE, false, 4, 4>(DL_ARGS);
+    default: return gemv_go<T, B, MODE, false, 2, 4>(DL_ARGS);
+  }
+#undef DL_ARGS
 }
 
 template <typename T, int B>
 static int gemv_launch(int mode, const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta, const void* nw,
                        float eps, void* y, int64_t y_rs, hipStream_t st) {
-  const size_t smem = (size_t)B * K * Elem<T>::kBytes;
-  const int groups = (N + 4 * kGemvR - 1) / (4 * kGemvR);
-  const int grid = groups < 2048 ? groups : 2048;
-#define DL_GEMV_GO(MODE)                                                                                                       \
-  {                                                                                                                            \
-    auto kfn = gemv_kernel<T, B, MODE>;                                                                                        \
-    if (smem > 64 * 1024) {                                                                                                    \
-      static bool attr_set = false;                                                                                            \
-      if (!attr_set) {                                                                                                         \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) { \
-          (void)hipGetLastError(); /* do not leave a sticky error behind */                                                    \
-          set_error("dl_gemv: cannot raise the dynamic LDS limit to 152 KiB");                                                 \
-          return DL_ERR_LAUNCH;                                                                                                \
-        }                                                                                                                      \
-        attr_set = true;                                                                                                       \
-      }                                                                                                                        \
-    }                                                                                                                          \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kGemvThreads), smem, st, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs); \
-  }
-  if (mode == DL_GEMV_ADDNORM) DL_GEMV_GO(1)
-  else if (mode == DL_GEMV_SILUMUL) DL_GEMV_GO(2)
-  else DL_GEMV_GO(0)
-#undef DL_GEMV_GO
-  return DL_OK;
+  const bool pair = (mode & DL_GEMV_OUT_SILU_PAIR) != 0;
+  const int pro = mode & 3;
+  if (pro == DL_GEMV_ADDNORM) return gemv_variant<T, B, 1>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st);
+  if (pro == DL_GEMV_SILUMUL) return gemv_variant<T, B, 2>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st);
+  return gemv_variant<T, B, 0>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st);
 }
 
 }  // namespace dl
 
 using namespace dl;
+
+extern "C" int dl_gemv_set_tuning(int grid_cap, int variant) {
+  DL_REQUIRE(grid_cap >= 1 && variant >= 0 && variant <= 4, "dl_gemv_set_tuning: bad arguments");
+  g_gemv_grid_cap = grid_cap;
+  g_gemv_variant = variant;
+  return DL_OK;
+}
 
 extern "C" int dl_gemv_max_batch(int K, int dtype) {
   const int es = dtype == DL_F32 ? 4 : 2;
@@ -208,14 +271,16 @@ extern "C" int dl_gemv(int mode, const void* W, int N, int K, const void* x, int
   const void* h = h_in;
   DL_REQUIRE(W && y, "dl_gemv: NULL pointer");
   DL_REQUIRE(N > 0 && K > 0 && B > 0, "dl_gemv: bad shape");
-  DL_REQUIRE(mode == DL_GEMV_PLAIN || mode == DL_GEMV_ADDNORM || mode == DL_GEMV_SILUMUL, "dl_gemv: bad mode %d", mode);
-  DL_REQUIRE(mode == DL_GEMV_ADDNORM ? (h && norm_w) : (x != nullptr), "dl_gemv: missing operand for mode %d", mode);
-  DL_REQUIRE(!(mode == DL_GEMV_ADDNORM && delta) || (h_out && h_out != h_in), "dl_gemv: h_out must be a distinct buffer when delta is given");
+  const int pro = mode & 3;
+  DL_REQUIRE((mode & ~(3 | DL_GEMV_OUT_SILU_PAIR)) == 0 && pro <= DL_GEMV_SILUMUL, "dl_gemv: bad mode %d", mode);
+  DL_REQUIRE(!(mode & DL_GEMV_OUT_SILU_PAIR) || N % 2 == 0, "dl_gemv: SILU_PAIR needs an even N");
+  DL_REQUIRE(pro == DL_GEMV_ADDNORM ? (h && norm_w) : (x != nullptr), "dl_gemv: missing operand for mode %d", mode);
+  DL_REQUIRE(!(pro == DL_GEMV_ADDNORM && delta) || (h_out && h_out != h_in), "dl_gemv: h_out must be a distinct buffer when delta is given");
   DL_REQUIRE(B <= dl_gemv_max_batch(K, dtype), "dl_gemv: B=%d rows of K=%d do not fit in LDS (max %d)", B, K, dl_gemv_max_batch(K, dtype));
   hipStream_t st = as_stream(stream);
   int rc = DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
-    DL_REQUIRE(K % Elem<T>::kVec == 0 && (mode == DL_GEMV_ADDNORM || x_row_stride % Elem<T>::kVec == 0), "dl_gemv: K / strides must be multiples of %d", Elem<T>::kVec);
+    DL_REQUIRE(K % Elem<T>::kVec == 0 && (pro == DL_GEMV_ADDNORM || x_row_stride % Elem<T>::kVec == 0), "dl_gemv: K / strides must be multiples of %d", Elem<T>::kVec);
     switch (B) {
       case 1: rc = gemv_launch<T, 1>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
       case 2: rc = gemv_launch<T, 2>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;

@@ -60,6 +60,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
+    "dl_attn_decode_rope": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -71,6 +75,7 @@ SIGNATURES = {
     ),
     "dl_text_predictor_decide": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, POINTER(TpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
+    "dl_gemv_set_tuning": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
@@ -224,6 +229,22 @@ def attn_decode(q, k_slab, v_slab, kv_len, extra, out, workspace, n_splits, n_he
     return out
 
 
+def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, workspace, n_splits, n_heads, n_kv_heads, head_dim):
+    """Fused RoPE + KV append + ragged decode attention.  qkv [B, (nH+2nKV)*d] un-rotated (not modified)."""
+    _dev(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out)
+    assert qkv.stride(1) == 1 and out.stride(1) == 1 and kv_len.dtype == torch.int32 and pos_base.dtype == torch.int32
+    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
+    B = qkv.shape[0]
+    _check(
+        lib().dl_attn_decode_rope(
+            _p(qkv), qkv.stride(0), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(0), k_slab.stride(1),
+            k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), B, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
+        ),
+        "dl_attn_decode_rope",
+    )
+    return out
+
+
 def topk_select(score, k):
     _dev(score)
     assert score.is_contiguous() and score.dim() == 2
@@ -301,7 +322,7 @@ def text_predictor_decide(x, weights: TpWeights, d_model, workspace, logits_out,
     return decision
 
 
-GEMV_PLAIN, GEMV_ADDNORM, GEMV_SILUMUL = 0, 1, 2
+GEMV_PLAIN, GEMV_ADDNORM, GEMV_SILUMUL, GEMV_OUT_SILU_PAIR = 0, 1, 2, 16
 
 
 def gemv_max_batch(K, dtype):
@@ -314,7 +335,7 @@ def gemv(w, y, x=None, mode=GEMV_PLAIN, h_in=None, h_out=None, delta=None, norm_
     assert w.is_contiguous() and y.stride(1) == 1
     N, K = w.shape
     B = y.shape[0]
-    if mode == GEMV_ADDNORM:
+    if (mode & 3) == GEMV_ADDNORM:
         assert h_in.is_contiguous() and h_in.shape == (B, K) and (delta is None or (delta.is_contiguous() and h_out.is_contiguous()))
         xs = 0
     else:

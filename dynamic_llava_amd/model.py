@@ -319,7 +319,7 @@ class _DecodeState:
         self.x = torch.empty((B, H), dtype=dtype, device=device)
         self.qkv = torch.empty((B, (nH + 2 * nKV) * d), dtype=dtype, device=device)
         self.o = torch.empty((B, H), dtype=dtype, device=device)
-        self.gu = torch.empty((B, 2 * I), dtype=dtype, device=device)
+        self.gu = torch.empty((B, I), dtype=dtype, device=device)  # act = silu(gate)*up, produced by the gate|up GEMV epilogue
         self.dn = torch.empty((B, H), dtype=dtype, device=device)
         # weight-streaming GEMV path for small decode batches (else torch/hipBLASLt GEMMs)
         self.use_gemv = B <= min(model.gemv_max_decode_batch, ops.gemv_max_batch(I, dtype), ops.gemv_max_batch(H, dtype))
@@ -328,7 +328,7 @@ class _DecodeState:
         self.logits = torch.empty((B, V), dtype=dtype, device=device)
         # split-KV: enough workgroups to cover the chip (256 CUs) without drowning in partials
         self.n_splits = max(1, min(32, 1024 // max(1, B * nH)))
-        self.attn_ws = ops.attn_decode_workspace(B, nH, d, self.n_splits, device)
+        self.attn_ws = ops.attn_decode_workspace(B, nH, d, 32, device)
         self.graph = None
         self.graph_key = None
 
@@ -616,6 +616,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         """Host mirrors of what `_prefill_run` did on the device (also the reference's in-place index shift, DML:1986-1994)."""
         cache.full_len_host = list(p["lens"])
         cache.seen_tokens = max(p["lens"])
+        cache.sparse_cap = cache.t_cap - (max(p["lens"]) - max(p["lens2"]))  # host-known upper bound of the evicted group's lengths
         if p["vision_on"]:
             drop = p["n_img"] - p["k"]
             for ix in indices:
@@ -669,12 +670,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 self.model.output_text_score_predictor.decide(h_cur, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
-            ops.rope_kv_write(st.qkv, cos, sin, st.cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
-            ops.attn_decode(st.qkv[:, : nH * d], cache.k[i], cache.v[i], lens, 1, st.attn, st.attn_ws, st.n_splits, nH, nKV, d)
+            # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
+            # only when the row is long enough to need more than one workgroup per head)
+            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d)
             ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
-            ops.gemv(layer.w_gu, st.gu, mode=A, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
+            ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
             h_cur, h_alt = h_alt, h_cur
-            ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu, mode=ops.GEMV_SILUMUL)
+            ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
             delta = st.dn
         ops.gemv(self.lm_head.weight, st.logits, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=self.model.norm.weight, eps=eps)
 
@@ -735,7 +737,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
     def _run_decode_steps(self, st, cache, n_steps):
         """Enqueue n greedy steps (graph replay when enabled)."""
-        key = (cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, repr(self.config.sparse_config))
+        key = (cache.slab.data_ptr(), cache.t_cap, cache.sparse_cap, self._rope[0].data_ptr(), self._eos, self._pad, repr(self.config.sparse_config))
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)

@@ -87,6 +87,15 @@ int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, cons
                    void* out, int64_t out_row_stride, void* workspace, int n_splits,
                    int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
 
+/* ---- F8 + F10 + F9 (decode) in ONE launch: RoPE of q and of the new key (DML:260-285), the KV append of the new token at
+ * slot kv_len[b] (CU:109-268) and the ragged attention over keys [0, kv_len[b]] (DML:1061-1122).
+ * qkv: [B, qkv_row_stride] UN-rotated projection output (q heads | k heads | v heads), not modified.
+ * pos_base[b]: RoPE position of the new token.  Same split-KV scheme as dl_attn_decode with 1024-thread workgroups. */
+int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
+                        const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab,
+                        int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride,
+                        void* workspace, int n_splits, int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
+
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
  * (= stable descending sort; the reference's argsort is non-stable).  n <= 4096. */
@@ -151,11 +160,17 @@ int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, 
  *                   hn is written to h_out (a buffer distinct from h_in; h_in, h_out: [B,K] contiguous).
  *                   delta == NULL: hn = h_in, h_out is not written.
  *   DL_GEMV_SILUMUL x = cast(cast(silu(g)) * u), g = x[b, 0:K], u = x[b, K:2K]   (DML:328)
+ * mode may be OR-ed with DL_GEMV_OUT_SILU_PAIR: W is a fused gate|up weight [2I,K] and the EPILOGUE emits
+ *   y[b,i] = cast(cast(silu(cast(W_i . x))) * cast(W_{I+i} . x)), y [B, I]   (DML:328 without materialising gate|up).
  * y: [B, y_row_stride].  K % 8 == 0. */
 #define DL_GEMV_PLAIN 0
 #define DL_GEMV_ADDNORM 1
 #define DL_GEMV_SILUMUL 2
+#define DL_GEMV_OUT_SILU_PAIR 16
 int dl_gemv_max_batch(int K, int dtype);
+/* tuning knob (process-global, not thread-safe; defaults are the tuned ones): workgroup cap and load-schedule variant
+ * 0:(2 neurons x 4 chunks in flight per wave) 1:(4x2) 2:(2x8) 3:(1x8) 4:(4x4). */
+int dl_gemv_set_tuning(int grid_cap, int variant);
 int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_stride, const void* h_in, void* h_out,
             const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, void* stream);
 

@@ -240,6 +240,44 @@ def test_attn_decode_ragged(ops, dtype, nH, nKV, d, n_splits):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nH,nKV,d", [(32, 32, 128), (8, 2, 128), (4, 4, 64)])
+@pytest.mark.parametrize("n_splits", [1, 3])
+def test_attn_decode_rope_fused_equals_unfused(ops, dtype, nH, nKV, d, n_splits):
+    """dl_attn_decode_rope == dl_rope_kv_write followed by dl_attn_decode: identical slab contents (bit-exact RoPE / append),
+    outputs equal up to the summation order of the online softmax."""
+    g = torch.Generator().manual_seed(17)
+    kv_len = [0, 16, 170, 631, 65, 1023]
+    B, T_cap = len(kv_len), 1100
+    pos = [5, 40, 631, 700, 65, 2000]  # RoPE position of the new token (the un-evicted count), != slot index after eviction
+    k0 = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    v0 = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    qkv = torch.randn(B, (nH + 2 * nKV) * d, generator=g).to(dtype)
+    cos, sin = orc.rope_table(d, 2048, 10000.0, dtype)
+    lens = torch.tensor(kv_len, dtype=torch.int32).cuda()
+    posd = torch.tensor(pos, dtype=torch.int32).cuda()
+    # un-fused reference path
+    ka, va, qa = k0.cuda().clone(), v0.cuda().clone(), qkv.cuda().clone()
+    cu = torch.arange(0, B + 1, dtype=torch.int32).cuda()
+    ops.rope_kv_write(qa, cos.cuda(), sin.cuda(), cu, None, posd, lens, ka, va, nH, nKV, d)
+    out_a = torch.empty(B, nH * d, dtype=dtype, device="cuda")
+    ws = ops.attn_decode_workspace(B, nH, d, 8, "cuda")
+    ops.attn_decode(qa[:, : nH * d], ka, va, lens, 1, out_a, ws, 4, nH, nKV, d)
+    # fused path
+    kb, vb, qb = k0.cuda().clone(), v0.cuda().clone(), qkv.cuda().clone()
+    out_b = torch.full((B, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_decode_rope(qb, cos.cuda(), sin.cuda(), posd, lens, kb, vb, out_b, ws, n_splits, nH, nKV, d)
+    assert torch.equal(qb.cpu(), qkv), "the fused kernel must not modify qkv"
+    assert torch.equal(ka, kb) and torch.equal(va, vb), "slab contents (rotated key / value at slot kv_len[b]) must be bit-identical"
+    tol = 2e-5 if dtype == torch.float32 else 2 * ULP[dtype]
+    assert float((out_a.float() - out_b.float()).abs().max()) < tol
+    for b in range(B):  # and against an fp32 SDPA evaluation of the same rounded operands
+        T = kv_len[b] + 1
+        ref = _sdpa_ref(qa[b].cpu()[: nH * d].view(1, nH, d), ka[b, :, :T].cpu().transpose(0, 1), va[b, :, :T].cpu().transpose(0, 1), False)[0]
+        err = float((out_b[b].cpu().float().view(nH, d) - ref).abs().max())
+        assert err < (2e-5 if dtype == torch.float32 else 3 * ULP[dtype]), (b, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(576, 512, 4096), (36, 128, 256), (100, 1536, 512), (70, 32, 64), (1, 2048, 512)])
 @pytest.mark.parametrize("flags", [0, 1, 2, 3])
 def test_linear_epilogues(ops, dtype, M, N, K, flags):
@@ -296,6 +334,19 @@ def test_gemv_modes(ops, dtype, B, N, K):
     _close_ulp(y, ref, dtype, 2.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
     with pytest.raises(ops.HipOpsError):
         ops.gemv(wd, y, mode=ops.GEMV_ADDNORM, h_in=h_out, h_out=h_out, delta=dl.cuda(), norm_w=nw.cuda())  # in-place residual is a race
+    # SILU_PAIR epilogue on a fused gate|up weight: act = silu(W[:I] x) * (W[I:] x), every tuning variant
+    if N % 2 == 0:
+        I = N // 2
+        gu_ref = F.linear(x.float(), w.float()).to(dtype)
+        ref = F.silu(gu_ref[:, :I]) * gu_ref[:, I:]
+        for variant in range(5):
+            ops.lib().dl_gemv_set_tuning(512, variant)
+            act = torch.empty(B, I, dtype=dtype, device="cuda")
+            ops.gemv(wd, act, x=x.cuda(), mode=ops.GEMV_OUT_SILU_PAIR)
+            _close_ulp(act, ref, dtype, 4.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
+            ops.gemv(wd, y, x=x.cuda())
+            _close_ulp(y, gu_ref, dtype, 1.0, atol=1e-4 if dtype == torch.float32 else 2e-3)
+        ops.lib().dl_gemv_set_tuning(512, 0)
 
 
 def _vp_sd(cfg, seed, gain):
