@@ -107,12 +107,22 @@ def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim):
     out = torch.empty((B, H), device=dev, dtype=dt)
     lens = torch.tensor([t - 1 for t in T_list], dtype=torch.int32, device=dev)
     cos, sin = model._rope_tables(T_cap + 1)
-    n_splits = max(1, min(32, -(-T_cap // 512)))
+    n_splits = max(1, min(32, max(1, 256 // (B * n_heads)), -(-T_cap // 64)))  # same rule as KVSlabCache.n_splits
     ws = ops.attn_decode_workspace(B, n_heads, head_dim, 32, dev)
-    ms = graph_time_ms(lambda: ops.attn_decode_rope(qkv, cos, sin, lens, lens, k, v, out, ws, n_splits, n_heads, n_heads, head_dim))
+    # rotate over several slabs so that, as in the real decode step (13 GB of weights streamed in between), K/V come from HBM
+    n_buf = 8 if k.numel() * 4 < 200e6 else 1
+    ks = [k] + [torch.randn_like(k) for _ in range(n_buf - 1)]
+    vs = [v] + [torch.randn_like(v) for _ in range(n_buf - 1)]
+    it = [0]
+
+    def launch():
+        i = it[0] = (it[0] + 1) % n_buf
+        ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, ws, n_splits, n_heads, n_heads, head_dim)
+
+    ms = graph_time_ms(launch)
     nbytes = sum(2 * t * H * 2 + 2 * H * 2 for t in T_list)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    name = "dl_attn_decode_rope (attn_decode_split_kernel<.,128,16,fused>" + (" + attn_decode_combine_kernel)" if n_splits > 1 else ")")
+    name = "dl_attn_decode_rope (attn_decode_split_kernel<bf16,128,4,fused>" + (" + attn_decode_combine_kernel)" if n_splits > 1 else ")")
     return {"kernel": name, "shape": label, "n_splits": n_splits, "bytes": nbytes, "us": round(ms * 1e3, 3), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
@@ -274,6 +284,7 @@ def main():
     cfg = DynamicLlavaConfig(num_hidden_layers=args.layers)  # LLaVA-1.5-7B defaults, sparse_layer=2, keep 0.2
     model = build_random_model(cfg, dtype=dtype, device=device, seed=0, predictor_gain=args.predictor_gain)
     model.use_hip_graph = not args.no_graph
+    model.tp_side_stream = os.environ.get("DL_TP_SIDE", "0") == "1"
     prompt, images = make_inputs(cfg, device, dtype)
     n_prompt = N_SYS + N_IMG + N_Q
     T_new = args.new_tokens

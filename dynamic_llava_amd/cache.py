@@ -67,11 +67,12 @@ class KVSlabCache:
         self.seen_tokens = 0
         self.sparse_cap = self.t_cap  # host-known upper bound of lens[1] (set by the prefill: t_cap minus the dropped image tokens)
 
-    def n_splits(self, layer_idx: int, rows_times_heads: int, keys_per_wg: int = 512, max_splits: int = 32) -> int:
-        """Split-KV factor for the fused decode attention: one 1024-thread workgroup digests ~512 keys in two passes, so a
-        row only needs splitting when its (host-known upper bound) length exceeds that."""
+    def n_splits(self, layer_idx: int, rows_times_heads: int, max_splits: int = 32) -> int:
+        """Split-KV factor of the decode attention (tools/bench_attn_decode.py sweep): enough workgroups to cover the 256 CUs
+        (rows x heads x splits >= 256), never fewer than ~64 keys per workgroup, judged on the host-known length bound."""
         cap = self.t_cap if self.group(layer_idx) == 0 else min(self.sparse_cap, self.t_cap)
-        return max(1, min(max_splits, -(-cap // keys_per_wg)))
+        want = max(1, 256 // max(1, rows_times_heads))
+        return max(1, min(max_splits, want, -(-cap // 64)))
 
     # ---- which length vector a layer uses ----
     def group(self, layer_idx: int) -> int:

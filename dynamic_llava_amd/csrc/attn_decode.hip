@@ -274,21 +274,23 @@ extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k
 extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
                                    const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
                                    int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
-                                   int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream) {
+                                   int wg_waves, int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(wg_waves == 4 || wg_waves == 16, "dl_attn_decode_rope: wg_waves must be 4 or 16");
   DL_REQUIRE(qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && out, "dl_attn_decode_rope: NULL pointer");
   DL_REQUIRE(B > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && n_pos > 0, "dl_attn_decode_rope: bad shape");
   DL_REQUIRE(n_splits >= 1 && n_splits <= kMaxSplits, "dl_attn_decode_rope: n_splits=%d must be in [1, %d]", n_splits, kMaxSplits);
   DL_REQUIRE(n_splits == 1 || workspace, "dl_attn_decode_rope: workspace required when n_splits > 1");
   DL_REQUIRE(head_dim == 128 || head_dim == 64, "dl_attn_decode_rope: head_dim=%d unsupported (64 or 128)", head_dim);
   hipStream_t st = as_stream(stream);
+#define DL_FUSED_ARGS qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride, workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, st
   DL_DISPATCH_DTYPE(dtype, T, {
-    if (head_dim == 128)
-      launch_split<T, 128, 16, true>(qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride,
-                                     workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, st);
-    else
-      launch_split<T, 64, 16, true>(qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride,
-                                    workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, st);
+    if (head_dim == 128) {
+      if (wg_waves == 16) launch_split<T, 128, 16, true>(DL_FUSED_ARGS); else launch_split<T, 128, 4, true>(DL_FUSED_ARGS);
+    } else {
+      if (wg_waves == 16) launch_split<T, 64, 16, true>(DL_FUSED_ARGS); else launch_split<T, 64, 4, true>(DL_FUSED_ARGS);
+    }
   });
+#undef DL_FUSED_ARGS
   DL_CHECK_LAUNCH("dl_attn_decode_rope");
   return DL_OK;
 }

@@ -313,6 +313,8 @@ class _DecodeState:
         self.decision = torch.ones(B, dtype=torch.int32, device=device)
         self.tp_logits = torch.zeros((B, 2), dtype=torch.float32, device=device)
         self.tp_ws = torch.empty(B * cfg.sparse_config["d_model"], dtype=torch.float32, device=device)
+        self.tp_x = torch.empty((B, H), dtype=dtype, device=device)  # snapshot of the hidden state entering layer `sparse_layer`
+        self.tp_stream = torch.cuda.Stream(device=device)  # the predictor runs beside layers >= sparse_layer (graph fork/join)
         self.cu = torch.arange(0, B + 1, dtype=torch.int32, device=device)
         self.h = torch.empty((B, H), dtype=dtype, device=device)
         self.h2 = torch.empty((B, H), dtype=dtype, device=device)  # residual ping-pong partner (dl_gemv ADDNORM)
@@ -347,6 +349,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._dstate = None
         self._prefill_graphs = {}
         self.use_hip_graph = True
+        self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
         self.gemv_max_decode_batch = 4  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
         self.eval()
@@ -668,7 +671,15 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if delta is not None:
                 h_cur, h_alt = h_alt, h_cur
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
-                self.model.output_text_score_predictor.decide(h_cur, st.tp_ws, st.tp_logits, st.decision)
+                # only the end-of-step length advance consumes the decision: run the predictor on a side stream (a parallel
+                # branch of the captured graph) on a snapshot of the residual stream, off the layer chain's critical path
+                if self.tp_side_stream:
+                    st.tp_x.copy_(h_cur)
+                    st.tp_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st.tp_stream):
+                        self.model.output_text_score_predictor.decide(st.tp_x, st.tp_ws, st.tp_logits, st.decision)
+                else:
+                    self.model.output_text_score_predictor.decide(h_cur, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
             # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
             # only when the row is long enough to need more than one workgroup per head)
@@ -679,6 +690,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
             delta = st.dn
         ops.gemv(self.lm_head.weight, st.logits, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=self.model.norm.weight, eps=eps)
+        if use_tp and self.tp_side_stream:
+            torch.cuda.current_stream().wait_stream(st.tp_stream)  # join before anything reads st.decision
 
     def _decode_step_gemm(self, st: _DecodeState, cache: KVSlabCache):
         cfg, sc = self.config, self.config.sparse_config
@@ -693,8 +706,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
             qkv = F.linear(st.x, layer.w_qkv)
-            ops.rope_kv_write(qkv, cos, sin, st.cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
-            ops.attn_decode(qkv[:, : nH * d], cache.k[i], cache.v[i], lens, 1, st.attn, st.attn_ws, st.n_splits, nH, nKV, d)
+            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d)
             o = F.linear(st.attn, layer.self_attn.o_proj.weight)
             ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x)
             ops.silu_mul(F.linear(st.x, layer.w_gu), out=st.act)

@@ -90,11 +90,13 @@ int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, cons
 /* ---- F8 + F10 + F9 (decode) in ONE launch: RoPE of q and of the new key (DML:260-285), the KV append of the new token at
  * slot kv_len[b] (CU:109-268) and the ragged attention over keys [0, kv_len[b]] (DML:1061-1122).
  * qkv: [B, qkv_row_stride] UN-rotated projection output (q heads | k heads | v heads), not modified.
- * pos_base[b]: RoPE position of the new token.  Same split-KV scheme as dl_attn_decode with 1024-thread workgroups. */
+ * pos_base[b]: RoPE position of the new token.  Same split-KV scheme as dl_attn_decode; wg_waves = 4 or 16 waves per
+ * workgroup (256 / 1024 threads). */
 int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
                         const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab,
                         int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride,
-                        void* workspace, int n_splits, int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
+                        void* workspace, int n_splits, int wg_waves, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
+                        void* stream);
 
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
