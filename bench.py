@@ -328,6 +328,16 @@ def main():
         decode_attn_roofline(model, "configs[4]-like: 13B heads (40x128), B=1, T=2048", 1, [2048], 40, d),
         decode_attn_roofline(model, "B=32, T=2048", 32, [2048] * 32, nH, d),
     ] + gemv_roofline(model) + other_kernel_rooflines(model, n_prompt)
+    traffic, traffic_src = None, None
+    try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_probe.py under rocprofv3 --pmc, see profiles/)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = {r["case"]: r for r in json.load(f)}
+        r = pmc["decode_attn B=1 T=226"]
+        traffic = int((r["fetch_bytes_corrected"] + r["write_bytes"]) * roof_main["bytes"] / r["algorithmic_bytes"])
+        traffic_src = (f"profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes, "
+                       f"measured traffic/algorithmic = {r['traffic_over_algorithmic']} at B=1 T=226, scaled to this launch's algorithmic bytes")
+    except Exception:
+        pass
     res = {
         "metric": "prefill+decode tokens/s/GPU, LLaVA-1.5-7B @ vision_keep_rate=0.2, 1 img",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -341,7 +351,7 @@ def main():
                    "prefill_tokens_per_s": round(n_prompt / pre_ms * 1e3, 1), "decode_tokens_per_s": round(1e3 / dec_ms, 1),
                    "kv_len_full": t_full, "kv_len_sparse": t_sparse,
                    "decode_weight_stream_GBps": round(sum(p.numel() * p.element_size() for n, p in model.named_parameters() if ".layers." in n or n.startswith("lm_head")) / dec_ms / 1e6, 1)},
-        "roofline": {"bound": "hbm", "achieved": roof_main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_main["frac"], "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": roof_main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_main["frac"], "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": roof_main["kernel"], "shape": roof_main["shape"], "bytes_per_launch": roof_main["bytes"], "us_per_launch": roof_main["us"]},
         "roofline_kernels": extra,
     }

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Launches the HBM-bound kernels on known shapes so that a `rocprofv3 --kernel-trace --pmc <counter>` pass can attribute
+FETCH_SIZE / WRITE_SIZE to them (one counter group per pass, no other trace domains).  Prints the algorithmic bytes per
+launch as JSON so that tools/pmc_report.py can put measured traffic next to them."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dynamic_llava_amd import hip_ops as ops
+from oracle.ref_cpu import rope_table
+
+dev, dt = "cuda", torch.bfloat16
+nH, d = 32, 128
+H = nH * d
+cos, sin = (t.to(dev) for t in rope_table(d, 4096, 10000.0, dt))
+plan = []
+
+
+def attn(tag, B, Ts, ns):
+    T_cap = max(Ts) + 1
+    lens = torch.tensor([t - 1 for t in Ts], dtype=torch.int32, device=dev)
+    qkv = torch.randn(B, 3 * H, device=dev, dtype=dt)
+    out = torch.empty(B, H, device=dev, dtype=dt)
+    ws = ops.attn_decode_workspace(B, nH, d, 32, dev)
+    for rep in range(3):  # fresh slabs every launch: cold in L2 / Infinity Cache
+        k = torch.randn(B, nH, T_cap, d, device=dev, dtype=dt)
+        v = torch.randn_like(k)
+        torch.cuda.synchronize()
+        ops.attn_decode_rope(qkv, cos, sin, lens, lens, k, v, out, ws, ns, nH, nH, d)
+        torch.cuda.synchronize()
+    plan.append({"tag": tag, "kernel": "attn_decode_split_kernel", "grid_x": ns, "B": B, "algorithmic_bytes": sum(2 * t * H * 2 + 2 * H * 2 for t in Ts)})
+
+
+attn("decode_attn B=1 T=226", 1, [226], 8)
+attn("decode_attn B=1 T=695", 1, [695], 8)
+attn("decode_attn B=32 ragged", 32, [200 + (i * 701) % 700 for i in range(32)], 1)
+attn("decode_attn B=32 T=2048", 32, [2048] * 32, 1)
+
+for tag, N, K, mode in [("gemv qkv", 12288, 4096, ops.GEMV_ADDNORM), ("gemv o", 4096, 4096, ops.GEMV_PLAIN), ("gemv gate_up", 22016, 4096, ops.GEMV_ADDNORM | ops.GEMV_OUT_SILU_PAIR), ("gemv down", 4096, 11008, ops.GEMV_PLAIN)]:
+    pair = bool(mode & ops.GEMV_OUT_SILU_PAIR)
+    y = torch.empty(1, N // 2 if pair else N, device=dev, dtype=dt)
+    x = torch.randn(1, K, device=dev, dtype=dt)
+    h, h2, dl = (torch.randn(1, K, device=dev, dtype=dt) for _ in range(3))
+    nw = torch.ones(K, device=dev, dtype=dt)
+    for rep in range(3):
+        w = torch.randn(N, K, device=dev, dtype=dt)
+        torch.cuda.synchronize()
+        if (mode & 3) == ops.GEMV_ADDNORM:
+            ops.gemv(w, y, mode=mode, h_in=h, h_out=h2, delta=dl, norm_w=nw, eps=1e-5)
+        else:
+            ops.gemv(w, y, x=x)
+        torch.cuda.synchronize()
+    plan.append({"tag": tag, "kernel": "gemv_kernel", "N": N, "K": K, "algorithmic_bytes": N * K * 2})
+
+for rows in (631, 170):
+    x = torch.randn(rows, H, device=dev, dtype=dt)
+    w = torch.ones(H, device=dev, dtype=dt)
+    for rep in range(3):
+        x = torch.randn(rows, H, device=dev, dtype=dt)
+        torch.cuda.synchronize()
+        ops.rmsnorm(x, w, 1e-5)
+        torch.cuda.synchronize()
+    plan.append({"tag": f"rmsnorm [{rows},{H}]", "kernel": "rmsnorm_kernel", "rows": rows, "algorithmic_bytes": 2 * rows * H * 2 + H * 2})
+print("PLAN " + json.dumps(plan))
