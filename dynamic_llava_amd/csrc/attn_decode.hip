@@ -25,6 +25,23 @@ __device__ __forceinline__ void rope16(const float (&own)[Elem<T>::kVec], const 
     out[i] = Elem<T>::round(Elem<T>::round(own[i] * cs[i]) + Elem<T>::round((UPPER ? par[i] : -par[i]) * sn[i]));
 }
 
+template <typename T>
+__device__ __forceinline__ void unpack_kv(const uint4& r, float (&f)[Elem<T>::kVec]) {
+  if constexpr (Elem<T>::kVec == 4) {
+    f[0] = __uint_as_float(r.x);
+    f[1] = __uint_as_float(r.y);
+    f[2] = __uint_as_float(r.z);
+    f[3] = __uint_as_float(r.w);
+  } else {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = Elem<T>::to_f((uint16_t)(w[i] & 0xffffu));
+      f[2 * i + 1] = Elem<T>::to_f((uint16_t)(w[i] >> 16));
+    }
+  }
+}
+
 template <typename T, int D, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     const void* __restrict__ q_, int64_t q_row_stride, const void* k_slab_, const void* v_slab_, int64_t stride_b, int64_t stride_h,
@@ -53,25 +70,48 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
   const int k1s = min(Tn, k0 + chunk);               // this split's keys [k0, k1s)
   const int k1 = FUSED ? min(k1s, T_old) : k1s;      // ... of which [k0, k1) are read from the slab
 
-  float qv[V];
-  float cs[V], sn[V];
   const S* row = reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride;
+  const S* kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
+  const S* vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
   constexpr int HALF = D / 2;
   const int cpar = c < HALF ? c + HALF : c - HALF;
+
+  // ---- every load that does not depend on another load is issued up front, K/V first: a dependent HBM round trip costs
+  // ~1.5 us here, so the kernel's latency is (number of round trips), not bytes.  Chain: kv_len -> {K,V,q,cos,sin,new k/v}. ----
+  uint4 kraw[U], vraw[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int key = k0 + (u * NW + wid) * KPW + g;
+    ok[u] = key < k1;
+    const int64_t off = (int64_t)(ok[u] ? key : (k0 < k1 ? k0 : 0)) * D;
+    kraw[u] = *reinterpret_cast<const uint4*>(kb + off);
+    vraw[u] = *reinterpret_cast<const uint4*>(vb + off);
+  }
+  float qv[V], cs[V], sn[V];
+  const bool owns_new = FUSED && T_old >= k0 && T_old < k1s && wid == 0 && g == 0;
+  float kn[V], vn[V];
   if constexpr (FUSED) {
     int p = pos_base[b];
     p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    float own[V], par[V], kown[V], kpar[V];
     load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
     load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
-    float own[V], par[V];
     load16<T>(row + (int64_t)h * D + c, own);
     load16<T>(row + (int64_t)h * D + cpar, par);
+    if (owns_new) {
+      const S* krow = row + (int64_t)(n_heads + kvh) * D;
+      load16<T>(krow + c, kown);
+      load16<T>(krow + cpar, kpar);
+      load16<T>(row + (int64_t)(n_heads + n_kv_heads + kvh) * D + c, vn);
+    }
     if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
+    if (owns_new) {
+      if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
+    }
   } else {
     load16<T>(row + (int64_t)h * D + c, qv);
   }
-  const S* kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
-  const S* vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
 
   float m = -INFINITY, l = 0.f, o[V];
 #pragma unroll
@@ -80,14 +120,20 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
   // keys of this workgroup are dealt round-robin: key = base + (u * NW + wid) * KPW + g
   for (int base = k0; base < k1; base += NG * U) {
     float kx[U][V], vx[U][V];
-    bool ok[U];
+    if (base != k0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int key = base + (u * NW + wid) * KPW + g;
+        ok[u] = key < k1;
+        const int64_t off = (int64_t)(ok[u] ? key : k0) * D;
+        kraw[u] = *reinterpret_cast<const uint4*>(kb + off);
+        vraw[u] = *reinterpret_cast<const uint4*>(vb + off);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int key = base + (u * NW + wid) * KPW + g;
-      ok[u] = key < k1;
-      const int64_t off = (int64_t)(ok[u] ? key : k0) * D;
-      load16<T>(kb + off, kx[u]);
-      load16<T>(vb + off, vx[u]);
+      unpack_kv<T>(kraw[u], kx[u]);
+      unpack_kv<T>(vraw[u], vx[u]);
     }
     float s[U];
 #pragma unroll
@@ -120,13 +166,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
 
   if constexpr (FUSED) {
     // the new token (key index T_old): owned by lane group (wave 0, g 0) of the split whose range contains it
-    if (T_old >= k0 && T_old < k1s && wid == 0 && g == 0) {
-      float own[V], par[V], kn[V], vn[V];
-      const S* krow = row + (int64_t)(n_heads + kvh) * D;
-      load16<T>(krow + c, own);
-      load16<T>(krow + cpar, par);
-      if (c < HALF) rope16<T, false>(own, par, cs, sn, kn); else rope16<T, true>(own, par, cs, sn, kn);
-      load16<T>(row + (int64_t)(n_heads + n_kv_heads + kvh) * D + c, vn);
+    if (owns_new) {
       if (h % n_rep == 0 && T_old < T_cap) {  // one writer per kv head; eviction = the length is simply not advanced later
         S* kd = const_cast<S*>(kb) + (int64_t)T_old * D;
         S* vd = const_cast<S*>(vb) + (int64_t)T_old * D;
@@ -186,41 +226,39 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
 
 constexpr int kMaxSplits = 128;
 
-// Merge the split partials of one (row, head).  All (m, l) pairs are fetched in parallel into LDS first, and the
-// O-partials are read with independent (unrolled) loads: the partials were written by other CUs a few hundred
-// nanoseconds ago, so every dependent load here is a full L2/fabric round trip.
+// Merge the split partials of one (row, head).  The partials were written by other CUs a microsecond ago, so every dependent
+// load is a full fabric round trip: all (m, l, o) values of up to 8 splits are requested at once (one round trip).
 template <typename T, int D>
 __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ ws, void* __restrict__ out_,
                                                                 int64_t out_row_stride, int n_splits) {
-  __shared__ float sw[kMaxSplits];
-  __shared__ float sl[kMaxSplits];
   const int h = blockIdx.x, b = blockIdx.y, n_heads = gridDim.x, d = threadIdx.x;
   const float* p = ws + ((int64_t)b * n_heads + h) * n_splits * (D + 2);
-  for (int s = d; s < n_splits; s += D) {
-    sw[s] = p[s * (D + 2)];
-    sl[s] = p[s * (D + 2) + 1];
-  }
-  __syncthreads();
-  float M = -INFINITY;
-  for (int s = 0; s < n_splits; ++s) M = fmaxf(M, sw[s]);
-  float L = 0.f, O = 0.f;
-  if (M > -INFINITY) {
-    int s = 0;
-    for (; s + 8 <= n_splits; s += 8) {
-      float o8[8];
+  float M = -INFINITY, L = 0.f, O = 0.f;
+  for (int s0 = 0; s0 < n_splits; s0 += 8) {
+    float m8[8], l8[8], o8[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) o8[u] = p[(s + u) * (D + 2) + 2 + d];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float w = __expf(sw[s + u] - M);
-        L += sl[s + u] * w;
-        O += o8[u] * w;
-      }
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u < n_splits ? s0 + u : n_splits - 1;
+      m8[u] = p[s * (D + 2)];
+      l8[u] = p[s * (D + 2) + 1];
+      o8[u] = p[s * (D + 2) + 2 + d];
     }
-    for (; s < n_splits; ++s) {
-      const float w = __expf(sw[s] - M);
-      L += sl[s] * w;
-      O += p[s * (D + 2) + 2 + d] * w;
+    float mc = M;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < n_splits) mc = fmaxf(mc, m8[u]);
+    if (mc > -INFINITY) {
+      const float a = __expf(M - mc);  // M = -inf -> 0
+      L *= a;
+      O *= a;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < n_splits) {
+          const float w = __expf(m8[u] - mc);  // empty split: exp(-inf) = 0
+          L += l8[u] * w;
+          O += o8[u] * w;
+        }
+      M = mc;
     }
   }
   store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + d, L > 0.f ? O / L : 0.f);

@@ -58,6 +58,26 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nvec = K / V;
 
+  // ---- start the weight stream BEFORE the prologue: the first R*U chunks of this workgroup's first neurons are in
+  // flight while x is being built (a dependent HBM round trip costs ~1.5 us here; the prologue has two of them) ----
+  const S* W = reinterpret_cast<const S*>(W_);
+  const int n_out = PAIR ? N / 2 : N;                 // neurons indexed by the wave
+  constexpr int RW = PAIR ? 1 : R;                    // wave-owned output neurons per pass (PAIR: one act = two rows)
+  const int groups = (n_out + 4 * RW - 1) / (4 * RW);
+  uint4 pre[R][U];
+  const bool have_pre = (int)blockIdx.x < groups && lane + 64 * (U - 1) < nvec;
+  if (have_pre) {
+    const int n0 = blockIdx.x * 4 * RW + wid * RW;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int n = PAIR ? (n0 + r * n_out) : (n0 + r);
+      n = n < N ? n : N - 1;
+      if (PAIR && n0 >= n_out) n = r * n_out;
+#pragma unroll
+      for (int u = 0; u < U; ++u) pre[r][u] = ldg_nt(W + (int64_t)n * K + (lane + 64 * u) * V);
+    }
+  }
+
   // ---- prologue: build x in LDS ----
   if constexpr (MODE == 1) {  // ADDNORM
     const S* h = reinterpret_cast<const S*>(h_);
@@ -114,10 +134,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
   __syncthreads();
 
   // ---- stream the weights ----
-  const S* W = reinterpret_cast<const S*>(W_);
-  const int n_out = PAIR ? N / 2 : N;                 // neurons indexed by the wave
-  constexpr int RW = PAIR ? 1 : R;                    // wave-owned output neurons per pass (PAIR: one act = two rows)
-  const int groups = (n_out + 4 * RW - 1) / (4 * RW);
+  bool first = have_pre;
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     const int n0 = grp * 4 * RW + wid * RW;
     float acc[R][B];
@@ -134,10 +151,18 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
     int v = lane;
     for (; v + 64 * (U - 1) < nvec; v += 64 * U) {
       uint4 raw[R][U];
+      if (first) {  // already in flight since before the prologue
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int r = 0; r < R; ++r) raw[r][u] = ldg_nt(wp[r] + (v + 64 * u) * V);
+          for (int r = 0; r < R; ++r) raw[r][u] = pre[r][u];
+        first = false;
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) raw[r][u] = ldg_nt(wp[r] + (v + 64 * u) * V);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float wf[R][V];

@@ -1,0 +1,149 @@
+"""GPU: the BASELINE.json configs beyond the bench line, at full layer WIDTH (few layers so the oracle finishes in seconds),
+plus size-independent properties at full sizes.
+
+  C3  batch=32 images, ragged prompt lengths + per-row eviction (packed varlen; decode batch > 4 => hipBLASLt GEMM path)
+  C5  LLaVA-1.5-13B width, long decode with incremental output-text KV eviction (slab growth, split-KV, hipGraph vs eager)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as fx  # noqa: E402
+from oracle.ref_cpu import Oracle  # noqa: E402
+
+
+def _build(cfg_ns, sd, dtype):
+    from dynamic_llava_amd.builder import build_from_state_dict
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    return build_from_state_dict(DynamicLlavaConfig.from_namespace(cfg_ns), sd, None, dtype=dtype, device="cuda")
+
+
+def test_c3_batch32_ragged_rows_equal_b1_and_oracle():
+    """Every row of a ragged B=32 batch must equal its own B=1 run (SURVEY finding 2: that is the only well-defined batched
+    semantics), for prefill logits, per-step eviction decisions, per-row KV lengths and greedy tokens."""
+    dtype = torch.bfloat16
+    cfg = fx.llava7b_config(num_hidden_layers=3)
+    cfg.vocab_size = 4096
+    sd = fx.make_state_dict(cfg, seed=11, predictor_gain=50.0)
+    model = _build(cfg, sd, dtype)
+    g = torch.Generator().manual_seed(1)
+    B, steps = 32, 12
+    n_q = torch.randint(8, 65, (B,), generator=g).tolist()  # question lengths ~U[8,64]
+    prompts = [fx.make_prompt(cfg, 35, n_q[b], seed=b) for b in range(B)]
+    feats = torch.randn(B, 576, 4096, generator=g).to(dtype)
+    W = max(p.shape[0] for p in prompts)
+    ids = torch.zeros(B, W, dtype=torch.long)
+    am = torch.zeros(B, W, dtype=torch.long)
+    for b, p in enumerate(prompts):
+        ids[b, : p.shape[0]] = p
+        am[b, : p.shape[0]] = 1
+    out = model.generate(ids.cuda(), attention_mask=am.cuda(), image_features=feats.cuda(), max_new_tokens=steps, eos_token_id=None)
+    lens_b = [t.clone() for t in model.last_cache[1]]
+    logits_b = model.last_prefill_logits.clone()
+    assert out.shape == (B, steps)
+    assert lens_b[0].tolist() == [35 + 576 + n_q[b] + steps - 1 for b in range(B)]
+    kept = [int(lens_b[-1][b]) - (35 + 115 + n_q[b]) for b in range(B)]
+    assert all(0 <= k <= steps - 1 for k in kept) and 0 < sum(kept) < B * (steps - 1), "eviction must be exercised both ways"
+    ulp = 2.0**-7
+    # teacher-forced forward() loop, batched vs B=1 (different GEMM paths: hipBLASLt at B=32, dl_gemv at B=1 => same noise
+    # class, not bit-equal; decisions compared away from the decision boundary)
+    forced = fx.make_forced_tokens(cfg, 6, B, seed=3)
+    model.debug_records = {}
+    ob = model(ids.cuda(), attention_mask=am.cuda(), image_features=feats.cuda())
+    pkv = ob.past_key_values
+    cu = model.debug_records["cu_after"].cpu().tolist()
+    rows = [0, 7, 19, 31]
+    hist = {b: [ob.logits[b, cu[b + 1] - cu[b] - 1].cpu()] for b in rows}
+    dec_b, gap_b = [], []
+    for j in range(6):
+        ob = model(forced[j][:, None].cuda(), past_key_values=pkv)
+        pkv = ob.past_key_values
+        for b in rows:
+            hist[b].append(ob.logits[b, -1].cpu())
+        dec_b.append(model.debug_records["text_decision"].cpu().clone())
+        tl = model.debug_records["text_logit"].cpu()
+        gap_b.append((tl[:, 0] - tl[:, 1]).abs())
+    for b in rows:
+        o1 = model(prompts[b][None].cuda(), image_features=feats[b : b + 1].cuda())
+        p1 = o1.past_key_values
+        assert float((o1.logits[0, -1].cpu() - hist[b][0]).abs().max()) <= 8 * ulp * float(hist[b][0].abs().max()), f"row {b} prefill"
+        # generate() runs lm_head on the last rows only, forward() on all rows: different hipBLASLt kernels, <= 1-2 ulp apart
+        assert float((logits_b[b].cpu() - hist[b][0]).abs().max()) <= 2 * ulp * float(hist[b][0].abs().max()), "generate() vs forward() prefill"
+        for j in range(6):
+            o1 = model(forced[j][b : b + 1][:, None].cuda(), past_key_values=p1)
+            p1 = o1.past_key_values
+            if float(gap_b[j][b]) < 0.5:
+                break  # a boundary decision may legitimately differ between the two GEMM paths; stop comparing this row
+            assert int(model.debug_records["text_decision"][0]) == int(dec_b[j][b]), f"row {b} step {j}"
+            assert float((o1.logits[0, -1].cpu() - hist[b][j + 1]).abs().max()) <= 8 * ulp * float(hist[b][j + 1].abs().max()), f"row {b} step {j}"
+    model.debug_records = None
+    # oracle on two rows (B=1 reference semantics), prefill logits
+    for b in (0, 17):
+        o = Oracle(cfg, sd, dtype)
+        o32 = Oracle(cfg, {k: v.to(dtype) for k, v in sd.items()}, torch.float32)
+        with torch.no_grad():
+            l_ref, _ = o.forward(prompts[b][None], image_features=feats[b : b + 1])
+            l_32, _ = o32.forward(prompts[b][None], image_features=feats[b : b + 1].float())
+        e_hip = float((logits_b[b].cpu() - l_32[0, -1]).abs().max())
+        e_ref = float((l_ref[0, -1] - l_32[0, -1]).abs().max())
+        assert e_hip <= 2.0 * e_ref + 2 * ulp * float(l_32.abs().max()), (b, e_hip, e_ref)
+
+
+def test_c5_13b_width_long_decode_with_eviction():
+    """13B width (H=5120, 40x128 heads, I=13824), 3 layers, prompt 35+576+29 = 640 -> 179, decode to a total length of 2048
+    (1408 steps) with output-text eviction: hipGraph replay == eager launches bit-for-bit, KV-length bookkeeping exact,
+    slab growth through the forward() API, first steps against the oracle."""
+    dtype = torch.bfloat16
+    cfg = fx.llava13b_config(num_hidden_layers=3)
+    cfg.vocab_size = 4096
+    cfg.mm_hidden_size = 1024
+    sd = fx.make_state_dict(cfg, seed=13, predictor_gain=50.0)
+    model = _build(cfg, sd, dtype)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(1, 576, 5120, generator=g).to(dtype)
+    ids = fx.make_prompt(cfg, 35, 29, seed=9)[None]
+    n_new = 2048 - 640
+    model.use_hip_graph = True
+    a = model.generate(ids.cuda(), image_features=feats.cuda(), max_new_tokens=n_new, eos_token_id=None)
+    lens_a = [t.clone() for t in model.last_cache[1]]
+    model.use_hip_graph = False
+    b = model.generate(ids.cuda(), image_features=feats.cuda(), max_new_tokens=n_new, eos_token_id=None)
+    lens_b = model.last_cache[1]
+    assert torch.equal(a, b), "graph replay and eager launches must produce identical tokens"
+    assert int(lens_a[0][0]) == 640 + n_new - 1 == int(lens_b[0][0]) and int(lens_a[-1][0]) == int(lens_b[-1][0])
+    kept = int(lens_a[-1][0]) - 179
+    assert 0 < kept < n_new - 1, f"kept {kept} of {n_new - 1} generated tokens"
+    # forward() loop (the reference's own driver) reproduces generate(); the caller-owned slab (reserve 256) must grow
+    model.debug_records = {}
+    out = model(ids.cuda(), image_features=feats.cuda())
+    pkv = out.past_key_values
+    cap0 = pkv.t_cap
+    tok = out.logits[:, -1].argmax(-1)
+    dec = []
+    n_check = 300
+    for j in range(n_check):
+        assert int(tok[0]) == int(a[0, j]), f"forward-loop token {j}"
+        out = model(tok[:, None], past_key_values=pkv)
+        pkv = out.past_key_values
+        dec.append(int(model.debug_records["text_decision"][0]))
+        tok = out.logits[:, -1].argmax(-1)
+    assert pkv.t_cap > cap0, "slab must have grown"
+    assert int(pkv[1][-1][0]) == 179 + sum(dec) and int(pkv[1][0][0]) == 640 + n_check
+    assert pkv[0][-1][0].shape[-2] == 179 + sum(dec) and pkv[0][0][0].shape[-2] == 640 + n_check
+    model.debug_records = None
+    # oracle: prefill + 8 decode steps, teacher-forced with the tokens the HIP path generated
+    o = Oracle(cfg, sd, dtype)
+    with torch.no_grad():
+        l_ref, p_ref = o.forward(ids, image_features=feats)
+        agree = int(l_ref[0, -1].argmax()) == int(a[0, 0])
+        for j in range(8):
+            l_ref, p_ref = o.forward(a[:, j : j + 1].cpu(), past_key_values=p_ref)
+            gap = float((o.records["text_logit"][0, 0, 0] - o.records["text_logit"][0, 0, 1]).abs())
+            if gap > 0.5:
+                assert int(o.records["text_decision"][0, 0]) == dec[j], f"eviction decision, step {j}"
+            else:
+                break
+            agree += int(l_ref[0, -1].argmax()) == int(a[0, j + 1])
+    assert agree >= 1
