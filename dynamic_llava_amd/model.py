@@ -525,9 +525,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     def _check_ready(self):
         if not self._packed:
             raise ops.HipOpsError("call model.finalize() after loading weights (done by the builders)")
+
+    def _instruct_on(self, indices, B):
         sc = self.config.sparse_config
-        if sc["use_text_predictor"] and sc["use_instruct_predictor"]:
-            raise NotImplementedError("instruct-predictor branches (DML:2261-2375, 2506-2521) are SURVEY 8f row N2, not built yet")
+        return bool(sc["use_text_predictor"] and sc["use_instruct_predictor"]) and indices is not None and len(indices) == B and all(i is not None for i in indices)
 
     def _plan_prefill(self, lens, indices):
         """Everything about a prefill that the host knows up front (all shapes: k is the same for every row), plus the
@@ -547,6 +548,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         for n in lens:
             cu_list.append(cu_list[-1] + n)
         p = dict(B=B, lens=list(lens), vision_on=vision_on, n_img=n_img, k=k, cu_list=cu_list, cu=i32(cu_list), zeros=i32([0] * B), max_len=max(lens))
+        p["instruct_on"] = self._instruct_on(indices, B) and sc["sparse_layer"] < cfg.num_hidden_layers
+        if p["instruct_on"]:
+            # DML:2269 -- the reference asserts B == 1 on this branch
+            assert B == 1, "Using text predictor must keep the batch size to 1"
+            drop_v = (n_img - k) if vision_on else 0
+            p["li"] = (indices[0]["last_instruct"][0] - drop_v, indices[0]["last_instruct"][1] - drop_v)
+        p["instruct_drop"] = 0
         lens2 = list(lens)
         if vision_on:
             lens2 = [n - (n_img - k) for n in lens]
@@ -595,6 +603,30 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 if rec is not None:
                     rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=p["cu2"])
                 cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], p["cu2_list"][-1]
+            if i == SL and p["instruct_on"]:
+                # ---- SURVEY 8f N2 / DML:2261-2375: prefill, first instruct -- the instruct predictor drops tokens of the last
+                # instruct span (its final token always stays).  The kept count is data dependent: one device->host copy, as in
+                # the reference (torch.where).  B == 1 only, like the reference.
+                li0, li1 = p["li"]
+                n_span = li1 - 1 - li0
+                if n_span > 0:
+                    tp = self.model.instruct_score_predictor
+                    dec = torch.empty(n_span, dtype=torch.int32, device=dev)
+                    lg = torch.empty((n_span, 2), dtype=torch.float32, device=dev)
+                    tp.decide(h[li0 : li1 - 1], torch.empty(n_span * tp.d_model, dtype=torch.float32, device=dev), lg, dec)
+                    keep_rel = torch.nonzero(dec).flatten()
+                    idx = torch.cat([torch.arange(0, li0, device=dev), keep_rel + li0, torch.arange(li1 - 1, total, device=dev)])
+                    if pos is None:
+                        pos = torch.arange(total, dtype=torch.int32, device=dev)
+                    h = h.index_select(0, idx)
+                    pos = pos.index_select(0, idx)
+                    total = int(idx.numel())
+                    p["instruct_drop"] = n_span - int(keep_rel.numel())
+                    cu_list, max_len = [0, total], total
+                    cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
+                    if rec is not None:
+                        rec.update(instruct_logit=lg, instruct_keep=keep_rel, position_ids=pos, cu_after=cu)
+            if i == SL and (vision_on or p["instruct_on"]):
                 x = ops.rmsnorm(h, layer.input_layernorm.weight, eps)
             qkv = F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
@@ -606,20 +638,28 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             dn = F.linear(act, layer.mlp.down_proj.weight)
             if i + 1 == L:
                 x = ops.add_rmsnorm(h, dn, self.model.norm.weight, eps)
-            elif i + 1 == SL and vision_on:
+            elif i + 1 == SL and (vision_on or p["instruct_on"]):
                 ops.add_rmsnorm(h, dn, None, eps)  # residual add only: layer SL's norm runs after compaction
             else:
                 x = ops.add_rmsnorm(h, dn, self.model.layers[i + 1].input_layernorm.weight, eps)
         cache.lens.copy_(p["lens_dev"])  # layers < SL hold the full prompt, layers >= SL the compacted one
+        if p["instruct_drop"]:
+            cache.lens[1] -= p["instruct_drop"]
         if last_only:
-            x = x.index_select(0, p["last_rows"])
+            x = x.index_select(0, p["last_rows"] - p["instruct_drop"])
         return x
 
     def _prefill_host_update(self, p, cache, indices):
         """Host mirrors of what `_prefill_run` did on the device (also the reference's in-place index shift, DML:1986-1994)."""
         cache.full_len_host = list(p["lens"])
         cache.seen_tokens = max(p["lens"])
-        cache.sparse_cap = cache.t_cap - (max(p["lens"]) - max(p["lens2"]))  # host-known upper bound of the evicted group's lengths
+        cache.sparse_cap = cache.t_cap - (max(p["lens"]) - max(p["lens2"])) - p["instruct_drop"]  # host-known upper bound of the evicted group's lengths
+        if p["instruct_drop"]:  # DML:2365-2375
+            for ix in indices:
+                ix["instruct"][1] -= p["instruct_drop"]
+                ix["last_instruct"][1] -= p["instruct_drop"]
+                ix["answer"][0] -= p["instruct_drop"]
+                ix["answer"][1] -= p["instruct_drop"]
         if p["vision_on"]:
             drop = p["n_img"] - p["k"]
             for ix in indices:
@@ -639,6 +679,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._rope_tables(max(lens) + reserve)
         x = self._prefill_run(p, embeds, cache, indices, last_only)
         self._prefill_host_update(p, cache, indices)
+        if p["instruct_drop"]:
+            n = p["lens2"][0] - p["instruct_drop"]
+            return x, cache, [n], [0, n]
         return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
@@ -873,7 +916,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._prefill_logits_buf = torch.empty(st.logits.shape, dtype=torch.float32, device=self.device)
         vp = getattr(self.model, "image_score_predictor", None)
         hooked = vp is not None and (len(vp._forward_hooks) or len(vp._forward_pre_hooks))
-        graphable = self.use_hip_graph and self.debug_records is None and not hooked
+        graphable = self.use_hip_graph and self.debug_records is None and not hooked and not self._instruct_on(indices, B)  # data-dependent shapes
         if graphable:
             key = (lay["sig"], None if images is None else tuple(images.shape), None if image_features is None else tuple(image_features.shape),
                    cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new > 0, repr(self.config.sparse_config), lay["text_src"][0] if lay["text_src"] else -1)

@@ -36,6 +36,9 @@ CASES = {
     "tiny_fp32_keep50": dict(dtype="float32", sparse=dict(vision_keep_rate=0.5), prompts=[(3, 11)], steps=8, gain=50.0),
     "tiny_fp32_benchprompt": dict(dtype="float32", sparse=dict(use_text_predictor=False, use_output_text_predictor=False), prompts=[(1, 1)], steps=4, gain=50.0),
     "tiny_fp32_b3_same": dict(dtype="float32", sparse={}, prompts=[(5, 7)] * 3, steps=8, gain=50.0),
+    # instruct predictor on (the training default, train_sparse.py:156) -> prefill drops instruct tokens too
+    "tiny_fp32_instruct": dict(dtype="float32", sparse=dict(use_instruct_predictor=True), prompts=[(5, 23)], steps=8, gain=50.0),
+    "tiny_bf16_instruct": dict(dtype="bfloat16", sparse=dict(use_instruct_predictor=True), prompts=[(5, 23)], steps=8, gain=50.0),
 }
 
 
@@ -128,7 +131,10 @@ def pad_prompts(prompts):
 def main():
     dll = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only = sys.argv[1:]
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(0)
         dtype = getattr(torch, c["dtype"])
         cfg = fx.tiny_config(**c["sparse"])

@@ -410,8 +410,6 @@ class Oracle:
         sparse_layer = sc["sparse_layer"]
         rec = self.records = {"text_decision": None}
         vision_on = sc["use_vision_predictor"] and input_embeds_indices is not None and B == len(input_embeds_indices)
-        if sc.get("use_text_predictor") and sc.get("use_instruct_predictor"):
-            raise NotImplementedError("instruct-predictor branches (DML:2261-2375, 2506-2521) are SURVEY 8f row N2")
         if vision_on:
             init_image_n = input_embeds_indices[0]["image"][1] - input_embeds_indices[0]["image"][0]
             image_prev_decision = torch.ones(B, init_image_n, 1, dtype=h.dtype, device=h.device)
@@ -446,7 +444,26 @@ class Oracle:
                         d_[key][0] -= drop
                         d_[key][1] -= drop
             if sc["use_text_predictor"] and i == sparse_layer:
-                if past_len and h.shape[1] == 1 and sc["use_output_text_predictor"]:  # DML:2377-2391
+                if (not past_len) and input_embeds_indices is not None and B == len(input_embeds_indices) and sc["use_instruct_predictor"]:
+                    # DML:2261-2375 -- prefill, first instruct: drop the instruct tokens the predictor rejects (last one always stays)
+                    assert B == 1, "Using text predictor must keep the batch size to 1"
+                    li0, li1 = input_embeds_indices[0]["last_instruct"]
+                    span = h[:, li0 : li1 - 1, :]
+                    il = text_predictor(self.sd, "model.instruct_score_predictor.", span).reshape(B, -1, 2)
+                    keep_i = torch.where(il[0, :, 0] > il[0, :, 1])[0].unsqueeze(0)
+                    kept = span.gather(dim=1, index=keep_i[..., None].expand(B, -1, h.shape[2]))
+                    h = torch.cat([h[:, :li0, :], kept, h[:, li1 - 1 :, :]], dim=1)
+                    position_ids = torch.cat([position_ids[:, :li0], position_ids[:, li0 : li1 - 1].gather(dim=1, index=keep_i), position_ids[:, li1 - 1 :]], dim=1)
+                    rec.update(instruct_logit=il, instruct_keep=keep_i, position_ids=position_ids)
+                    drop_i = li1 - 1 - li0 - keep_i.shape[1]
+                    for d_ in input_embeds_indices:
+                        d_["instruct"][1] -= drop_i
+                        d_["last_instruct"][1] -= drop_i
+                        d_["answer"][0] -= drop_i
+                        d_["answer"][1] -= drop_i
+                elif past_len and h.shape[1] > 1 and sc["use_instruct_predictor"]:
+                    raise NotImplementedError("new-instruct round with a cache (DML:2506-2521) is SURVEY 8f row N2b")
+                elif past_len and h.shape[1] == 1 and sc["use_output_text_predictor"]:  # DML:2377-2391
                     tl = text_predictor(self.sd, "model.output_text_score_predictor.", h).reshape(B, -1, 2)
                     text_decision = tl[:, :, 0] > tl[:, :, 1]
                     rec.update(text_logit=tl, text_decision=text_decision)
