@@ -37,13 +37,13 @@ def build_random_model(cfg: DynamicLlavaConfig, dtype=torch.bfloat16, device="cu
     model = _construct(cfg, dtype, device)
     g = torch.Generator(device=device).manual_seed(seed)
     std = 0.02 if init_std is None else init_std
-    for name, p in model.named_parameters():
-        if "vision_tower" in name:
-            continue
-        if p.dim() >= 2:
+    for name, p in model.named_parameters():  # every parameter comes from the seeded generator: all DP ranks hold identical weights
+        if p.dim() >= 2 or "embedding" in name:
             p.normal_(0.0, std, generator=g)
         elif name.endswith("bias"):
             p.zero_()
+        elif "vision_tower" in name and ("norm" in name or "layrnorm" in name) and name.endswith("weight"):
+            p.fill_(1.0)
     if predictor_gain != 1.0:
         m = model.model
         if hasattr(m, "image_score_predictor"):

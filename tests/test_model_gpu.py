@@ -305,3 +305,52 @@ def test_instruct_predictor_generate_equals_reference_golden(golden_dir):
     assert out.cpu().tolist() == ref.tolist()
     with pytest.raises(AssertionError):  # DML:2269: the reference asserts B == 1 on this branch
         model.generate(ids.repeat(2, 1), images=images.repeat(2, 1, 1, 1), max_new_tokens=2)
+
+
+def test_checkpoint_roundtrip_through_load_pretrained_model(tmp_path):
+    """dynamic_llava_builder.load_pretrained_model surface: config.json + safetensors with the reference's key names."""
+    from dynamic_llava_amd.builder import load_pretrained_model, save_pretrained
+
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1)
+    model = _build(cfg, sd, clip, torch.float16)
+    save_pretrained(model, str(tmp_path))
+    tok, m2, proc, ctx = load_pretrained_model(str(tmp_path), None, "dynamic-llava-tiny")  # fp16 default like BLD:62
+    assert m2.dtype == torch.float16 and ctx == 2048
+    ids = fx.make_prompt(cfg, 5, 7)[None].cuda()
+    images = fx.make_images(cfg, 1).half().cuda()
+    a = model.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    b = m2.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    assert torch.equal(a, b)
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model(str(tmp_path), None, "x", load_4bit=True)
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model(str(tmp_path), "base", "x")
+
+
+def test_text_only_and_edge_prompts_vs_oracle():
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1)
+    model = _build(cfg, sd, clip, torch.float32)
+    o = Oracle(cfg, sd, torch.float32, clip=clip)
+    # (a) no image at all: plain language model (ARCH:180-188 early-out), generate + forward
+    ids = fx.make_prompt(cfg, 4, 9)[None]
+    ids = ids[ids != -200][None]
+    ref, _ = o.greedy(ids, max_new_tokens=6, eos_token_id=None)
+    out = model.generate(ids.cuda(), max_new_tokens=6, eos_token_id=None)
+    assert out.cpu().tolist() == ref.tolist()
+    l_ref, _ = o.forward(ids)
+    l = model(ids.cuda()).logits
+    assert l.shape == l_ref.shape and float((l.cpu() - l_ref).abs().max()) < 1e-3
+    # (b) image is the last prompt token (empty instruct span) and (c) image first (empty system span)
+    images = fx.make_images(cfg, 1)
+    for prompt in (torch.tensor([[1, 7, 9, -200]]), torch.tensor([[-200, 5, 6, 7]])):
+        ref, _ = o.greedy(prompt, images=images, max_new_tokens=5, eos_token_id=None)
+        out = model.generate(prompt.cuda(), images=images.cuda(), max_new_tokens=5, eos_token_id=None)
+        assert out.cpu().tolist() == ref.tolist(), prompt.tolist()
+    # (d) EOS on the very first token and max_new_tokens=1 (the prefill-latency bench, BIMG:134-147)
+    first = int(ref[0, 0])
+    out = model.generate(prompt.cuda(), images=images.cuda(), max_new_tokens=5, eos_token_id=first)
+    assert out.cpu().tolist() == [[first]]
