@@ -292,6 +292,7 @@ class DynamicLlavaLlamaModel(nn.Module):
         if cfg.mm_projector_type != "mlp2x_gelu":
             raise NotImplementedError("only the LLaVA-1.5 mlp2x_gelu projector is built (multimodal_projector/builder.py:172-179)")
         self.mm_projector = nn.Sequential(nn.Linear(cfg.mm_hidden_size, cfg.hidden_size), nn.GELU(), nn.Linear(cfg.hidden_size, cfg.hidden_size))
+        self.answer_indice = None  # dynamic_modeling_llama.py:1644 -- state of the no-KV-cache decode mode (never reset by the reference)
 
     def get_vision_tower(self):
         return getattr(self, "vision_tower", None)
@@ -555,6 +556,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             drop_v = (n_img - k) if vision_on else 0
             p["li"] = (indices[0]["last_instruct"][0] - drop_v, indices[0]["last_instruct"][1] - drop_v)
         p["instruct_drop"] = 0
+        p["nocache"] = False
+        p["nocache_lens"] = None
         lens2 = list(lens)
         if vision_on:
             lens2 = [n - (n_img - k) for n in lens]
@@ -626,7 +629,44 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
                     if rec is not None:
                         rec.update(instruct_logit=lg, instruct_keep=keep_rel, position_ids=pos, cu_after=cu)
-            if i == SL and (vision_on or p["instruct_on"]):
+            if i == SL and p["nocache"] and not p["instruct_on"] and indices is not None and sc["use_text_predictor"] and sc["use_output_text_predictor"]:
+                # ---- SURVEY 8f N3 / DML:2393-2504: decode WITHOUT KV cache.  The answer tokens [answer_indice, -1) of every row are
+                # compacted by top-k of the RAW keep logit with k = max kept count over the batch (data dependent: one host copy).
+                # First call: answer_indice == row length, so the last token is duplicated -- reproduced on purpose.
+                L_row = cu_list[1] - cu_list[0]
+                if any(cu_list[b + 1] - cu_list[b] != L_row for b in range(B)):
+                    raise NotImplementedError("use_cache=False expects equally long rows (the reference uses row 0's answer_indice for all, DML:2402-2409)")
+                if self.model.answer_indice is None:
+                    self.model.answer_indice = indices[0]["instruct"][1] - ((n_img - k) if vision_on else 0)
+                ai = self.model.answer_indice
+                n_span = max(0, L_row - 1 - ai)
+                num_keep = 0
+                keep = torch.zeros((B, 0), dtype=torch.int64, device=dev)
+                if n_span > 0:
+                    tp = self.model.output_text_score_predictor
+                    rows = (torch.tensor(cu_list[:-1], device=dev)[:, None] + ai + torch.arange(n_span, device=dev)[None, :]).reshape(-1)
+                    dec = torch.empty(B * n_span, dtype=torch.int32, device=dev)
+                    lg = torch.empty((B * n_span, 2), dtype=torch.float32, device=dev)
+                    tp.decide(h.index_select(0, rows), torch.empty(B * n_span * tp.d_model, dtype=torch.float32, device=dev), lg, dec)
+                    num_keep = int(dec.view(B, n_span).sum(dim=1).max().item())
+                    if num_keep > 0:
+                        keep = ops.topk_select(lg[:, 0].to(dt).view(B, n_span).contiguous(), num_keep)
+                    if rec is not None:
+                        rec.update(nocache_logit=lg.view(B, n_span, 2), nocache_keep=keep)
+                left = torch.arange(min(ai, L_row), device=dev)
+                idx = torch.cat([torch.cat([left, ai + keep[b], torch.tensor([L_row - 1], device=dev)]) + cu_list[b] for b in range(B)])
+                if pos is None:
+                    pos = torch.cat([torch.arange(L_row, dtype=torch.int32, device=dev) for _ in range(B)])
+                h = h.index_select(0, idx)
+                pos = pos.index_select(0, idx)
+                L_new = int(left.numel()) + num_keep + 1
+                cu_list = [b * L_new for b in range(B + 1)]
+                cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
+                max_len, total = L_new, B * L_new
+                p["nocache_lens"] = [L_new] * B
+                if rec is not None:
+                    rec.update(position_ids=pos, cu_after=cu)
+            if i == SL and (vision_on or p["instruct_on"] or p["nocache"]):
                 x = ops.rmsnorm(h, layer.input_layernorm.weight, eps)
             qkv = F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
@@ -638,7 +678,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             dn = F.linear(act, layer.mlp.down_proj.weight)
             if i + 1 == L:
                 x = ops.add_rmsnorm(h, dn, self.model.norm.weight, eps)
-            elif i + 1 == SL and (vision_on or p["instruct_on"]):
+            elif i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"]):
                 ops.add_rmsnorm(h, dn, None, eps)  # residual add only: layer SL's norm runs after compaction
             else:
                 x = ops.add_rmsnorm(h, dn, self.model.layers[i + 1].input_layernorm.weight, eps)
@@ -826,7 +866,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if output_attentions or output_hidden_states:
             raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused path")
         if use_cache is False:
-            raise NotImplementedError("use_cache=False (no-KV-cache decode, DML:2393-2504) is SURVEY 8f row N3, not built yet")
+            return self._forward_nocache(input_ids, attention_mask, past_key_values, inputs_embeds, images, image_features, input_embeds_indices)
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You have to specify either input_ids or inputs_embeds")  # DML:1686-1695
         cache = past_key_values
@@ -870,6 +910,33 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             for b in range(B):
                 logits[b, : lens2[b]] = logits_packed[cu_list[b] : cu_list[b + 1]]
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
+
+    def _forward_nocache(self, input_ids, attention_mask, past_key_values, inputs_embeds, images, image_features, input_embeds_indices):
+        """`model(total_input_ids, images=..., use_cache=False)` -- the whole sequence is re-run every step
+        (llava/dynamic_eval/bench_test/dynamic_llava_long_text_time_with_no_cache.py:336-343); no cache is returned."""
+        if past_key_values is not None:
+            raise NotImplementedError("use_cache=False with past_key_values")
+        cfg, sc = self.config, self.config.sparse_config
+        if inputs_embeds is not None:
+            B, N = inputs_embeds.shape[:2]
+            lens = [N] * B if attention_mask is None else attention_mask.sum(dim=1).tolist()
+            embeds = torch.cat([inputs_embeds[b, : lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
+            indices = input_embeds_indices
+        else:
+            embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
+        p = self._plan_prefill(lens, indices)
+        p["nocache"] = True
+        need = max(lens) + 2
+        c = getattr(self, "_scratch_cache", None)  # K/V are still written (the kernels are fused), into a scratch slab that is dropped
+        if c is None or c.batch != p["B"] or c.t_cap < need or c.dtype != self.dtype:
+            c = self._scratch_cache = KVSlabCache(cfg.num_hidden_layers, sc["sparse_layer"], p["B"], cfg.num_key_value_heads, cfg.head_dim, need + 64, self.dtype, self.device)
+        self._rope_tables(need)
+        x = self._prefill_run(p, embeds, c, indices, False)
+        lens2 = p["nocache_lens"] or p["lens2"]
+        if len(set(lens2)) != 1:
+            raise NotImplementedError("use_cache=False expects equally long rows")
+        logits = F.linear(x, self.lm_head.weight).float().view(p["B"], lens2[0], -1)
+        return CausalLMOutputWithPast(logits=logits, past_key_values=None)
 
     def _first_token(self, st, x_last, min_new):
         torch.matmul(x_last, self.lm_head.weight.t(), out=st.logits)

@@ -39,6 +39,10 @@ CASES = {
     # instruct predictor on (the training default, train_sparse.py:156) -> prefill drops instruct tokens too
     "tiny_fp32_instruct": dict(dtype="float32", sparse=dict(use_instruct_predictor=True), prompts=[(5, 23)], steps=8, gain=50.0),
     "tiny_bf16_instruct": dict(dtype="bfloat16", sparse=dict(use_instruct_predictor=True), prompts=[(5, 23)], steps=8, gain=50.0),
+    # decode WITHOUT KV cache (use_cache=False, DML:2393-2504), driven like
+    # llava/dynamic_eval/bench_test/dynamic_llava_long_text_time_with_no_cache.py:319-343 (whole sequence re-run per step)
+    "tiny_fp32_nocache": dict(dtype="float32", sparse={}, prompts=[(5, 7)], steps=10, gain=50.0, nocache=True),
+    "tiny_fp32_nocache_b2": dict(dtype="float32", sparse={}, prompts=[(5, 7), (5, 7)], steps=6, gain=50.0, nocache=True),
 }
 
 
@@ -122,6 +126,31 @@ def run_reference(dll, cfg, sd, clip, dtype, input_ids, images, steps, forced=No
     return res
 
 
+def run_reference_nocache(dll, cfg, sd, clip, dtype, input_ids, images, steps, forced):
+    """The reference's no-KV-cache loop: model(total_input_ids, images=images, use_cache=False), one appended token per step."""
+    model = build_reference_model(dll, cfg, sd, clip, dtype)
+    cap = {}
+    L = cfg.sparse_config["sparse_layer"]
+    model.model.layers[L].register_forward_pre_hook(lambda m, a, kw: cap.__setitem__("position_ids", kw.get("position_ids")), with_kwargs=True)
+    out = dict(step_logits=[], logits_len=[], position_ids=[], ids=[])
+    total = input_ids
+    imgs = images.to(dtype)
+    with torch.inference_mode():
+        for j in range(steps + 1):
+            o = model(total, images=imgs, use_cache=False)
+            assert o.past_key_values is None
+            logits = o.logits[:, -1, :].float()
+            out["step_logits"].append(logits.numpy().copy())
+            out["logits_len"].append(o.logits.shape[1])
+            out["position_ids"].append(cap["position_ids"].numpy().copy())
+            out["ids"].append(logits.argmax(-1).numpy().copy())
+            total = torch.cat([total, forced[j][:, None]], dim=1)
+    res = {"step_logits": np.stack(out["step_logits"]), "logits_len": np.array(out["logits_len"]), "ids": np.stack(out["ids"])}
+    for j, p in enumerate(out["position_ids"]):
+        res[f"position_ids_{j}"] = p
+    return res
+
+
 def pad_prompts(prompts):
     n = max(p.shape[0] for p in prompts)
     assert all(p.shape[0] == n for p in prompts), "golden cases use equal-length rows (reference B>1 + padding is not a supported eval mode)"
@@ -146,13 +175,19 @@ def main():
         forced = None
         if not c.get("greedy", False):  # teacher forcing, like the reference's own loop (BLTM:310-337 feeds label ids)
             forced = fx.make_forced_tokens(cfg, c["steps"] + 1, len(prompts), seed=0)
-        res = run_reference(dll, cfg, sd, clip, dtype, input_ids, images, c["steps"], forced)
+        if c.get("nocache"):
+            res = run_reference_nocache(dll, cfg, sd, clip, dtype, input_ids, images, c["steps"], forced)
+        else:
+            res = run_reference(dll, cfg, sd, clip, dtype, input_ids, images, c["steps"], forced)
         res["input_ids"] = input_ids.numpy()
         if forced is not None:
             res["forced"] = forced.numpy()
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **res)
-        print(name, "ids", res["ids"][:, 0].tolist(), "kv_last", res["kv_len_last"].tolist(), "dec", res["text_decision"][:, 0].tolist())
+        if c.get("nocache"):
+            print(name, "ids", res["ids"][:, 0].tolist(), "logits_len", res["logits_len"].tolist())
+        else:
+            print(name, "ids", res["ids"][:, 0].tolist(), "kv_last", res["kv_len_last"].tolist(), "dec", res["text_decision"][:, 0].tolist())
 
 
 if __name__ == "__main__":

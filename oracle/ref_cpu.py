@@ -244,6 +244,7 @@ class Oracle:
         self.nKV = cfg.num_key_value_heads
         self.d = cfg.hidden_size // self.nH
         self.records = {}
+        self.answer_indice = None  # DML:1644 -- state of the no-KV-cache decode mode, never reset by the reference
         self._table_len = 0
         self._ensure_table(cfg.max_position_embeddings)
 
@@ -463,6 +464,26 @@ class Oracle:
                         d_["answer"][1] -= drop_i
                 elif past_len and h.shape[1] > 1 and sc["use_instruct_predictor"]:
                     raise NotImplementedError("new-instruct round with a cache (DML:2506-2521) is SURVEY 8f row N2b")
+                elif (not past_len) and input_embeds_indices is not None and B == len(input_embeds_indices) and sc["use_output_text_predictor"] and not use_cache:
+                    # DML:2393-2504 -- output infer stage WITHOUT KV cache: the whole sequence is re-run every step and the answer
+                    # tokens [answer_indice, -1) are compacted by top-k of the RAW keep logit, k = max kept count over the batch.
+                    # (On the first call answer_indice == T', so left = everything and right = h[:, -1:] duplicates the last token.)
+                    if self.answer_indice is None:
+                        self.answer_indice = input_embeds_indices[0]["instruct"][1]
+                    ai = self.answer_indice
+                    span = h[:, ai:-1, :]
+                    tl = text_predictor(self.sd, "model.output_text_score_predictor.", span).reshape(B, -1, 2)
+                    text_decision = tl[:, :, 0] > tl[:, :, 1]
+                    num_keep = int(text_decision.sum(dim=1).max()) if text_decision.numel() else 0
+                    order = torch.argsort(tl[:, :, 0], dim=1, descending=True, stable=(self.tie_break != "torch"))
+                    keep_t, _ = torch.sort(order[:, :num_keep], dim=1, descending=False)
+                    kept = span.gather(dim=1, index=keep_t[..., None].expand(B, num_keep, h.shape[2]))
+                    h = torch.cat([h[:, :ai, :], kept, h[:, -1:, :]], dim=1)
+                    if position_ids.shape[0] != B:
+                        position_ids = position_ids.expand(B, -1)
+                    position_ids = torch.cat([position_ids[:, :ai], position_ids[:, ai:-1].gather(dim=1, index=keep_t), position_ids[:, -1:]], dim=1)
+                    rec.update(nocache_logit=tl, nocache_keep=keep_t, position_ids=position_ids)
+                    text_decision = None  # only used for the compaction above; layers run without a cache
                 elif past_len and h.shape[1] == 1 and sc["use_output_text_predictor"]:  # DML:2377-2391
                     tl = text_predictor(self.sd, "model.output_text_score_predictor.", h).reshape(B, -1, 2)
                     text_decision = tl[:, :, 0] > tl[:, :, 1]

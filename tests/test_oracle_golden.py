@@ -46,13 +46,39 @@ def _run_case(name, golden_dir, tie_break):
             cur = nxt[:, None] if forced is None else forced[j][:, None]
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
+STD = sorted(n for n in CASES if not CASES[n].get("nocache"))
+NOCACHE = sorted(n for n in CASES if CASES[n].get("nocache"))
+
+
+@pytest.mark.parametrize("name", NOCACHE)
+def test_oracle_nocache_matches_reference_golden(name, golden_dir):
+    """use_cache=False decode (DML:2393-2504), incl. the reference's first-call quirk (last token duplicated)."""
+    c = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dtype = getattr(torch, c["dtype"])
+    cfg = fx.tiny_config(**c["sparse"])
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
+    o = Oracle(cfg, sd, dtype, clip=fx.build_clip(cfg, seed=1), tie_break="torch")
+    total = torch.from_numpy(g["input_ids"])
+    images = fx.make_images(cfg, total.shape[0], seed=0).to(dtype)
+    forced = torch.from_numpy(g["forced"])
+    with torch.no_grad():
+        for j in range(g["step_logits"].shape[0]):
+            logits, pkv = o.forward(total, images=images, use_cache=False)
+            assert pkv is None and logits.shape[1] == g["logits_len"][j]
+            np.testing.assert_array_equal(logits[:, -1].float().numpy(), g["step_logits"][j])
+            np.testing.assert_array_equal(o.records["position_ids"].numpy(), g[f"position_ids_{j}"])
+            total = torch.cat([total, forced[j][:, None]], dim=1)
+    assert g["logits_len"][0] == g[f"position_ids_0"].shape[1] and g["position_ids_0"][0, -1] == g["position_ids_0"][0, -2]  # the quirk
+
+
+@pytest.mark.parametrize("name", STD)
 def test_oracle_matches_reference_golden(name, golden_dir):
     # tie_break="torch" calls argsort exactly as the reference does (DML:1902-1908)
     _run_case(name, golden_dir, "torch")
 
 
-@pytest.mark.parametrize("name", [n for n in sorted(CASES) if "ties" not in n])
+@pytest.mark.parametrize("name", [n for n in STD if "ties" not in n])
 def test_pinned_tiebreak_equals_reference_when_no_ties(name, golden_dir):
     # with distinct boundary scores the pinned (stable) rule must select the same set as the reference
     _run_case(name, golden_dir, "stable")
