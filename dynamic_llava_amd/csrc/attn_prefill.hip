@@ -31,7 +31,8 @@ template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
                                                                  const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
                                                                  void* __restrict__ out_, int64_t out_rs,
-                                                                 const int32_t* __restrict__ cu, int n_rep, float scale) {
+                                                                 const int32_t* __restrict__ cu, int n_rep, float scale,
+                                                                 const int32_t* __restrict__ kv_len, int64_t kv_sb, int64_t kv_sh) {
   using S = uint16_t;
   constexpr int KS = D / 32;   // MFMA k-steps over the head dim
   constexpr int DT = D / 16;   // 16-wide output column tiles
@@ -53,8 +54,15 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __re
   const int lr = lane & 15, lg = lane >> 4;
   const int kvh = h / n_rep;
   const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
-  const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
-  const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  // K/V either come from the same packed projection output as q (fresh prefill) or from the KV slab (chunk on a cache:
+  // keys [0, off) were cached before, this chunk's keys sit at [off, off + L); query j sees keys <= off + j)
+  const int off = kv_len ? kv_len[b] : 0;
+  const int Lk = off + L;
+  if (kv_len) kv_rs = D;
+  const S* kb = kv_len ? reinterpret_cast<const S*>(k_) + (int64_t)b * kv_sb + (int64_t)kvh * kv_sh
+                       : reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = kv_len ? reinterpret_cast<const S*>(v_) + (int64_t)b * kv_sb + (int64_t)kvh * kv_sh
+                       : reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
 
   // Q fragments (A operand): row = lane&15, k = (lane>>4)*8 .. +8
   uint4 qf[KS];
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __re
   }
   S* Pw = Ps + w * 16 * LDP;
 
-  const int n_tiles = CAUSAL ? min((L + kBN - 1) / kBN, qt + 1) : (L + kBN - 1) / kBN;
+  const int n_tiles = CAUSAL ? min((Lk + kBN - 1) / kBN, (q0 + kBM - 1 + off) / kBN + 1) : (Lk + kBN - 1) / kBN;
   for (int jt = 0; jt < n_tiles; ++jt) {
     const int key0 = jt * kBN;
     // ---- stage K (row-major) and V (transposed) tiles ----
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __re
       const int idx = it * 256 + tid;
       const int key = idx / CPR, ch = idx % CPR;
       uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
-      if (key0 + key < L) {
+      if (key0 + key < Lk) {
         kv4 = *reinterpret_cast<const uint4*>(kb + (int64_t)(key0 + key) * kv_rs + ch * 8);
         vv4 = *reinterpret_cast<const uint4*>(vb + (int64_t)(key0 + key) * kv_rs + ch * 8);
       }
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __re
       for (int nt = 0; nt < NT; ++nt) {
         const int ki = key0 + nt * 16 + lr;
         float s = acc_s[nt][r] * scale;
-        if (ki >= L || (CAUSAL && ki > qi)) s = -INFINITY;
+        if (ki >= Lk || (CAUSAL && ki > qi + off)) s = -INFINITY;
         acc_s[nt][r] = s;
         mx = fmaxf(mx, s);
       }
@@ -184,7 +192,8 @@ __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __
                                                                    const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
                                                                    void* __restrict__ out_, int64_t out_rs,
                                                                    const int32_t* __restrict__ cu, int n_rep, float scale, int D,
-                                                                   int causal, int max_len) {
+                                                                   int causal, int max_len, const int32_t* __restrict__ kv_len, int64_t kv_sb,
+                                                                   int64_t kv_sh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* qs = reinterpret_cast<float*>(smem);  // [4][D]
   float* sc = qs + 4 * D;                      // [4][max_len]
@@ -195,17 +204,21 @@ __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __
   const int qi = blockIdx.x * 4 + w;
   const bool valid = qi < L;  // invalid waves still take part in the barriers
   const int kvh = h / n_rep;
+  const int off = kv_len ? kv_len[b] : 0;
+  const int Lk = off + L;
+  if (kv_len) kv_rs = D;
+  const int64_t kbase = kv_len ? (int64_t)b * kv_sb + (int64_t)kvh * kv_sh : (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
   float* myq = qs + w * D;
   float* mys = sc + (int64_t)w * max_len;
   if (valid)
     for (int e = lane; e < D; e += 64) myq[e] = load1<T>(q_, ((int64_t)tok0 + qi) * q_rs + (int64_t)h * D + e);
   __syncthreads();
-  const int nk = valid ? (causal ? qi + 1 : L) : 0;
+  const int nk = valid ? (causal ? min(qi + off + 1, Lk) : Lk) : 0;
   float mx = -INFINITY;
   for (int key = lane; key < nk; key += 64) {
     float a = 0.f;
-    const int64_t off = ((int64_t)tok0 + key) * kv_rs + (int64_t)kvh * D;
-    for (int e = 0; e < D; ++e) a += myq[e] * load1<T>(k_, off + e);
+    const int64_t ko = kbase + (int64_t)key * kv_rs;
+    for (int e = 0; e < D; ++e) a += myq[e] * load1<T>(k_, ko + e);
     a *= scale;
     mys[key] = a;
     mx = fmaxf(mx, a);
@@ -223,58 +236,77 @@ __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __
   const float inv = 1.0f / sum;
   for (int e = lane; e < D; e += 64) {
     float o = 0.f;
-    for (int key = 0; key < nk; ++key) o += mys[key] * load1<T>(v_, ((int64_t)tok0 + key) * kv_rs + (int64_t)kvh * D + e);
+    for (int key = 0; key < nk; ++key) o += mys[key] * load1<T>(v_, kbase + (int64_t)key * kv_rs + e);
     store1<T>(out_, ((int64_t)tok0 + qi) * out_rs + (int64_t)h * D + e, o * inv);
   }
 }
 
 template <typename T, int D>
 static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_rs, int64_t kv_rs, void* out, int64_t out_rs,
-                        const int32_t* cu, int B, int max_seqlen, int n_heads, int n_rep, int causal, hipStream_t st) {
+                        const int32_t* cu, int B, int max_seqlen, int n_heads, int n_rep, int causal, hipStream_t st,
+                        const int32_t* kv_len = nullptr, int64_t kv_sb = 0, int64_t kv_sh = 0) {
   const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + 4 * 16 * (kBN + kPad)) * 2;
   const dim3 grid((unsigned)((max_seqlen + kBM - 1) / kBM), (unsigned)n_heads, (unsigned)B);
   const float scale = 1.0f / sqrtf((float)D);
   if (causal)
     hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, true>), grid, dim3(256), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep,
-                       scale);
+                       scale, kv_len, kv_sb, kv_sh);
   else
     hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, false>), grid, dim3(256), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep,
-                       scale);
+                       scale, kv_len, kv_sb, kv_sh);
 }
 
 }  // namespace dl
 
 using namespace dl;
 
-extern "C" int dl_attn_prefill(const void* q, const void* k, const void* v, int64_t q_row_stride, int64_t kv_row_stride, void* out,
-                               int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen, int n_heads, int n_kv_heads,
-                               int head_dim, int causal, int dtype, void* stream) {
-  DL_REQUIRE(q && k && v && out && cu_seqlens, "dl_attn_prefill: NULL pointer");
-  DL_REQUIRE(B > 0 && max_seqlen >= 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "dl_attn_prefill: bad shape");
+static int attn_prefill_impl(const char* who, const void* q, const void* k, const void* v, int64_t q_row_stride, int64_t kv_row_stride,
+                             void* out, int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen, int max_kv_len, int n_heads,
+                             int n_kv_heads, int head_dim, int causal, int dtype, void* stream, const int32_t* kv_len, int64_t kv_sb,
+                             int64_t kv_sh) {
+  DL_REQUIRE(q && k && v && out && cu_seqlens, "%s: NULL pointer", who);
+  DL_REQUIRE(B > 0 && max_seqlen >= 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "%s: bad shape", who);
   if (max_seqlen == 0) return DL_OK;
   hipStream_t st = as_stream(stream);
   const int n_rep = n_heads / n_kv_heads;
   if (dtype == DL_F32) {
-    DL_REQUIRE(head_dim > 0 && head_dim <= 256, "dl_attn_prefill: head_dim=%d unsupported for f32", head_dim);
-    DL_REQUIRE(max_seqlen <= 8192, "dl_attn_prefill: f32 path supports max_seqlen <= 8192");
-    const size_t smem = (size_t)(4 * head_dim + 4 * (size_t)max_seqlen) * sizeof(float);
+    DL_REQUIRE(head_dim > 0 && head_dim <= 256, "%s: head_dim=%d unsupported for f32", who, head_dim);
+    DL_REQUIRE(max_kv_len <= 8192, "%s: f32 path supports up to 8192 keys", who);
+    const size_t smem = (size_t)(4 * head_dim + 4 * (size_t)max_kv_len) * sizeof(float);
     hipLaunchKernelGGL((attn_prefill_simple_kernel<f32_t>), dim3((unsigned)((max_seqlen + 3) / 4), (unsigned)n_heads, (unsigned)B),
                        dim3(256), smem, st, q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, n_rep,
-                       1.0f / sqrtf((float)head_dim), head_dim, causal, max_seqlen);
+                       1.0f / sqrtf((float)head_dim), head_dim, causal, max_kv_len, kv_len, kv_sb, kv_sh);
   } else if (dtype == DL_F16 || dtype == DL_BF16) {
-    DL_REQUIRE(head_dim == 64 || head_dim == 128, "dl_attn_prefill: head_dim=%d unsupported (64 or 128)", head_dim);
-    DL_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0, "dl_attn_prefill: row strides must be multiples of 8 elements");
+    DL_REQUIRE(head_dim == 64 || head_dim == 128, "%s: head_dim=%d unsupported (64 or 128)", who, head_dim);
+    DL_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0, "%s: row strides must be multiples of 8 elements", who);
+#define DL_PF_ARGS q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st, kv_len, kv_sb, kv_sh
     if (dtype == DL_BF16) {
-      if (head_dim == 128) launch_mfma<bf16_t, 128>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
-      else launch_mfma<bf16_t, 64>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
+      if (head_dim == 128) launch_mfma<bf16_t, 128>(DL_PF_ARGS); else launch_mfma<bf16_t, 64>(DL_PF_ARGS);
     } else {
-      if (head_dim == 128) launch_mfma<f16_t, 128>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
-      else launch_mfma<f16_t, 64>(q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st);
+      if (head_dim == 128) launch_mfma<f16_t, 128>(DL_PF_ARGS); else launch_mfma<f16_t, 64>(DL_PF_ARGS);
     }
+#undef DL_PF_ARGS
   } else {
-    set_error("dl_attn_prefill: unsupported dtype %d", dtype);
+    set_error("%s: unsupported dtype %d", who, dtype);
     return DL_ERR_ARG;
   }
-  DL_CHECK_LAUNCH("dl_attn_prefill");
+  DL_CHECK_LAUNCH(who);
   return DL_OK;
+}
+
+extern "C" int dl_attn_prefill(const void* q, const void* k, const void* v, int64_t q_row_stride, int64_t kv_row_stride, void* out,
+                               int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen, int n_heads, int n_kv_heads,
+                               int head_dim, int causal, int dtype, void* stream) {
+  return attn_prefill_impl("dl_attn_prefill", q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, max_seqlen,
+                           n_heads, n_kv_heads, head_dim, causal, dtype, stream, nullptr, 0, 0);
+}
+
+extern "C" int dl_attn_prefill_cached(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t slab_stride_b,
+                                      int64_t slab_stride_h, const int32_t* kv_len, void* out, int64_t out_row_stride,
+                                      const int32_t* cu_seqlens, int B, int max_seqlen, int max_kv_len, int n_heads, int n_kv_heads,
+                                      int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(kv_len != nullptr, "dl_attn_prefill_cached: kv_len is NULL");
+  DL_REQUIRE(max_kv_len >= max_seqlen, "dl_attn_prefill_cached: max_kv_len must bound kv_len[b] + row length");
+  return attn_prefill_impl("dl_attn_prefill_cached", q, k_slab, v_slab, q_row_stride, head_dim, out, out_row_stride, cu_seqlens, B, max_seqlen,
+                           max_kv_len, n_heads, n_kv_heads, head_dim, 1, dtype, stream, kv_len, slab_stride_b, slab_stride_h);
 }

@@ -55,6 +55,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
+    "dl_attn_prefill_cached": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    ),
     "dl_attn_decode_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "dl_attn_decode": (
         c_int,
@@ -205,6 +209,22 @@ def attn_prefill(q, k, v, out, cu_seqlens, max_seqlen, n_heads, n_kv_heads, head
             head_dim, 1 if causal else 0, dtype_code(q.dtype), _stream(),
         ),
         "dl_attn_prefill",
+    )
+    return out
+
+
+def attn_prefill_cached(q, k_slab, v_slab, kv_len, out, cu_seqlens, max_seqlen, max_kv_len, n_heads, n_kv_heads, head_dim):
+    """Causal attention of a packed query chunk against the KV slab (chunk keys already appended at [kv_len[b], ...))."""
+    _dev(q, k_slab, v_slab, kv_len, out, cu_seqlens)
+    assert q.stride(1) == 1 and out.stride(1) == 1 and kv_len.dtype == torch.int32
+    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
+    B = cu_seqlens.numel() - 1
+    _check(
+        lib().dl_attn_prefill_cached(
+            _p(q), q.stride(0), _p(k_slab), _p(v_slab), k_slab.stride(0), k_slab.stride(1), _p(kv_len), _p(out), out.stride(0), _p(cu_seqlens), B,
+            int(max_seqlen), int(max_kv_len), n_heads, n_kv_heads, head_dim, dtype_code(q.dtype), _stream(),
+        ),
+        "dl_attn_prefill_cached",
     )
     return out
 

@@ -874,8 +874,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             cache = KVSlabCache.from_legacy_cache(cache, self.config.sparse_config["sparse_layer"], device=self.device)
         decode = cache is not None and max(cache.full_len_host) > 0
         if decode:
-            if input_ids is None or input_ids.shape[1] != 1:
-                raise NotImplementedError("multi-token forward on a non-empty cache (DML:2506-2521) is SURVEY 8f row N2")
+            if input_ids is None:
+                raise NotImplementedError("inputs_embeds on a non-empty cache")
+            if input_ids.shape[1] != 1:
+                return self._forward_chunk(input_ids, attention_mask, cache)
             B = input_ids.shape[0]
             st = self._get_dstate(B, 0)
             cache.ensure_capacity(2)
@@ -937,6 +939,67 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             raise NotImplementedError("use_cache=False expects equally long rows")
         logits = F.linear(x, self.lm_head.weight).float().view(p["B"], lens2[0], -1)
         return CausalLMOutputWithPast(logits=logits, past_key_values=None)
+
+    def _forward_chunk(self, input_ids, attention_mask, cache: KVSlabCache):
+        """T > 1 new tokens on a non-empty cache -- the multi-round "new instruct" call (DML:2506-2521: the instruct
+        predictor decides which of the chunk's tokens are stored in layers >= sparse_layer, the last one always) or, without the
+        instruct predictor, plain chunked prefill.  Every chunk token attends to the cache and causally to the chunk
+        (CU:256-268 `get_cache`), then only the kept K/V rows stay in the slab (CU:165-241, without the zero padding)."""
+        cfg, sc = self.config, self.config.sparse_config
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError("padded chunks on a cache")
+        dev, dt = self.device, self.dtype
+        B, T = input_ids.shape
+        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
+        instruct = bool(sc["use_text_predictor"] and sc["use_instruct_predictor"]) and SL < L
+        cache.ensure_capacity(T + 1)
+        cos, sin = self._rope_tables(max(cache.full_len_host) + T + 1)
+        sparse_host = cache.lens[1].tolist()  # one device->host copy per chunk (the reference syncs per row per layer, CU:197-199)
+        total = B * T
+        cu = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=dev)
+        h = self.model.embed_tokens(input_ids.reshape(-1).to(dev)).clone()
+        x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps)
+        keep_idx = None
+        for i, layer in enumerate(self.model.layers):
+            if i == SL and instruct:
+                tp = self.model.instruct_score_predictor
+                dec = torch.empty(total, dtype=torch.int32, device=dev)
+                lg = torch.empty((total, 2), dtype=torch.float32, device=dev)
+                tp.decide(h, torch.empty(total * tp.d_model, dtype=torch.float32, device=dev), lg, dec)
+                dec = dec.view(B, T)
+                dec[:, -1] = 1  # DML:2521
+                keep_idx = [torch.nonzero(dec[b]).flatten() for b in range(B)]
+                if self.debug_records is not None:
+                    self.debug_records.update(text_decision=dec.clone(), text_logit=lg.view(B, T, 2).clone())
+            g = cache.group(i)
+            lens = cache.lens[g]
+            bound = (max(cache.full_len_host) if g == 0 else max(sparse_host)) + T
+            qkv = F.linear(x, layer.w_qkv)
+            ops.rope_kv_write(qkv, cos, sin, cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
+            attn = torch.empty((total, nH * d), dtype=dt, device=dev)
+            ops.attn_prefill_cached(qkv[:, : nH * d], cache.k[i], cache.v[i], lens, attn, cu, T, bound, nH, nKV, d)
+            if keep_idx is not None and g == 1:  # keep only the chosen rows of this chunk, packed right after the old ones
+                for b in range(B):
+                    n, src = int(keep_idx[b].numel()), keep_idx[b] + sparse_host[b]
+                    cache.k[i][b, :, sparse_host[b] : sparse_host[b] + n] = cache.k[i][b][:, src]
+                    cache.v[i][b, :, sparse_host[b] : sparse_host[b] + n] = cache.v[i][b][:, src]
+            o = F.linear(attn, layer.self_attn.o_proj.weight)
+            x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
+            act = ops.silu_mul(F.linear(x, layer.w_gu))
+            dn = F.linear(act, layer.mlp.down_proj.weight)
+            nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
+            x = ops.add_rmsnorm(h, dn, nw, eps)
+        cache.lens[0] += T
+        if keep_idx is not None:
+            cache.lens[1] += torch.tensor([int(k.numel()) for k in keep_idx], dtype=torch.int32, device=dev)
+        else:
+            cache.lens[1] += T
+        cache.full_len_host = [n + T for n in cache.full_len_host]
+        cache.seen_tokens += T
+        cache.sparse_cap = min(cache.t_cap, max(sparse_host) + T + (cache.t_cap - max(cache.full_len_host)))
+        logits = F.linear(x, self.lm_head.weight).float().view(B, T, -1)
+        return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
 
     def _first_token(self, st, x_last, min_new):
         torch.matmul(x_last, self.lm_head.weight.t(), out=st.logits)

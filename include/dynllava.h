@@ -77,6 +77,14 @@ int dl_attn_prefill(const void* q, const void* k, const void* v, int64_t q_row_s
                     void* out, int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen,
                     int n_heads, int n_kv_heads, int head_dim, int causal, int dtype, void* stream);
 
+/* ---- chunk on a cache (multi-round "new instruct", DML:2506-2521 / chunked prefill): causal attention of a packed chunk of
+ * queries against the KV slab.  Row b's chunk keys must already sit in the slab at [kv_len[b], kv_len[b] + L_b) (dl_rope_kv_write
+ * with kv_base = kv_len); query j of row b attends keys [0, kv_len[b] + j].  max_kv_len >= max_b (kv_len[b] + L_b) (host bound). */
+int dl_attn_prefill_cached(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t slab_stride_b,
+                           int64_t slab_stride_h, const int32_t* kv_len, void* out, int64_t out_row_stride,
+                           const int32_t* cu_seqlens, int B, int max_seqlen, int max_kv_len, int n_heads, int n_kv_heads,
+                           int head_dim, int dtype, void* stream);
+
 /* ---- F9 (decode) + F11: one query token per row against the ragged KV slab (DML:1061-1122 with
  * CU:256-268).  Row b attends keys [0, kv_len[b] + extra) of its slab; q: [B, q_row_stride].
  * Split-KV: `n_splits` workgroups per (row, head); partials in `workspace` (float), merged by a

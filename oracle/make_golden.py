@@ -41,6 +41,10 @@ CASES = {
     "tiny_bf16_instruct": dict(dtype="bfloat16", sparse=dict(use_instruct_predictor=True), prompts=[(5, 23)], steps=8, gain=50.0),
     # decode WITHOUT KV cache (use_cache=False, DML:2393-2504), driven like
     # llava/dynamic_eval/bench_test/dynamic_llava_long_text_time_with_no_cache.py:319-343 (whole sequence re-run per step)
+    # multi-round dialogue -- a new instruct chunk (T > 1) on a non-empty cache (DML:2506-2521); with the
+    # instruct predictor off the same call is plain chunked prefill on a cache
+    "tiny_fp32_multiround": dict(dtype="float32", sparse=dict(use_instruct_predictor=True), prompts=[(5, 9)], steps=0, gain=50.0, rounds=[3, ("chunk", 8), 4, ("chunk", 5), 3]),
+    "tiny_fp32_chunked": dict(dtype="float32", sparse={}, prompts=[(5, 9)], steps=0, gain=50.0, rounds=[2, ("chunk", 7), 3]),
     "tiny_fp32_nocache": dict(dtype="float32", sparse={}, prompts=[(5, 7)], steps=10, gain=50.0, nocache=True),
     "tiny_fp32_nocache_b2": dict(dtype="float32", sparse={}, prompts=[(5, 7), (5, 7)], steps=6, gain=50.0, nocache=True),
 }
@@ -151,6 +155,42 @@ def run_reference_nocache(dll, cfg, sd, clip, dtype, input_ids, images, steps, f
     return res
 
 
+def run_reference_rounds(dll, cfg, sd, clip, dtype, input_ids, images, rounds, seed=0):
+    """prefill, then a schedule of single-token decode steps (int n) and multi-token chunks (("chunk", T)) on the growing cache."""
+    model = build_reference_model(dll, cfg, sd, clip, dtype)
+    cap = {}
+    L = cfg.sparse_config["sparse_layer"]
+    model.model.layers[L].register_forward_pre_hook(lambda m, a, kw: cap.__setitem__("text_decision", kw.get("text_decision")), with_kwargs=True)
+    g = torch.Generator().manual_seed(4000 + seed)
+    B = input_ids.shape[0]
+    calls = [input_ids]
+    for r in rounds:
+        if isinstance(r, int):
+            calls += [torch.randint(3, cfg.vocab_size, (B, 1), generator=g) for _ in range(r)]
+        else:
+            calls.append(torch.randint(3, cfg.vocab_size, (B, r[1]), generator=g))
+    out = dict(step_logits=[], len_first=[], len_last=[], kv_len_first=[], kv_len_last=[])
+    pkv = None
+    with torch.inference_mode():
+        for j, ids in enumerate(calls):
+            cap.clear()
+            o = model(ids, images=images.to(dtype) if j == 0 else None, past_key_values=pkv)
+            pkv = o.past_key_values
+            out["step_logits"].append(o.logits[:, -1, :].float().numpy().copy())
+            td = cap.get("text_decision")
+            out.setdefault("decisions", []).append(np.zeros((B, 0), dtype=np.int64) if td is None else td.long().numpy().copy())
+            out["len_first"].append(pkv[1][0].numpy().copy())
+            out["len_last"].append(pkv[1][-1].numpy().copy())
+            out["kv_len_first"].append(pkv[0][0][0].shape[-2])
+            out["kv_len_last"].append(pkv[0][-1][0].shape[-2])
+    res = {k: np.stack(v) for k, v in out.items() if k != "decisions"}
+    for j, (ids, d) in enumerate(zip(calls, out["decisions"])):
+        res[f"call_ids_{j}"] = ids.numpy()
+        res[f"decision_{j}"] = d
+    res["n_calls"] = np.array(len(calls))
+    return res
+
+
 def pad_prompts(prompts):
     n = max(p.shape[0] for p in prompts)
     assert all(p.shape[0] == n for p in prompts), "golden cases use equal-length rows (reference B>1 + padding is not a supported eval mode)"
@@ -173,9 +213,11 @@ def main():
         input_ids = pad_prompts(prompts)
         images = fx.make_images(cfg, len(prompts), seed=0)
         forced = None
-        if not c.get("greedy", False):  # teacher forcing, like the reference's own loop (BLTM:310-337 feeds label ids)
+        if not c.get("greedy", False) and not c.get("rounds"):  # teacher forcing, like the reference's own loop (BLTM:310-337 feeds label ids)
             forced = fx.make_forced_tokens(cfg, c["steps"] + 1, len(prompts), seed=0)
-        if c.get("nocache"):
+        if c.get("rounds"):
+            res = run_reference_rounds(dll, cfg, sd, clip, dtype, input_ids, images, c["rounds"])
+        elif c.get("nocache"):
             res = run_reference_nocache(dll, cfg, sd, clip, dtype, input_ids, images, c["steps"], forced)
         else:
             res = run_reference(dll, cfg, sd, clip, dtype, input_ids, images, c["steps"], forced)
@@ -184,7 +226,9 @@ def main():
             res["forced"] = forced.numpy()
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **res)
-        if c.get("nocache"):
+        if c.get("rounds"):
+            print(name, "kv_first", res["kv_len_first"].tolist(), "kv_last", res["kv_len_last"].tolist())
+        elif c.get("nocache"):
             print(name, "ids", res["ids"][:, 0].tolist(), "logits_len", res["logits_len"].tolist())
         else:
             print(name, "ids", res["ids"][:, 0].tolist(), "kv_last", res["kv_len_last"].tolist(), "dec", res["text_decision"][:, 0].tolist())

@@ -463,7 +463,12 @@ class Oracle:
                         d_["answer"][0] -= drop_i
                         d_["answer"][1] -= drop_i
                 elif past_len and h.shape[1] > 1 and sc["use_instruct_predictor"]:
-                    raise NotImplementedError("new-instruct round with a cache (DML:2506-2521) is SURVEY 8f row N2b")
+                    # DML:2506-2521 -- a new instruct chunk on top of a cache (multi-round dialogue): every new token attends to the
+                    # cache and to the chunk (causally); only the tokens the instruct predictor keeps (the last one always) are stored
+                    tl = text_predictor(self.sd, "model.instruct_score_predictor.", h).reshape(B, -1, 2)
+                    text_decision = tl[:, :, 0] > tl[:, :, 1]
+                    text_decision[:, -1:] = True
+                    rec.update(text_logit=tl, text_decision=text_decision)
                 elif (not past_len) and input_embeds_indices is not None and B == len(input_embeds_indices) and sc["use_output_text_predictor"] and not use_cache:
                     # DML:2393-2504 -- output infer stage WITHOUT KV cache: the whole sequence is re-run every step and the answer
                     # tokens [answer_indice, -1) are compacted by top-k of the RAW keep logit, k = max kept count over the batch.

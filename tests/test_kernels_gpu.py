@@ -458,3 +458,33 @@ def test_c_abi_rejects_bad_arguments(ops):
         ops.rmsnorm(x, torch.ones(100, dtype=torch.bfloat16, device="cuda"), 1e-5)  # H % 8 != 0
     with pytest.raises(ops.HipOpsError):
         ops.rmsnorm(torch.zeros(4, 128), torch.ones(128), 1e-5)  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nH,nKV,d", [(4, 4, 128), (4, 2, 64)])
+def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d):
+    """Chunk of queries against the KV slab: query j of row b sees keys [0, kv_len[b] + j]."""
+    g = torch.Generator().manual_seed(18)
+    kv_len = [0, 37, 200]
+    Lq = [70, 5, 64]
+    B, T_cap = 3, 300
+    k_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    v_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    total = sum(Lq)
+    q = torch.randn(total, nH * d, generator=g).to(dtype)
+    cu = torch.tensor([0] + list(torch.tensor(Lq).cumsum(0)), dtype=torch.int32)
+    out = torch.full((total, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_prefill_cached(q.cuda(), k_slab.cuda(), v_slab.cuda(), torch.tensor(kv_len, dtype=torch.int32).cuda(), out, cu.cuda(), max(Lq),
+                            max(a + b for a, b in zip(kv_len, Lq)), nH, nKV, d)
+    out = out.cpu().float().view(total, nH, d)
+    assert torch.isfinite(out).all()
+    for b in range(B):
+        a, e = int(cu[b]), int(cu[b + 1])
+        Lk = kv_len[b] + Lq[b]
+        qf = q[a:e].float().view(Lq[b], nH, d).transpose(0, 1)
+        kf = k_slab[b, :, :Lk].float().repeat_interleave(nH // nKV, dim=0)
+        vf = v_slab[b, :, :Lk].float().repeat_interleave(nH // nKV, dim=0)
+        mask = torch.arange(Lk)[None, :] <= (torch.arange(Lq[b])[:, None] + kv_len[b])
+        ref = F.scaled_dot_product_attention(qf[None], kf[None], vf[None], attn_mask=mask)[0].transpose(0, 1)
+        tol = 2e-5 if dtype == torch.float32 else 6 * ULP[dtype]
+        assert float((out[a:e] - ref).abs().max()) < tol, f"row {b}"

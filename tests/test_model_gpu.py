@@ -40,7 +40,7 @@ def _golden_setup(name):
     return c, dtype, cfg, sd, clip
 
 
-@pytest.mark.parametrize("name", sorted(n for n in CASES if "b3" not in n and not CASES[n].get("nocache")))
+@pytest.mark.parametrize("name", sorted(n for n in CASES if "b3" not in n and not CASES[n].get("nocache") and not CASES[n].get("rounds")))
 def test_forward_loop_vs_reference_golden(name, golden_dir):
     """The reference's own driver loop (dynamic_llava_long_text_mem.py:310-337): model(ids, images=..., past_key_values=pkv)."""
     c, dtype, cfg, sd, clip = _golden_setup(name)
@@ -374,3 +374,25 @@ def test_nocache_decode_vs_reference_golden(name, golden_dir):
         np.testing.assert_array_equal(pos, g[f"position_ids_{j}"], err_msg=f"step {j}")
         assert np.abs(out.logits[:, -1].cpu().numpy() - g["step_logits"][j]).max() < 1e-3, f"step {j}"
         total = torch.cat([total, forced[j][:, None]], dim=1)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n].get("rounds")))
+def test_multiround_chunks_on_cache_vs_reference_golden(name, golden_dir):
+    """multi-token chunks on a non-empty cache (new-instruct round DML:2506-2521 / chunked prefill),
+    interleaved with decode steps; logits, per-token store decisions and KV lengths against the reference."""
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    model.debug_records = {}
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    pkv = None
+    for j in range(int(g["n_calls"])):
+        ids = torch.from_numpy(g[f"call_ids_{j}"]).cuda()
+        out = model(ids, images=images if j == 0 else None, past_key_values=pkv)
+        pkv = out.past_key_values
+        assert np.abs(out.logits[:, -1].cpu().numpy() - g["step_logits"][j]).max() < 1e-3, f"call {j}"
+        np.testing.assert_array_equal(pkv[1][0].numpy(), g["len_first"][j], err_msg=f"call {j}")
+        np.testing.assert_array_equal(pkv[1][-1].numpy(), g["len_last"][j], err_msg=f"call {j}")
+        assert pkv[0][0][0].shape[-2] == g["kv_len_first"][j] and pkv[0][-1][0].shape[-2] == g["kv_len_last"][j]
+        if ids.shape[1] > 1 and j > 0 and g[f"decision_{j}"].size:
+            np.testing.assert_array_equal(model.debug_records["text_decision"].cpu().numpy(), g[f"decision_{j}"])

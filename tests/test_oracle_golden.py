@@ -46,7 +46,33 @@ def _run_case(name, golden_dir, tie_break):
             cur = nxt[:, None] if forced is None else forced[j][:, None]
 
 
-STD = sorted(n for n in CASES if not CASES[n].get("nocache"))
+STD = sorted(n for n in CASES if not CASES[n].get("nocache") and not CASES[n].get("rounds"))
+ROUNDS = sorted(n for n in CASES if CASES[n].get("rounds"))
+
+
+@pytest.mark.parametrize("name", ROUNDS)
+def test_oracle_multiround_matches_reference_golden(name, golden_dir):
+    """multi-token chunks on a non-empty cache (DML:2506-2521 with the instruct predictor, plain chunked prefill
+    without), interleaved with single-token decode steps."""
+    c = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dtype = getattr(torch, c["dtype"])
+    cfg = fx.tiny_config(**c["sparse"])
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
+    o = Oracle(cfg, sd, dtype, clip=fx.build_clip(cfg, seed=1), tie_break="torch")
+    images = fx.make_images(cfg, 1, seed=0).to(dtype)
+    pkv = None
+    with torch.no_grad():
+        for j in range(int(g["n_calls"])):
+            ids = torch.from_numpy(g[f"call_ids_{j}"])
+            logits, pkv = o.forward(ids, images=images if j == 0 else None, past_key_values=pkv)
+            np.testing.assert_array_equal(logits[:, -1].float().numpy(), g["step_logits"][j], err_msg=f"call {j}")
+            np.testing.assert_array_equal(pkv[1][0].numpy(), g["len_first"][j])
+            np.testing.assert_array_equal(pkv[1][-1].numpy(), g["len_last"][j])
+            assert pkv[0][0][0].shape[-2] == g["kv_len_first"][j] and pkv[0][-1][0].shape[-2] == g["kv_len_last"][j]
+            td = o.records.get("text_decision")
+            if g[f"decision_{j}"].size:
+                np.testing.assert_array_equal(td.long().numpy(), g[f"decision_{j}"])
 NOCACHE = sorted(n for n in CASES if CASES[n].get("nocache"))
 
 
