@@ -6,6 +6,8 @@
 // MFMA B-operands are 16-byte LDS reads); S = Q K^T and O += P V on v_mfma_f32_16x16x32_{bf16,f16};
 // online softmax in fp32 on the MFMA C layout (row = (lane>>4)*4 + reg, col = lane&15).
 // f32: simple wave-per-query kernel (parity/debug path, exact fp32 arithmetic).
+#include <stdlib.h>
+
 #include "dl_common.h"
 
 namespace dl {
@@ -25,10 +27,12 @@ __device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b,
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-constexpr int kBM = 64, kBN = 64, kPad = 8;
+constexpr int kBN = 64, kPad = 8;
 
-template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
+// NW waves per workgroup, 16 query rows per wave (BM = 16 * NW): small prompts use fewer waves per workgroup so that the
+// grid still covers the chip (T=170, 32 heads: NW=4 -> 96 workgroups, NW=1 -> 352).
+template <typename T, int D, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
                                                                  const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
                                                                  void* __restrict__ out_, int64_t out_rs,
                                                                  const int32_t* __restrict__ cu, int n_rep, float scale,
@@ -43,7 +47,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __re
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S* Ks = reinterpret_cast<S*>(smem);   // [kBN][LDK]
   S* Vt = Ks + kBN * LDK;               // [D][LDV]
-  S* Ps = Vt + D * LDV;                 // [4][16][LDP]
+  S* Ps = Vt + D * LDV;                 // [NW][16][LDP]
+  constexpr int kBM = 16 * NW;
+  constexpr int NT_ = NW * 64;
 
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tok0 = cu[b];
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const void* __re
     // ---- stage K (row-major) and V (transposed) tiles ----
     constexpr int CPR = D / 8;  // 16-byte chunks per row
 #pragma unroll
-    for (int it = 0; it < (kBN * CPR) / 256; ++it) {
-      const int idx = it * 256 + tid;
+    for (int it = 0; it < (kBN * CPR) / NT_; ++it) {
+      const int idx = it * NT_ + tid;
       const int key = idx / CPR, ch = idx % CPR;
       uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
       if (key0 + key < Lk) {
@@ -245,15 +251,24 @@ template <typename T, int D>
 static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_rs, int64_t kv_rs, void* out, int64_t out_rs,
                         const int32_t* cu, int B, int max_seqlen, int n_heads, int n_rep, int causal, hipStream_t st,
                         const int32_t* kv_len = nullptr, int64_t kv_sb = 0, int64_t kv_sh = 0) {
-  const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + 4 * 16 * (kBN + kPad)) * 2;
-  const dim3 grid((unsigned)((max_seqlen + kBM - 1) / kBM), (unsigned)n_heads, (unsigned)B);
   const float scale = 1.0f / sqrtf((float)D);
-  if (causal)
-    hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, true>), grid, dim3(256), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep,
-                       scale, kv_len, kv_sb, kv_sh);
-  else
-    hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, false>), grid, dim3(256), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep,
-                       scale, kv_len, kv_sb, kv_sh);
+  // tools/bench_attn_prefill.py: 2 waves (32 query rows) per workgroup win for short rows (more workgroups, 16-180 us range),
+  // 4 waves for long ones; 1 wave never wins (each workgroup then stages whole K/V tiles alone)
+  int nw = max_seqlen <= 256 ? 2 : 4;
+  if (const char* e = getenv("DL_PF_NW")) nw = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 4);  // tuning experiments only
+#define DL_LAUNCH_PF(NWV, CAUS)                                                                                                          \
+  {                                                                                                                                      \
+    const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + NWV * 16 * (kBN + kPad)) * 2;                                     \
+    const dim3 grid((unsigned)((max_seqlen + 16 * NWV - 1) / (16 * NWV)), (unsigned)n_heads, (unsigned)B);                              \
+    hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, CAUS, NWV>), grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, \
+                       cu, n_rep, scale, kv_len, kv_sb, kv_sh);                                                                          \
+  }
+  if (causal) {
+    if (nw == 4) DL_LAUNCH_PF(4, true) else if (nw == 2) DL_LAUNCH_PF(2, true) else DL_LAUNCH_PF(1, true)
+  } else {
+    if (nw == 4) DL_LAUNCH_PF(4, false) else if (nw == 2) DL_LAUNCH_PF(2, false) else DL_LAUNCH_PF(1, false)
+  }
+#undef DL_LAUNCH_PF
 }
 
 }  // namespace dl
