@@ -122,7 +122,7 @@ def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim):
     ms = graph_time_ms(launch)
     nbytes = sum(2 * t * H * 2 + 2 * H * 2 for t in T_list)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    name = "dl_attn_decode_rope (attn_decode_split_kernel<bf16,128,4,fused>" + (" + attn_decode_combine_kernel)" if n_splits > 1 else ")")
+    name = "dl_attn_decode_rope (attn_decode_split_kernel<bf16,128,4,fused,4>" + (" + attn_decode_combine_kernel)" if n_splits > 1 else ")")
     return {"kernel": name, "shape": label, "n_splits": n_splits, "bytes": nbytes, "us": round(ms * 1e3, 3), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 

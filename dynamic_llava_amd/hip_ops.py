@@ -66,7 +66,7 @@ SIGNATURES = {
     ),
     "dl_attn_decode_rope": (
         c_int,
-        [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -81,6 +81,7 @@ SIGNATURES = {
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv_set_tuning": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -231,7 +232,7 @@ def attn_prefill_cached(q, k_slab, v_slab, kv_len, out, cu_seqlens, max_seqlen, 
 
 def attn_decode_workspace(B, n_heads, head_dim, n_splits, device):
     nbytes = lib().dl_attn_decode_workspace_bytes(B, n_heads, head_dim, n_splits)
-    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
+    return torch.zeros(max(int(nbytes) // 4, 1), dtype=torch.float32, device=device)
 
 
 def attn_decode(q, k_slab, v_slab, kv_len, extra, out, workspace, n_splits, n_heads, n_kv_heads, head_dim):
@@ -249,7 +250,7 @@ def attn_decode(q, k_slab, v_slab, kv_len, extra, out, workspace, n_splits, n_he
     return out
 
 
-def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, workspace, n_splits, n_heads, n_kv_heads, head_dim, wg_waves=4):
+def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, workspace, n_splits, n_heads, n_kv_heads, head_dim, keys_in_flight=64, chunk_keys=0):
     """Fused RoPE + KV append + ragged decode attention.  qkv [B, (nH+2nKV)*d] un-rotated (not modified)."""
     _dev(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out)
     assert qkv.stride(1) == 1 and out.stride(1) == 1 and kv_len.dtype == torch.int32 and pos_base.dtype == torch.int32
@@ -258,7 +259,7 @@ def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, works
     _check(
         lib().dl_attn_decode_rope(
             _p(qkv), qkv.stride(0), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(0), k_slab.stride(1),
-            k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), int(wg_waves), B, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
+            k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), int(keys_in_flight), int(chunk_keys), B, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
         ),
         "dl_attn_decode_rope",
     )
@@ -381,3 +382,7 @@ def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos
         "dl_decode_advance",
     )
     return next_ids
+
+
+def launch_probe(grid=1, block=64):
+    _check(lib().dl_launch_probe(int(grid), int(block), _stream()), "dl_launch_probe")

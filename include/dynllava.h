@@ -98,13 +98,16 @@ int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, cons
 /* ---- F8 + F10 + F9 (decode) in ONE launch: RoPE of q and of the new key (DML:260-285), the KV append of the new token at
  * slot kv_len[b] (CU:109-268) and the ragged attention over keys [0, kv_len[b]] (DML:1061-1122).
  * qkv: [B, qkv_row_stride] UN-rotated projection output (q heads | k heads | v heads), not modified.
- * pos_base[b]: RoPE position of the new token.  Same split-KV scheme as dl_attn_decode; wg_waves = 4 or 16 waves per
- * workgroup (256 / 1024 threads). */
+ * pos_base[b]: RoPE position of the new token.  Same split-KV scheme as dl_attn_decode.
+ * keys_in_flight = 64 or 256: K/V rows a workgroup requests per loop trip (256 = one HBM round trip for a 256-key split:
+ * the batch-1 decode step is latency-bound).  chunk_keys > 0: split s owns keys [s*chunk_keys, (s+1)*chunk_keys) (the last
+ * split also takes any remainder), so the K/V rows are requested before kv_len[b] has been read; 0: the kernel balances
+ * ceil((kv_len[b]+1) / n_splits) keys per split itself.  Results are identical either way up to the merge order. */
 int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
                         const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab,
                         int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride,
-                        void* workspace, int n_splits, int wg_waves, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
-                        void* stream);
+                        void* workspace, int n_splits, int keys_in_flight, int chunk_keys, int B, int n_heads, int n_kv_heads,
+                        int head_dim, int dtype, void* stream);
 
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
@@ -193,6 +196,9 @@ int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_s
                       int64_t* next_ids, int64_t* out_ids, int out_cap, int32_t* step, int32_t* finished,
                       int eos_id, int pad_id, int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision,
                       void* stream);
+
+/* ---- diagnostics: one empty kernel (launch-floor measurements, tools/bench_launch_floor.py). */
+int dl_launch_probe(int grid, int block, void* stream);
 
 #ifdef __cplusplus
 }
