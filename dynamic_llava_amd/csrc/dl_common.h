@@ -60,6 +60,10 @@ __device__ __forceinline__ float f16_bits_to_float(uint16_t b) {
   return (float)h;
 }
 __device__ __forceinline__ uint16_t float_to_f16_bits(float f) {
+  // The value must exist as an fp32 number before it is rounded to fp16, as in the eager reference (fp32 op, then a cast).
+  // Without the barrier the compiler folds `cast(a * b)` into v_fma_mixlo_f16, which rounds the exact product ONCE: a different
+  // result whenever the fp32 product lands on an fp16 tie (e.g. 1.702f * x in QuickGELU: 4e-4 of all elements).
+  asm("" : "+v"(f));
   _Float16 h = (_Float16)f;  // v_cvt_f16_f32: RNE
   uint16_t b;
   __builtin_memcpy(&b, &h, 2);

@@ -57,16 +57,19 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_
 }
 
 // ---- nn.LayerNorm over the last dim (predictors: DML:1325,1375; CTL:293,308), optional row gather ----
-template <typename T>
-__global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* __restrict__ x_, const int32_t* __restrict__ row_index,
-                                                              const void* __restrict__ w_, const void* __restrict__ b_,
-                                                              void* __restrict__ out_, int H, float eps) {
+// ADD (the CLIP encoder layer's `residual + hidden_states` followed by the next LayerNorm, HF modeling_clip CLIPEncoderLayer.forward):
+// x = cast(x + delta) first, written back in place.
+template <typename T, bool ADD>
+__global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* x_, const int32_t* __restrict__ row_index,
+                                                              const void* __restrict__ delta_, const void* __restrict__ w_,
+                                                              const void* __restrict__ b_, void* __restrict__ out_, int H, float eps) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const int64_t src = row_index ? (int64_t)row_index[row] : row;
   const S* xr = reinterpret_cast<const S*>(x_) + src * H;
+  const S* delta = ADD ? reinterpret_cast<const S*>(delta_) + row * H : nullptr;
   const int nvec = H / V;
   float x[kMaxVecPerThread][V];
   float s = 0.f;
@@ -75,10 +78,18 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* __restr
     const int v = threadIdx.x + i * kThreads;
     if (v < nvec) {
       load16<T>(xr + v * V, x[i]);
+      if constexpr (ADD) {
+        float d[V];
+        load16<T>(delta + v * V, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
+        store16<T>(const_cast<S*>(xr) + v * V, x[i]);
+      }
 #pragma unroll
       for (int j = 0; j < V; ++j) s += x[i][j];
     }
   }
+  if (w_ == nullptr) return;  // residual add only
   const float mean = block_sum<4>(s, red) / (float)H;
   float q = 0.f;
 #pragma unroll
@@ -107,6 +118,26 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* __restr
       for (int j = 0; j < V; ++j) o[j] = (x[i][j] - mean) * rstd * wv[j] + bv[j];
       store16<T>(out + v * V, o);
     }
+  }
+}
+
+// ---- CLIP's QuickGELU (HF activations.QuickGELUActivation: `input * torch.sigmoid(1.702 * input)`), three roundings as in eager ----
+template <typename T>
+__global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const void* __restrict__ x_, void* __restrict__ out_, int64_t nvec) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  const S* x = reinterpret_cast<const S*>(x_);
+  S* out = reinterpret_cast<S*>(out_);
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < nvec; idx += (int64_t)gridDim.x * kThreads) {
+    float a[V], o[V];
+    load16<T>(x + idx * V, a);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float t = Elem<T>::round(1.702f * a[j]);
+      const float sg = Elem<T>::round(1.0f / (1.0f + expf(-t)));
+      o[j] = a[j] * sg;
+    }
+    store16<T>(out + idx * V, o);
   }
 }
 
@@ -174,10 +205,40 @@ extern "C" int dl_layernorm(const void* x, const int32_t* row_index, const void*
   if (rows == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_layernorm: unsupported H=%d", H);
-    hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), x, row_index, w, b, out, H,
-                       eps);
+    hipLaunchKernelGGL((layernorm_kernel<T, false>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), x, row_index, nullptr, w,
+                       b, out, H, eps);
   });
   DL_CHECK_LAUNCH("dl_layernorm");
+  return DL_OK;
+}
+
+extern "C" int dl_add_layernorm(void* h, const void* delta, const void* w, const void* b, void* out, int64_t rows, int H, float eps,
+                                int dtype, void* stream) {
+  DL_REQUIRE(h && delta, "dl_add_layernorm: NULL pointer");
+  DL_REQUIRE((w == nullptr) == (out == nullptr) && (w == nullptr) == (b == nullptr), "dl_add_layernorm: w, b and out must all be given or all be NULL");
+  DL_REQUIRE(rows >= 0 && H > 0, "dl_add_layernorm: bad shape");
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_layernorm: unsupported H=%d", H);
+    hipLaunchKernelGGL((layernorm_kernel<T, true>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, nullptr, delta, w, b,
+                       out, H, eps);
+  });
+  DL_CHECK_LAUNCH("dl_add_layernorm");
+  return DL_OK;
+}
+
+extern "C" int dl_quick_gelu(const void* x, void* out, int64_t n, int dtype, void* stream) {
+  DL_REQUIRE(x && out, "dl_quick_gelu: NULL pointer");
+  DL_REQUIRE(n >= 0, "dl_quick_gelu: bad size");
+  if (n == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(n % Elem<T>::kVec == 0, "dl_quick_gelu: n must be a multiple of %d", Elem<T>::kVec);
+    const int64_t nvec = n / Elem<T>::kVec;
+    const int64_t blocks = (nvec + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL((quick_gelu_kernel<T>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kThreads), 0, as_stream(stream), x, out,
+                       nvec);
+  });
+  DL_CHECK_LAUNCH("dl_quick_gelu");
   return DL_OK;
 }
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "dl_gemv_set_tuning": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
+    "dl_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_quick_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -309,6 +311,26 @@ def layernorm(x, w, b, eps=1e-5, row_index=None, rows=None):
     rows = (x.numel() // H) if rows is None else rows
     out = torch.empty((rows, H), dtype=x.dtype, device=x.device)
     _check(lib().dl_layernorm(_p(x), _p(row_index), _p(w), _p(b), _p(out), rows, H, eps, dtype_code(x.dtype), _stream()), "dl_layernorm")
+    return out
+
+
+def add_layernorm(h, delta, w=None, b=None, eps=1e-5, out=None):
+    """h += delta in place (rounded to the dtype); returns LN(h) * w + b (or None when w is None: residual add only)."""
+    _dev(h, delta, w, b, out)
+    assert h.is_contiguous() and delta.is_contiguous() and h.shape == delta.shape
+    H = h.shape[-1]
+    rows = h.numel() // H
+    if w is not None and out is None:
+        out = torch.empty_like(h)
+    _check(lib().dl_add_layernorm(_p(h), _p(delta), _p(w), _p(b), _p(out) if w is not None else None, rows, H, eps, dtype_code(h.dtype), _stream()), "dl_add_layernorm")
+    return out if w is not None else None
+
+
+def quick_gelu(x, out=None):
+    _dev(x, out)
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().dl_quick_gelu(_p(x), _p(out), x.numel(), dtype_code(x.dtype), _stream()), "dl_quick_gelu")
     return out
 
 

@@ -201,7 +201,8 @@ class TextPredictor(nn.Module):
 
 
 class CLIPVisionTower(nn.Module):
-    """llava/model/multimodal_encoder/clip_encoder.py:7-102 -- stays on PyTorch-ROCm (north_star)."""
+    """llava/model/multimodal_encoder/clip_encoder.py:7-102.  The HF CLIPVisionModel is the parameter container (state-dict keys
+    unchanged); forward() runs its encoder on the library GEMMs + this package's HIP kernels."""
 
     def __init__(self, cfg: DynamicLlavaConfig):
         super().__init__()
@@ -238,15 +239,85 @@ class CLIPVisionTower(nn.Module):
 
         conv.forward = types.MethodType(gemm_forward, conv)
 
+    def pack(self):
+        """Fuse q|k|v of every encoder layer into one [3C, C] weight (+bias) for a single projection GEMM.  Call after the
+        weights are loaded / cast (finalize() does)."""
+        vm = next(m for n, m in self.vision_tower.named_modules() if hasattr(m, "encoder") and hasattr(m, "embeddings"))
+        self._vm = [vm]  # in a list: not a registered submodule (the parameter tree / state-dict keys stay HF's)
+        self._qkv = []
+        for l in vm.encoder.layers:
+            a = l.self_attn
+            self._qkv.append((torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous(), torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()))
+        self._cu = {}
+        return self
+
+    def _n_layers_needed(self):
+        """hidden_states[k] is the stream after k encoder layers; select_layer = -2 needs L-1 of the L layers (HF computes all L
+        and throws the last one away)."""
+        L = len(self._vm[0].encoder.layers)
+        k = self.select_layer if self.select_layer >= 0 else L + 1 + self.select_layer
+        if not 0 <= k <= L:
+            raise ValueError(f"mm_vision_select_layer={self.select_layer} out of range for {L} layers")
+        return k
+
     @torch.no_grad()
     def forward(self, images):
-        out = self.vision_tower(images.to(device=self.device, dtype=self.dtype), output_hidden_states=True)
-        f = out.hidden_states[self.select_layer]
+        """clip_encoder.py:53-71 (`feature_select(vision_tower(images, output_hidden_states=True))`).  The encoder runs packed
+        ([B*T, C] rows, cu_seqlens) on: hipBLASLt for the plain GEMMs (bias fused), dl_layernorm / dl_add_layernorm (residual add +
+        next LayerNorm in one pass), dl_attn_prefill (non-causal MFMA flash attention, head_dim 64) and dl_quick_gelu -- 8 launches
+        per layer instead of the ~18 of the eager module, each rounding to the model dtype where the eager module does."""
+        if getattr(self, "_vm", None) is None:
+            self.pack()
+        vm = self._vm[0]
+        cfgv = vm.config if hasattr(vm, "config") else self.config
+        if cfgv.hidden_act != "quick_gelu":
+            raise ops.HipOpsError(f"CLIP hidden_act={cfgv.hidden_act!r}: only quick_gelu (OpenAI CLIP) is implemented")
+        x = images.to(device=self.device, dtype=self.dtype)
+        B = x.shape[0]
+        emb = vm.embeddings(x)  # patch GEMM + class token + position embedding (once per image; plain torch)
+        T, C = emb.shape[1], emb.shape[2]
+        nH = cfgv.num_attention_heads
+        d = C // nH
+        eps = cfgv.layer_norm_eps
+        pre = getattr(vm, "pre_layrnorm", None) or getattr(vm, "pre_layernorm")
+        h = ops.layernorm(emb.reshape(B * T, C).contiguous(), pre.weight, pre.bias, eps)
+        cu = self._cu.get(B)
+        if cu is None:
+            cu = self._cu[B] = (torch.arange(B + 1, device=h.device, dtype=torch.int32) * T).contiguous()
+        hip_attn = h.dtype == torch.float32 or d in (64, 128)
+        layers = vm.encoder.layers[: self._n_layers_needed()]
+        xn = ops.layernorm(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if len(layers) else None
+        for i, l in enumerate(layers):
+            wq, bq = self._qkv[i]
+            qkv = F.linear(xn, wq, bq)
+            if hip_attn:
+                attn = torch.empty((B * T, C), dtype=h.dtype, device=h.device)
+                ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
+            else:  # head dims the MFMA kernel does not tile (tiny test towers): torch SDPA on the same packed projection
+                q, k, v = (t.reshape(B, T, nH, d).transpose(1, 2) for t in qkv.split(C, dim=1))
+                attn = F.scaled_dot_product_attention(q, k, v, scale=d**-0.5).transpose(1, 2).reshape(B * T, C)
+            y = F.linear(attn, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias)
+            xn = ops.add_layernorm(h, y, l.layer_norm2.weight, l.layer_norm2.bias, eps)
+            g = ops.quick_gelu(F.linear(xn, l.mlp.fc1.weight, l.mlp.fc1.bias))
+            y = F.linear(g, l.mlp.fc2.weight, l.mlp.fc2.bias)
+            if i + 1 < len(layers):
+                nl = layers[i + 1]
+                xn = ops.add_layernorm(h, y, nl.layer_norm1.weight, nl.layer_norm1.bias, eps)
+            else:
+                ops.add_layernorm(h, y)
+        f = h.view(B, T, C)
         if self.select_feature == "patch":
             f = f[:, 1:]
         elif self.select_feature != "cls_patch":
             raise ValueError(f"Unexpected select feature: {self.select_feature}")
         return f.to(images.dtype) if images.is_floating_point() else f
+
+    @torch.no_grad()
+    def forward_eager(self, images):
+        """The HF module as the reference runs it (tests compare the packed path against this)."""
+        out = self.vision_tower(images.to(device=self.device, dtype=self.dtype), output_hidden_states=True)
+        f = out.hidden_states[self.select_layer]
+        return f[:, 1:] if self.select_feature == "patch" else f
 
     @property
     def dtype(self):
@@ -381,6 +452,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             raise ops.HipOpsError("the model must live on the GPU (no CPU path exists)")
         for l in self.model.layers:
             l.pack()
+        if self.get_vision_tower() is not None:
+            self.get_vision_tower().pack()
         self._packed = True
         self._build_rope(self.config.max_position_embeddings)
         self._dstate = None

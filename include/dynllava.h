@@ -137,6 +137,16 @@ int dl_linear(const void* A, int64_t lda, const void* W, const void* bias, void*
 int dl_layernorm(const void* x, const int32_t* row_index, const void* w, const void* b, void* out,
                  int64_t rows, int H, float eps, int dtype, void* stream);
 
+/* ---- the CLIP ViT tower's glue between its (library) GEMMs: llava/model/multimodal_encoder/clip_encoder.py:53-71 runs
+ * transformers' CLIPVisionModel, whose encoder layer is LN1 -> attention -> residual add -> LN2 -> fc1 -> QuickGELU -> fc2 ->
+ * residual add (transformers modeling_clip.py CLIPEncoderLayer.forward / CLIPMLP.forward; a pinned dependency, not under
+ * /root/reference).  dl_add_layernorm: h[r,:] = cast(h[r,:] + delta[r,:]) in place, then out[r,:] = LN(h[r,:]) * w + b
+ * (w = b = out = NULL: the add only).  dl_quick_gelu: out = cast(x * cast(sigmoid(cast(1.702 * x)))), the three roundings of
+ * the eager `input * torch.sigmoid(1.702 * input)`.  The attention itself is dl_attn_prefill (non-causal, head_dim 64). */
+int dl_add_layernorm(void* h, const void* delta, const void* w, const void* b, void* out, int64_t rows, int H, float eps,
+                     int dtype, void* stream);
+int dl_quick_gelu(const void* x, void* out, int64_t n, int dtype, void* stream);
+
 /* ---- F1: VisionPredictor.forward DML:1348-1359 (+ CTL:153-180, 320-323) followed by
  * log_softmax(...)[:, :, 0] DML:1867,1898.  All pointers are device pointers to nn.Module parameters
  * with the reference's state-dict layout (model.image_score_predictor.*). */

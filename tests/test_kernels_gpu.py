@@ -100,6 +100,37 @@ def test_layernorm_gather(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,H", [(577, 1024), (37, 64), (3, 4096)])
+def test_add_layernorm(ops, dtype, rows, H):
+    """CLIP encoder glue: h = cast(h + delta) in place (bit-exact), out = LayerNorm(h) as torch rounds it."""
+    g = torch.Generator().manual_seed(31)
+    h = torch.randn(rows, H, generator=g).to(dtype)
+    dl = torch.randn(rows, H, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(H, generator=g)).to(dtype)
+    h_ref = h + dl
+    ref = F.layer_norm(h_ref, (H,), w, b, 1e-5)
+    hd = h.cuda().clone()
+    out = ops.add_layernorm(hd, dl.cuda(), w.cuda(), b.cuda(), 1e-5)
+    assert torch.equal(hd.cpu(), h_ref), "residual stream must be bit-exact"
+    _close_ulp(out, ref, dtype, 1.0, atol=2e-6)
+    hd2 = h.cuda().clone()
+    assert ops.add_layernorm(hd2, dl.cuda()) is None and torch.equal(hd2.cpu(), h_ref), "add-only form"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_quick_gelu(ops, dtype):
+    """x * sigmoid(1.702 x) with the eager op's three roundings: exact up to the last-bit difference of expf implementations."""
+    g = torch.Generator().manual_seed(32)
+    x = (3 * torch.randn(577, 4096, generator=g)).to(dtype)
+    ref = x * torch.sigmoid(1.702 * x)
+    out = ops.quick_gelu(x.cuda())
+    _close_ulp(out, ref, dtype, 1.0, atol=1e-6)
+    if dtype != torch.float32:
+        assert _frac_exact(out, ref, dtype) > 0.999
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("nH,nKV,d", [(32, 32, 128), (8, 2, 128), (2, 2, 64)])
 def test_rope_kv_write_bit_exact(ops, dtype, nH, nKV, d):
     """RoPE reproduces the eager op's three roundings (DML:283-284) => bit-exact vs the oracle in every dtype."""

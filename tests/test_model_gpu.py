@@ -396,3 +396,38 @@ def test_multiround_chunks_on_cache_vs_reference_golden(name, golden_dir):
         assert pkv[0][0][0].shape[-2] == g["kv_len_first"][j] and pkv[0][-1][0].shape[-2] == g["kv_len_last"][j]
         if ids.shape[1] > 1 and j > 0 and g[f"decision_{j}"].size:
             np.testing.assert_array_equal(model.debug_records["text_decision"].cpu().numpy(), g[f"decision_{j}"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_clip_tower_packed_path_matches_eager_module(dtype):
+    """the CLIP ViT-L/14-336 tower on the packed HIP path (dl_layernorm / dl_add_layernorm / dl_attn_prefill /
+    dl_quick_gelu around the library GEMMs) against the HF module run eagerly, full size (24 layers, 577 tokens, 2 images).
+    fp32: equal to 1e-4.  16-bit: in the same noise class as the eager module itself, both judged against an fp32 run."""
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+    from dynamic_llava_amd.model import CLIPVisionTower
+
+    cfg = DynamicLlavaConfig.from_namespace(fx.llava7b_config(num_hidden_layers=1))
+    torch.manual_seed(5)
+    tower = CLIPVisionTower(cfg)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for n, p in tower.named_parameters():  # non-trivial LayerNorm affine / biases so that every term is exercised
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+    truth_tower = copy.deepcopy(tower).to("cuda", torch.float32)
+    imgs = torch.randn(2, 3, 336, 336, generator=g)
+    truth = truth_tower.forward_eager(imgs.cuda()).float()
+    t = tower.to("cuda", dtype).pack()
+    x = imgs.cuda().to(dtype)
+    eager = t.forward_eager(x).float()
+    hip = t(x).float()
+    assert hip.shape == (2, 576, 1024) and torch.isfinite(hip).all()
+    if dtype == torch.float32:
+        assert float((hip - truth).abs().max()) < 1e-4 * max(1.0, float(truth.abs().max()))
+        return
+    e_ref, e_hip = (eager - truth), (hip - truth)
+    assert float(e_hip.abs().max()) <= 2.0 * float(e_ref.abs().max()) + 1e-3, (float(e_hip.abs().max()), float(e_ref.abs().max()))
+    assert float(e_hip.pow(2).mean().sqrt()) <= 1.5 * float(e_ref.pow(2).mean().sqrt()) + 1e-4
+    # unused last layer is really skipped, CLS token dropped
+    t.select_feature = "cls_patch"
+    assert t(x).shape == (2, 577, 1024)
