@@ -254,8 +254,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     if (n_splits == 1) {
       store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + tid, L > 0.f ? O / L : 0.f);
     } else {
-      float* p = ws + (((int64_t)b * n_heads + h) * n_splits + split) * (D + 2);
-      p[2 + tid] = O;
+      float* p = ws + (((int64_t)b * n_heads + h) * n_splits + split) * (D + kAttnPartPad);
+      p[kAttnPartPad + tid] = O;
       if (tid == 0) {
         p[0] = M;
         p[1] = L;
@@ -268,41 +268,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
 constexpr int kMaxSplits = 128;
 
 // Merge the split partials of one (row, head).  The partials were written by other CUs a microsecond ago, so every dependent
-// load is a full fabric round trip: all (m, l, o) values of up to 8 splits are requested at once (one round trip).
+// load is a full fabric round trip: all (m, l, o) values of up to 8 splits are requested at once (attn_split_merge).
 template <typename T, int D>
 __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ ws, void* __restrict__ out_,
                                                                 int64_t out_row_stride, int n_splits) {
   const int h = blockIdx.x, b = blockIdx.y, n_heads = gridDim.x, d = threadIdx.x;
-  const float* p = ws + ((int64_t)b * n_heads + h) * n_splits * (D + 2);
-  float M = -INFINITY, L = 0.f, O = 0.f;
-  for (int s0 = 0; s0 < n_splits; s0 += 8) {
-    float m8[8], l8[8], o8[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int s = s0 + u < n_splits ? s0 + u : n_splits - 1;
-      m8[u] = p[s * (D + 2)];
-      l8[u] = p[s * (D + 2) + 1];
-      o8[u] = p[s * (D + 2) + 2 + d];
-    }
-    float mc = M;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (s0 + u < n_splits) mc = fmaxf(mc, m8[u]);
-    if (mc > -INFINITY) {
-      const float a = __expf(M - mc);  // M = -inf -> 0
-      L *= a;
-      O *= a;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (s0 + u < n_splits) {
-          const float w = __expf(m8[u] - mc);  // empty split: exp(-inf) = 0
-          L += l8[u] * w;
-          O += o8[u] * w;
-        }
-      M = mc;
-    }
-  }
-  store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + d, L > 0.f ? O / L : 0.f);
+  float o[1];
+  attn_split_merge<1>(ws + ((int64_t)b * n_heads + h) * n_splits * (D + kAttnPartPad), n_splits, D, d, o);
+  store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + d, o[0]);
 }
 
 template <typename T, int D, int NW, bool FUSED, int U>
@@ -325,7 +298,7 @@ using namespace dl;
 
 extern "C" int64_t dl_attn_decode_workspace_bytes(int B, int n_heads, int head_dim, int n_splits) {
   if (n_splits <= 1) return 0;
-  return (int64_t)B * n_heads * n_splits * (head_dim + 2) * (int64_t)sizeof(float);
+  return (int64_t)B * n_heads * n_splits * (head_dim + kAttnPartPad) * (int64_t)sizeof(float);
 }
 
 extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t slab_stride_b,

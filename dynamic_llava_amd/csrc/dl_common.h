@@ -75,6 +75,7 @@ struct Elem;
 template <>
 struct Elem<f32_t> {
   static constexpr int kBytes = 4;
+  static constexpr bool kBf16 = false;
   static constexpr int kVec = 4;  // elements per 16-byte access
   using storage = float;
   __device__ static __forceinline__ float to_f(float s) { return s; }
@@ -84,6 +85,7 @@ struct Elem<f32_t> {
 template <>
 struct Elem<f16_t> {
   static constexpr int kBytes = 2;
+  static constexpr bool kBf16 = false;
   static constexpr int kVec = 8;
   using storage = uint16_t;
   __device__ static __forceinline__ float to_f(uint16_t s) { return f16_bits_to_float(s); }
@@ -93,6 +95,7 @@ struct Elem<f16_t> {
 template <>
 struct Elem<bf16_t> {
   static constexpr int kBytes = 2;
+  static constexpr bool kBf16 = true;
   static constexpr int kVec = 8;
   using storage = uint16_t;
   __device__ static __forceinline__ float to_f(uint16_t s) { return bf16_bits_to_float(s); }
@@ -207,5 +210,58 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
       dl::set_error("unsupported dtype %d", (int)dtype); \
       return DL_ERR_ARG;                                 \
   }
+
+// ---- split-KV partials of the decode attention: entry (row b, head h, split s) = [m, l, -, -, o[0..D)] floats (D + 4: the
+// o vector is 16-byte aligned).  attn_split_merge: the merged, normalised output for NV consecutive head dims starting at d0, in
+// split order, 8 splits per round trip. ----
+constexpr int kAttnPartPad = 4;
+template <int NV>
+__device__ __forceinline__ void attn_split_merge(const float* __restrict__ p, int n_splits, int D, int d0, float (&out)[NV]) {
+  const int stride = D + kAttnPartPad;
+  float M = -INFINITY, L = 0.f, O[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) O[e] = 0.f;
+  for (int s0 = 0; s0 < n_splits; s0 += 8) {
+    float m8[8], l8[8], o8[8][NV];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u < n_splits ? s0 + u : n_splits - 1;
+      const float* q = p + (int64_t)s * stride;
+      m8[u] = q[0];
+      l8[u] = q[1];
+      if constexpr (NV == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(q + kAttnPartPad + d0);
+        o8[u][0] = v.x;
+        o8[u][1] = v.y;
+        o8[u][2] = v.z;
+        o8[u][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) o8[u][e] = q[kAttnPartPad + d0 + e];
+      }
+    }
+    float mc = M;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < n_splits) mc = fmaxf(mc, m8[u]);
+    if (mc > -INFINITY) {
+      const float a = __expf(M - mc);  // M = -inf -> 0
+      L *= a;
+#pragma unroll
+      for (int e = 0; e < NV; ++e) O[e] *= a;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < n_splits) {
+          const float w = __expf(m8[u] - mc);  // empty split: exp(-inf) = 0
+          L += l8[u] * w;
+#pragma unroll
+          for (int e = 0; e < NV; ++e) O[e] += o8[u][e] * w;
+        }
+      M = mc;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NV; ++e) out[e] = L > 0.f ? O[e] / L : 0.f;
+}
 
 }  // namespace dl
