@@ -1,0 +1,249 @@
+// dl_gemm_smallm: Y[M,N] = X[M,K] @ W[N,K]^T for decode batches M <= 32 -- the nn.Linear calls of DML:1011-1013 (q/k/v_proj),
+// DML:1127 (o_proj), DML:328 (gate/up/down_proj) and DML:2709 (lm_head) when 5..32 rows are decoded together.  Like dl_gemv this is
+// pure weight streaming (M flop per weight byte), but the vector ALU cannot keep up beyond ~4 rows (4 v_dot2c per row and 16-byte
+// chunk), so the products go to the matrix cores:
+//
+//  * X (one K slice of it) is RESIDENT in LDS for the whole kernel ([16*NB rows][Ks], padded rows): no staging pipeline, one
+//    barrier.  K is split over gridDim.y slices when M*K*2 exceeds LDS or when N alone gives too few waves; partial sums go to an
+//    fp32 workspace and are added in slice order by a second launch (deterministic).
+//  * a WAVE owns 16 neurons at a time.  Weights go straight from HBM into the MFMA A-operand: lane l reads 16 bytes of row
+//    (l & 15) at k-group (l >> 4), i.e. one instruction = 16 rows x 64 contiguous bytes, through an 8-deep register ring
+//    (8 KiB per wave, 64 KiB per CU in flight).  B-operand = 16 batch rows x 32 k from LDS (conflict-free 16-byte reads).
+//    v_mfma_f32_16x16x32: D[neuron][batch]; every lane ends up with 4 consecutive neurons of one batch row: stored directly, no
+//    cross-lane reduction.  Two accumulators per batch tile break the MFMA dependency chain.
+#include "dl_common.h"
+
+namespace dl {
+
+typedef __bf16 sm_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 sm_f16x8_t __attribute__((ext_vector_type(8)));
+typedef float sm_f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ sm_f32x4_t sm_mfma(const uint4& a, const uint4& b, sm_f32x4_t c);
+template <>
+__device__ __forceinline__ sm_f32x4_t sm_mfma<bf16_t>(const uint4& a, const uint4& b, sm_f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sm_bf16x8_t, a), __builtin_bit_cast(sm_bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ sm_f32x4_t sm_mfma<f16_t>(const uint4& a, const uint4& b, sm_f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sm_f16x8_t, a), __builtin_bit_cast(sm_f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int kSmU = 8;          // weight ring depth: K steps of 32 in flight per wave
+constexpr int kSmKUnit = 256;    // K slices are multiples of kSmU * 32
+constexpr int kSmMaxM = 32;
+constexpr int kSmLdsBytes = 150 * 1024;
+
+// NB: batch tiles of 16 rows (M <= 16*NB).  NW: waves per workgroup.
+template <typename T, int NB, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(const void* __restrict__ X_, int64_t ldx, const void* __restrict__ W_,
+                                                               void* __restrict__ Y_, int64_t ldy, float* __restrict__ part, int M, int N,
+                                                               int K, int n_slices) {
+  using S = uint16_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_smem[];
+  S* xs = reinterpret_cast<S*>(sm_smem);
+  const S* X = reinterpret_cast<const S*>(X_);
+  const S* W = reinterpret_cast<const S*>(W_);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  // this workgroup's K slice, in units of 256
+  const int units = K / kSmKUnit;
+  const int slice = blockIdx.y;
+  const int u0 = (int)((int64_t)units * slice / n_slices), u1 = (int)((int64_t)units * (slice + 1) / n_slices);
+  const int k0 = u0 * kSmKUnit, Ks = (u1 - u0) * kSmKUnit;
+  const int ld = Ks + 8;  // LDS row stride (elements): +16 bytes -> rows shift by 4 banks
+  const int steps = Ks / 32;
+
+  // this wave's neuron tiles: t = first, first + stride, ...
+  const int n_tiles = (N + 15) / 16;
+  const int first = blockIdx.x * NW + wid, stride = gridDim.x * NW;
+  const int my_tiles = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+  const int total = my_tiles * steps;  // linear (tile, step) stream of this wave
+
+  auto wbase = [&](int tile_i) -> const S* {  // lane's weight row of this wave's tile_i-th tile, at the slice start
+    int n = (first + tile_i * stride) * 16 + lr;
+    n = n < N ? n : N - 1;
+    return W + (int64_t)n * K + k0 + lg * 8;
+  };
+  auto wptr = [&](int t) -> const S* {  // weight fragment address of linear step t
+    const int tile_i = t / steps;
+    return wbase(tile_i) + (t - tile_i * steps) * 32;
+  };
+
+  // ---- start the weight stream before X is staged ----
+  uint4 wr[kSmU];
+#pragma unroll
+  for (int u = 0; u < kSmU; ++u)
+    if (u < total) wr[u] = *reinterpret_cast<const uint4*>(wptr(u));
+
+  // ---- X slice -> LDS (rows >= M are zero) ----
+  {
+    const int chunks_per_row = Ks / 8;
+    const int n_chunks = NB * 16 * chunks_per_row;
+    for (int c = tid; c < n_chunks; c += NW * 64) {
+      const int row = c / chunks_per_row, col = (c - row * chunks_per_row) * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (row < M) v = *reinterpret_cast<const uint4*>(X + (int64_t)row * ldx + k0 + col);
+      *reinterpret_cast<uint4*>(xs + row * ld + col) = v;
+    }
+  }
+  __syncthreads();
+
+  sm_f32x4_t acc[NB][2];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb][0] = acc[nb][1] = sm_f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const S* xb = xs + lr * ld + lg * 8;
+  int st = 0, ti = 0;  // step within the tile, tile index
+  for (int t0 = 0; t0 < total; t0 += kSmU) {  // steps is a multiple of kSmU: a ring round never straddles a tile
+    const bool more = t0 + kSmU < total;  // the next round exists (whole rounds only)
+    const int st_n = st + kSmU == steps ? 0 : st + kSmU;
+    const S* wn = more ? wbase(st_n == 0 ? ti + 1 : ti) + st_n * 32 : nullptr;
+#pragma unroll
+    for (int u = 0; u < kSmU; ++u) {
+      const uint4 a = wr[u];
+      if (more) wr[u] = *reinterpret_cast<const uint4*>(wn + u * 32);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const uint4 b = *reinterpret_cast<const uint4*>(xb + nb * 16 * ld + (st + u) * 32);
+        acc[nb][u & 1] = sm_mfma<T>(a, b, acc[nb][u & 1]);
+      }
+    }
+    st += kSmU;
+    if (st == steps) {  // tile finished: D[neuron = lg*4 + e][batch = lr]
+      const int n = (first + ti * stride) * 16 + lg * 4;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int m = nb * 16 + lr;
+        if (m < M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[nb][0][e] + acc[nb][1][e];
+            if (n + e < N) {
+              if (n_slices == 1)
+                store1<T>(Y_, (int64_t)m * ldy + n + e, v);
+              else
+                part[((int64_t)slice * M + m) * N + n + e] = v;
+            }
+          }
+        }
+        acc[nb][0] = acc[nb][1] = sm_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      st = 0;
+      ++ti;
+    }
+  }
+}
+
+// Y[m,n] = cast(sum_s part[s,m,n]) in slice order.  N % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_smallm_reduce_kernel(const float* __restrict__ part, int n_slices, int M, int N,
+                                                                  void* __restrict__ Y_, int64_t ldy) {
+  const int64_t nq = (int64_t)M * (N / 4);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nq; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / (N / 4);
+    const int n = (int)(idx - m * (N / 4)) * 4;
+    float4 s = *reinterpret_cast<const float4*>(part + m * N + n);
+    for (int k = 1; k < n_slices; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)k * M + m) * N + n);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    store1<T>(Y_, m * ldy + n, s.x);
+    store1<T>(Y_, m * ldy + n + 1, s.y);
+    store1<T>(Y_, m * ldy + n + 2, s.z);
+    store1<T>(Y_, m * ldy + n + 3, s.w);
+  }
+}
+
+// slices: enough to (a) fit the X slice in LDS and (b) give the 256 CUs ~8 waves each.
+static int sm_slices(int M, int N, int K, int want) {
+  const int units = K / kSmKUnit;
+  const int rows = M <= 16 ? 16 : 32;
+  const int max_ks = (kSmLdsBytes / (rows * 2) - 8) / kSmKUnit * kSmKUnit;
+  int s_lds = 1;
+  while ((units + s_lds - 1) / s_lds * kSmKUnit > max_ks) ++s_lds;
+  int s = want;
+  if (s <= 0) {
+    const int n_tiles = (N + 15) / 16;
+    s = (6144 + n_tiles - 1) / n_tiles;  // tools/bench_gemm_smallm.py: many short weight streams beat few long ones (qkv, o, down: 8; gate|up: 5)
+    if (s > 8) s = 8;
+  }
+  if (s < s_lds) s = s_lds;
+  if (s > units) s = units;
+  return s;
+}
+
+template <typename T, int NB, int NW>
+static int sm_go(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, float* part, int M, int N, int K, int n_slices,
+                 hipStream_t st) {
+  const int units = K / kSmKUnit;
+  const int max_ks = (units + n_slices - 1) / n_slices * kSmKUnit;
+  const size_t smem = (size_t)NB * 16 * (max_ks + 8) * 2;
+  auto kfn = gemm_smallm_kernel<T, NB, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("dl_gemm_smallm: cannot raise the dynamic LDS limit to 152 KiB");
+      return DL_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int n_tiles = (N + 15) / 16;
+  int gx = (n_tiles + NW - 1) / NW;
+  const int cap = 8192 / NW / n_slices > 0 ? 8192 / NW / n_slices : 1;  // further tiles are looped over
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, (unsigned)n_slices), dim3(NW * 64), smem, st, X, ldx, W, Y, ldy, part, M, N, K, n_slices);
+  if (n_slices > 1) {
+    const int64_t nq = (int64_t)M * (N / 4);
+    const int64_t blocks = (nq + 255) / 256;
+    hipLaunchKernelGGL((gemm_smallm_reduce_kernel<T>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, part, n_slices, M, N, Y,
+                       ldy);
+  }
+  return DL_OK;
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" int dl_gemm_smallm_max_m(void) { return kSmMaxM; }
+
+extern "C" int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % kSmKUnit) return 0;
+  const int s = sm_slices(M, N, K, n_slices);
+  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, void* workspace, int M, int N, int K,
+                              int n_slices, int wg_waves, int dtype, void* stream) {
+  DL_REQUIRE(X && W && Y, "dl_gemm_smallm: NULL pointer");
+  DL_REQUIRE(M > 0 && M <= kSmMaxM && N > 0 && K > 0, "dl_gemm_smallm: bad shape M=%d (max %d) N=%d K=%d", M, kSmMaxM, N, K);
+  DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, "dl_gemm_smallm: bf16 / f16 only (MFMA path)");
+  DL_REQUIRE(K % kSmKUnit == 0 && N % 4 == 0 && ldx % 8 == 0, "dl_gemm_smallm: K %% 256, N %% 4 and ldx %% 8 must be 0");
+  DL_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0, "dl_gemm_smallm: X and W must be 16-byte aligned");
+  DL_REQUIRE(n_slices >= 0 && n_slices <= 64, "dl_gemm_smallm: n_slices must be in [0, 64]");
+  DL_REQUIRE(wg_waves == 0 || wg_waves == 4 || wg_waves == 8, "dl_gemm_smallm: wg_waves must be 0 (auto), 4 or 8");
+  const int s = sm_slices(M, N, K, n_slices);
+  DL_REQUIRE(s == 1 || workspace, "dl_gemm_smallm: workspace required (dl_gemm_smallm_workspace_bytes)");
+  hipStream_t st = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  const bool w8 = wg_waves != 4;
+  int rc = DL_OK;
+#define DL_SM_ARGS X, ldx, W, Y, ldy, part, M, N, K, s, st
+  if (dtype == DL_BF16) {
+    if (M <= 16) rc = w8 ? sm_go<bf16_t, 1, 8>(DL_SM_ARGS) : sm_go<bf16_t, 1, 4>(DL_SM_ARGS);
+    else rc = w8 ? sm_go<bf16_t, 2, 8>(DL_SM_ARGS) : sm_go<bf16_t, 2, 4>(DL_SM_ARGS);
+  } else {
+    if (M <= 16) rc = w8 ? sm_go<f16_t, 1, 8>(DL_SM_ARGS) : sm_go<f16_t, 1, 4>(DL_SM_ARGS);
+    else rc = w8 ? sm_go<f16_t, 2, 8>(DL_SM_ARGS) : sm_go<f16_t, 2, 4>(DL_SM_ARGS);
+  }
+#undef DL_SM_ARGS
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_gemm_smallm");
+  return DL_OK;
+}

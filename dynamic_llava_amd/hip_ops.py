@@ -82,6 +82,9 @@ SIGNATURES = {
     "dl_gemv_set_tuning": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
+    "dl_gemm_smallm_max_m": (c_int, []),
+    "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "dl_gemm_smallm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "dl_quick_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dl_decode_advance": (
@@ -408,3 +411,28 @@ def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos
 
 def launch_probe(grid=1, block=64):
     _check(lib().dl_launch_probe(int(grid), int(block), _stream()), "dl_launch_probe")
+
+
+def gemm_smallm_ok(M, N, K, dtype):
+    """Shapes dl_gemm_smallm takes (callers use the library GEMM otherwise)."""
+    return dtype in (torch.bfloat16, torch.float16) and 0 < M <= 32 and K % 256 == 0 and N % 4 == 0
+
+
+def gemm_smallm(x, w, out=None, workspace=None, n_slices=0, wg_waves=0):
+    """out[M,N] = x[M,K] @ w[N,K]^T (nn.Linear, no bias) for M <= 32.  workspace: fp32 scratch for split-K partials (allocated here
+    if missing / too small -- pass a persistent one under hipGraph capture)."""
+    _dev(x, w, out, workspace)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.is_contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    assert out.stride(1) == 1
+    need = int(lib().dl_gemm_smallm_workspace_bytes(M, N, K, int(n_slices)))
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    _check(
+        lib().dl_gemm_smallm(_p(x), x.stride(0), _p(w), _p(out), out.stride(0), _p(workspace), M, N, K, int(n_slices), int(wg_waves), dtype_code(x.dtype), _stream()),
+        "dl_gemm_smallm",
+    )
+    return out

@@ -403,6 +403,11 @@ class _DecodeState:
         # split-KV: enough workgroups to cover the chip (256 CUs) without drowning in partials
         self.n_splits = max(1, min(32, 1024 // max(1, B * nH)))
         self.attn_ws = ops.attn_decode_workspace(B, nH, d, 32, device)
+        # decode batches past the GEMV range: dl_gemm_smallm (weights streamed into the matrix cores) up to smallm_max_decode_batch rows
+        self.use_smallm = (not self.use_gemv) and B <= model.smallm_max_decode_batch and all(
+            ops.gemm_smallm_ok(B, n, k, dtype) for n, k in (((nH + 2 * nKV) * d, H), (H, nH * d), (2 * I, H), (H, I), (V, H))
+        )
+        self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
         self.graph = None
         self.graph_key = None
 
@@ -423,6 +428,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.use_hip_graph = True
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
         self.gemv_max_decode_batch = 4  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
+        self.smallm_max_decode_batch = 16  # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
         self.eval()
 
@@ -855,21 +861,28 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
         cos, sin = self._rope
         use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
+        if st.use_smallm:
+            lin = lambda x, w: ops.gemm_smallm(x, w, workspace=st.lin_ws)  # noqa: E731
+        else:
+            lin = F.linear
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
         ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x)
         for i, layer in enumerate(self.model.layers):
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
-            qkv = F.linear(st.x, layer.w_qkv)
+            qkv = lin(st.x, layer.w_qkv)
             ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d)
-            o = F.linear(st.attn, layer.self_attn.o_proj.weight)
+            o = lin(st.attn, layer.self_attn.o_proj.weight)
             ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x)
-            ops.silu_mul(F.linear(st.x, layer.w_gu), out=st.act)
-            dn = F.linear(st.act, layer.mlp.down_proj.weight)
+            ops.silu_mul(lin(st.x, layer.w_gu), out=st.act)
+            dn = lin(st.act, layer.mlp.down_proj.weight)
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
-        torch.matmul(st.x, self.lm_head.weight.t(), out=st.logits)
+        if st.use_smallm:
+            ops.gemm_smallm(st.x, self.lm_head.weight, out=st.logits, workspace=st.lin_ws)
+        else:
+            torch.matmul(st.x, self.lm_head.weight.t(), out=st.logits)
 
     def _pooled_cache(self, B, t_need):
         """generate() owns its cache, so the slab is reused across calls: stable pointers keep the captured hipGraphs valid."""

@@ -207,6 +207,17 @@ int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_s
                       int eos_id, int pad_id, int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision,
                       void* stream);
 
+/* ---- decode GEMM for 5..32 rows: Y[M,N] = X[M,K] @ W[N,K]^T (nn.Linear without bias: DML:1011-1013, 1127, 328, 2709), M <=
+ * dl_gemm_smallm_max_m().  Weight-streaming like dl_gemv, products on the matrix cores (X resident in LDS, weights HBM -> MFMA
+ * operand registers).  bf16 / f16, fp32 accumulate, one rounding.  K % 256 == 0, N % 4 == 0; ldx / ldy: row strides (elements).
+ * n_slices: split-K factor (0 = auto; the kernel may raise it so that the X slice fits LDS); when the effective factor is > 1
+ * the fp32 partials go to `workspace` (dl_gemm_smallm_workspace_bytes(M, N, K, n_slices)) and a second launch adds them in slice
+ * order.  wg_waves: 4 / 8 waves per workgroup (0 = auto). */
+int dl_gemm_smallm_max_m(void);
+int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices);
+int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, void* workspace, int M, int N, int K,
+                   int n_slices, int wg_waves, int dtype, void* stream);
+
 /* ---- diagnostics: one empty kernel (launch-floor measurements, tools/bench_launch_floor.py). */
 int dl_launch_probe(int grid, int block, void* stream);
 

@@ -524,3 +524,25 @@ def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d):
         ref = F.scaled_dot_product_attention(qf[None], kf[None], vf[None], attn_mask=mask)[0].transpose(0, 1)
         tol = 2e-5 if dtype == torch.float32 else 6 * ULP[dtype]
         assert float((out[a:e] - ref).abs().max()) < tol, f"row {b}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize(
+    "M,N,K,n_slices,wg_waves",
+    [(32, 4096, 4096, 0, 0), (16, 12288, 4096, 1, 4), (5, 22016, 4096, 0, 8), (8, 4096, 11008, 0, 0), (32, 4096, 11008, 0, 4), (17, 200, 512, 2, 0),
+     (1, 64, 256, 0, 0), (9, 132, 768, 3, 8), (32, 32000, 4096, 0, 0), (24, 1000, 1280, 1, 0)],
+)
+def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves):
+    """Small-batch decode GEMM on the matrix cores == F.linear with fp32 accumulation and one rounding: both batch-tile counts, ragged M / N
+    (tiles beyond N clamp, rows beyond M are zero), uneven K slices, LDS-forced slicing (32 x 11008), strided X / Y, deterministic."""
+    g = torch.Generator().manual_seed(43)
+    x_full = torch.randn(M, K + 64, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    ref = F.linear(x_full[:, :K].float(), w.float()).to(dtype)
+    y_full = torch.full((M, N + 8), float("nan"), dtype=dtype, device="cuda")
+    out = ops.gemm_smallm(x_full.cuda()[:, :K], w.cuda(), out=y_full[:, :N], n_slices=n_slices, wg_waves=wg_waves)
+    assert torch.isnan(y_full[:, N:]).all(), "must not write outside [M, N]"
+    _close_ulp(out, ref, dtype, 1.0, atol=1e-3)
+    assert _frac_exact(out, ref, dtype) > 0.97
+    out2 = ops.gemm_smallm(x_full.cuda()[:, :K], w.cuda(), n_slices=n_slices, wg_waves=wg_waves)
+    assert torch.equal(out, out2)

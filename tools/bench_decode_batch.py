@@ -22,14 +22,14 @@ def run(B, n_new):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 
-for B in (2, 4, 5, 6, 8):
-    for maxb in (4, 8):
-        if B <= 4 and maxb == 8:
+for B in (4, 5, 8, 12, 16):
+    for maxb in (4, 16):
+        if B <= 4 and maxb == 16:
             continue
-        model.gemv_max_decode_batch = maxb
+        model.smallm_max_decode_batch = maxb if maxb > 4 else 0
         model._dstate = None
         for _ in range(2):
             run(B, 33); run(B, 1)
         t = min(run(B, 65) for _ in range(3)) - min(run(B, 1) for _ in range(3))
-        path = "dl_gemv" if B <= maxb else "library GEMM"
+        path = "dl_gemv" if B <= 4 else ("dl_gemm_smallm" if maxb > 4 else "library GEMM")
         print(f"B={B} ({path:12s}): {t / 64 * 1e3:6.3f} ms/step  {B * 64 / t:8.1f} tok/s", flush=True)
