@@ -9,16 +9,18 @@ constexpr int kThreads = 256;
 constexpr int kMaxVecPerThread = 8;  // H <= 256 * 8 * kVec  (16384 for 2-byte types, 8192 for fp32)
 
 // ---- RMSNorm: DML:134-139.  ADD: h = cast(h + delta) first (DML:1289/1295), written back. ----
-template <typename T, bool ADD>
+// ADD = 2: delta = cast(sum_s parts[s, row, :]) -- the fp32 split-K partials of dl_gemm_smallm(defer_reduce), summed in slice order.
+template <typename T, int ADD>
 __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_, const void* __restrict__ delta_,
                                                             const void* __restrict__ w_, void* __restrict__ out_, int H,
-                                                            float eps) {
+                                                            float eps, int n_slices = 0, int64_t slice_stride = 0) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   S* h = reinterpret_cast<S*>(h_) + row * H;
-  const S* delta = ADD ? reinterpret_cast<const S*>(delta_) + row * H : nullptr;
+  const S* delta = ADD == 1 ? reinterpret_cast<const S*>(delta_) + row * H : nullptr;
+  const float* parts = ADD == 2 ? reinterpret_cast<const float*>(delta_) + row * H : nullptr;
   const int nvec = H / V;
   float x[kMaxVecPerThread][V];
   float ss = 0.f;
@@ -27,11 +29,29 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_
     const int v = threadIdx.x + i * kThreads;
     if (v < nvec) {
       load16<T>(h + v * V, x[i]);
-      if constexpr (ADD) {
+      if constexpr (ADD == 1) {
         float d[V];
         load16<T>(delta + v * V, d);
 #pragma unroll
         for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
+        store16<T>(h + v * V, x[i]);
+      }
+      if constexpr (ADD == 2) {
+        float d[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = 0.f;
+        for (int s = 0; s < n_slices; ++s) {
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) {
+            const float4 p = *reinterpret_cast<const float4*>(parts + s * slice_stride + v * V + q * 4);
+            d[q * 4] += p.x;
+            d[q * 4 + 1] += p.y;
+            d[q * 4 + 2] += p.z;
+            d[q * 4 + 3] += p.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + Elem<T>::round(d[j]));
         store16<T>(h + v * V, x[i]);
       }
 #pragma unroll
@@ -69,7 +89,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* x_, con
   const int64_t row = blockIdx.x;
   const int64_t src = row_index ? (int64_t)row_index[row] : row;
   const S* xr = reinterpret_cast<const S*>(x_) + src * H;
-  const S* delta = ADD ? reinterpret_cast<const S*>(delta_) + row * H : nullptr;
+  const S* delta = ADD == 1 ? reinterpret_cast<const S*>(delta_) + row * H : nullptr;
+  const float* parts = ADD == 2 ? reinterpret_cast<const float*>(delta_) + row * H : nullptr;
   const int nvec = H / V;
   float x[kMaxVecPerThread][V];
   float s = 0.f;
@@ -166,6 +187,32 @@ __global__ __launch_bounds__(kThreads) void silu_mul_kernel(const void* __restri
   }
 }
 
+// act_fn(gate) * up (DML:328) reading the gate|up projection as fp32 split-K partials [n_slices][rows][2I] (dl_gemm_smallm with
+// defer_reduce): gate / up = cast(sum over slices), then the two roundings of the eager op.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void silu_mul_parts_kernel(const float* __restrict__ parts, int n_slices, void* __restrict__ out_,
+                                                                   int64_t rows, int I) {
+  const int q_per_row = I / 4;
+  const int64_t total = rows * q_per_row, slice_stride = rows * 2 * (int64_t)I;
+  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = idx / q_per_row;
+    const int c = (int)(idx - r * q_per_row) * 4;
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_slices; ++s) {
+      const float4 pg = *reinterpret_cast<const float4*>(parts + s * slice_stride + r * 2 * I + c);
+      const float4 pu = *reinterpret_cast<const float4*>(parts + s * slice_stride + r * 2 * I + I + c);
+      g[0] += pg.x; g[1] += pg.y; g[2] += pg.z; g[3] += pg.w;
+      u[0] += pu.x; u[1] += pu.y; u[2] += pu.z; u[3] += pu.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = Elem<T>::round(g[j]), uj = Elem<T>::round(u[j]);
+      const float sg = Elem<T>::round(gj / (1.0f + expf(-gj)));
+      store1<T>(out_, r * I + c + j, sg * uj);
+    }
+  }
+}
+
 }  // namespace dl
 
 using namespace dl;
@@ -176,7 +223,7 @@ extern "C" int dl_rmsnorm(const void* x, const void* w, void* out, int64_t rows,
   if (rows == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_rmsnorm: unsupported H=%d", H);
-    hipLaunchKernelGGL((rmsnorm_kernel<T, false>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), const_cast<void*>(x),
+    hipLaunchKernelGGL((rmsnorm_kernel<T, 0>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), const_cast<void*>(x),
                        nullptr, w, out, H, eps);
   });
   DL_CHECK_LAUNCH("dl_rmsnorm");
@@ -191,10 +238,25 @@ extern "C" int dl_add_rmsnorm(void* h, const void* delta, const void* w, void* o
   if (rows == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm: unsupported H=%d", H);
-    hipLaunchKernelGGL((rmsnorm_kernel<T, true>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, delta, w, out, H,
+    hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, delta, w, out, H,
                        eps);
   });
   DL_CHECK_LAUNCH("dl_add_rmsnorm");
+  return DL_OK;
+}
+
+extern "C" int dl_add_rmsnorm_parts(void* h, const float* parts, int n_slices, const void* w, void* out, int64_t rows, int H, float eps,
+                                    int dtype, void* stream) {
+  DL_REQUIRE(h && parts && n_slices >= 1, "dl_add_rmsnorm_parts: bad arguments");
+  DL_REQUIRE((w == nullptr) == (out == nullptr), "dl_add_rmsnorm_parts: w and out must both be given or both be NULL");
+  DL_REQUIRE(rows >= 0 && H > 0 && ((uintptr_t)parts & 15) == 0, "dl_add_rmsnorm_parts: bad shape / alignment");
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0 && H % 4 == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm_parts: unsupported H=%d", H);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, parts, w, out, H, eps, n_slices,
+                       (int64_t)rows * H);
+  });
+  DL_CHECK_LAUNCH("dl_add_rmsnorm_parts");
   return DL_OK;
 }
 
@@ -239,6 +301,20 @@ extern "C" int dl_quick_gelu(const void* x, void* out, int64_t n, int dtype, voi
                        nvec);
   });
   DL_CHECK_LAUNCH("dl_quick_gelu");
+  return DL_OK;
+}
+
+extern "C" int dl_silu_mul_parts(const float* parts, int n_slices, void* out, int64_t rows, int I, int dtype, void* stream) {
+  DL_REQUIRE(parts && out && n_slices >= 1, "dl_silu_mul_parts: bad arguments");
+  DL_REQUIRE(rows >= 0 && I > 0 && I % 4 == 0 && ((uintptr_t)parts & 15) == 0, "dl_silu_mul_parts: bad shape / alignment");
+  if (rows == 0) return DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    const int64_t total = rows * (I / 4);
+    const int64_t blocks = (total + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL((silu_mul_parts_kernel<T>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kThreads), 0, as_stream(stream), parts,
+                       n_slices, out, rows, I);
+  });
+  DL_CHECK_LAUNCH("dl_silu_mul_parts");
   return DL_OK;
 }
 

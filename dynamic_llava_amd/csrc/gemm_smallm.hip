@@ -39,7 +39,7 @@ constexpr int kSmLdsBytes = 150 * 1024;
 template <typename T, int NB, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(const void* __restrict__ X_, int64_t ldx, const void* __restrict__ W_,
                                                                void* __restrict__ Y_, int64_t ldy, float* __restrict__ part, int M, int N,
-                                                               int K, int n_slices) {
+                                                               int K, int n_slices, int direct) {
   using S = uint16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm_smem[];
   S* xs = reinterpret_cast<S*>(sm_smem);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(const void* __rest
           for (int e = 0; e < 4; ++e) {
             const float v = acc[nb][0][e] + acc[nb][1][e];
             if (n + e < N) {
-              if (n_slices == 1)
+              if (direct)
                 store1<T>(Y_, (int64_t)m * ldy + n + e, v);
               else
                 part[((int64_t)slice * M + m) * N + n + e] = v;
@@ -133,6 +133,124 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(const void* __rest
       st = 0;
       ++ti;
     }
+  }
+}
+
+// ---- variant 2: coalesced weight loads, transposed through wave-private LDS ----
+// The direct-fragment loads above touch 16 rows x 64 B per instruction (half a cache line per row) and top out near 3.5-4 TB/s.
+// Here a wave loads its [16 neurons x 256 k] chunk as dl_gemv does -- each instruction two rows x 512 contiguous bytes, non-temporal,
+// two chunks (16 KiB) in flight per wave -- parks it in its own 8 KiB of LDS (no barrier: only the wave itself reads it back) and
+// reads the MFMA A-fragments from there.  8 waves per workgroup; X slice resident as before.
+constexpr int kSmKC = 256;
+constexpr int kSmStLd = kSmKC + 8;
+constexpr int kSmStWaves = 8;
+
+__device__ __forceinline__ uint4 sm_ldg_nt(const void* p) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(r.x, r.y, r.z, r.w);
+}
+
+template <typename T, int NB>
+__global__ __launch_bounds__(kSmStWaves * 64) void gemm_smallm_staged_kernel(const void* __restrict__ X_, int64_t ldx,
+                                                                             const void* __restrict__ W_, void* __restrict__ Y_, int64_t ldy,
+                                                                             float* __restrict__ part, int M, int N, int K, int n_slices, int direct) {
+  using S = uint16_t;
+  constexpr int NW = kSmStWaves;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_smem[];
+  const S* X = reinterpret_cast<const S*>(X_);
+  const S* W = reinterpret_cast<const S*>(W_);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int units = K / kSmKUnit;
+  const int slice = blockIdx.y;
+  const int u0 = (int)((int64_t)units * slice / n_slices), u1 = (int)((int64_t)units * (slice + 1) / n_slices);
+  const int k0 = u0 * kSmKUnit, Ks = (u1 - u0) * kSmKUnit;
+  const int ld = Ks + 8;
+  const int cpt = Ks / kSmKC;  // chunks per tile
+  S* stg = reinterpret_cast<S*>(sm_smem) + wid * 16 * kSmStLd;         // wave-private staging [16][kSmStLd]
+  S* xs = reinterpret_cast<S*>(sm_smem) + NW * 16 * kSmStLd;           // X slice [NB*16][ld]
+
+  const int n_tiles = (N + 15) / 16;
+  const int first = blockIdx.x * NW + wid, stride = gridDim.x * NW;
+  const int my_tiles = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+  const int total = my_tiles * cpt;
+
+  const int srow = lane >> 5, scol = (lane & 31) * 8;  // staging-load role of this lane: row 2j + srow, 16 bytes at scol
+  auto issue = [&](int t, uint4(&r)[8]) {
+    const int tile_i = t / cpt, c = t - tile_i * cpt;
+    const int n0 = (first + tile_i * stride) * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int n = n0 + 2 * j + srow;
+      n = n < N ? n : N - 1;
+      r[j] = sm_ldg_nt(W + (int64_t)n * K + k0 + c * kSmKC + scol);
+    }
+  };
+
+  uint4 ra[8], rb[8];
+  if (total > 0) issue(0, ra);
+  if (total > 1) issue(1, rb);
+
+  {  // X slice -> LDS (rows >= M are zero)
+    const int chunks_per_row = Ks / 8;
+    const int n_chunks = NB * 16 * chunks_per_row;
+    for (int c = tid; c < n_chunks; c += NW * 64) {
+      const int row = c / chunks_per_row, col = (c - row * chunks_per_row) * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (row < M) v = *reinterpret_cast<const uint4*>(X + (int64_t)row * ldx + k0 + col);
+      *reinterpret_cast<uint4*>(xs + row * ld + col) = v;
+    }
+  }
+  __syncthreads();
+
+  sm_f32x4_t acc[NB][2];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb][0] = acc[nb][1] = sm_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const S* xb = xs + lr * ld + lg * 8;
+  const S* ab = stg + lr * kSmStLd + lg * 8;
+  int ci = 0, ti = 0;  // chunk within the tile, tile index
+
+  auto consume = [&](uint4(&r)[8], int t_next) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(stg + (2 * j + srow) * kSmStLd + scol) = r[j];
+    if (t_next < total) issue(t_next, r);
+#pragma unroll
+    for (int ks = 0; ks < kSmKC / 32; ++ks) {
+      const uint4 a = *reinterpret_cast<const uint4*>(ab + ks * 32);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const uint4 b = *reinterpret_cast<const uint4*>(xb + nb * 16 * ld + ci * kSmKC + ks * 32);
+        acc[nb][ks & 1] = sm_mfma<T>(a, b, acc[nb][ks & 1]);
+      }
+    }
+    if (++ci == cpt) {  // tile finished: D[neuron = lg*4 + e][batch = lr]
+      const int n = (first + ti * stride) * 16 + lg * 4;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int m = nb * 16 + lr;
+        if (m < M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[nb][0][e] + acc[nb][1][e];
+            if (n + e < N) {
+              if (direct)
+                store1<T>(Y_, (int64_t)m * ldy + n + e, v);
+              else
+                part[((int64_t)slice * M + m) * N + n + e] = v;
+            }
+          }
+        }
+        acc[nb][0] = acc[nb][1] = sm_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      ci = 0;
+      ++ti;
+    }
+  };
+
+  for (int t = 0; t < total; t += 2) {
+    consume(ra, t + 2);
+    if (t + 1 < total) consume(rb, t + 3);
   }
 }
 
@@ -160,16 +278,19 @@ __global__ __launch_bounds__(256) void gemm_smallm_reduce_kernel(const float* __
 }
 
 // slices: enough to (a) fit the X slice in LDS and (b) give the 256 CUs ~8 waves each.
-static int sm_slices(int M, int N, int K, int want) {
+static int sm_slices(int M, int N, int K, int want, int variant) {
   const int units = K / kSmKUnit;
   const int rows = M <= 16 ? 16 : 32;
-  const int max_ks = (kSmLdsBytes / (rows * 2) - 8) / kSmKUnit * kSmKUnit;
+  const int budget = kSmLdsBytes - (variant == 2 ? kSmStWaves * 16 * kSmStLd * 2 : 0);
+  const int max_ks = (budget / (rows * 2) - 8) / kSmKUnit * kSmKUnit;
   int s_lds = 1;
   while ((units + s_lds - 1) / s_lds * kSmKUnit > max_ks) ++s_lds;
   int s = want;
   if (s <= 0) {
     const int n_tiles = (N + 15) / 16;
-    s = (6144 + n_tiles - 1) / n_tiles;  // tools/bench_gemm_smallm.py: many short weight streams beat few long ones (qkv, o, down: 8; gate|up: 5)
+    // tools/bench_gemm_smallm.py: many short weight streams beat few long ones.  Direct fragments: qkv / o / down 8, gate|up 5;
+    // LDS-staged (2048 waves in one round): gate|up / lm_head 4, qkv / o / down 8.
+    s = variant == 2 ? (n_tiles >= 1024 ? 4 : 8) : (6144 + n_tiles - 1) / n_tiles;
     if (s > 8) s = 8;
   }
   if (s < s_lds) s = s_lds;
@@ -179,7 +300,7 @@ static int sm_slices(int M, int N, int K, int want) {
 
 template <typename T, int NB, int NW>
 static int sm_go(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, float* part, int M, int N, int K, int n_slices,
-                 hipStream_t st) {
+                 int direct, hipStream_t st) {
   const int units = K / kSmKUnit;
   const int max_ks = (units + n_slices - 1) / n_slices * kSmKUnit;
   const size_t smem = (size_t)NB * 16 * (max_ks + 8) * 2;
@@ -197,13 +318,42 @@ static int sm_go(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy
   int gx = (n_tiles + NW - 1) / NW;
   const int cap = 8192 / NW / n_slices > 0 ? 8192 / NW / n_slices : 1;  // further tiles are looped over
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, (unsigned)n_slices), dim3(NW * 64), smem, st, X, ldx, W, Y, ldy, part, M, N, K, n_slices);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, (unsigned)n_slices), dim3(NW * 64), smem, st, X, ldx, W, Y, ldy, part, M, N, K, n_slices, direct);
+  return DL_OK;
+}
+
+template <typename T>
+static void sm_reduce(float* part, void* Y, int64_t ldy, int M, int N, int n_slices, hipStream_t st) {
   if (n_slices > 1) {
     const int64_t nq = (int64_t)M * (N / 4);
     const int64_t blocks = (nq + 255) / 256;
     hipLaunchKernelGGL((gemm_smallm_reduce_kernel<T>), dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, part, n_slices, M, N, Y,
                        ldy);
   }
+}
+
+template <typename T, int NB>
+static int sm_go_staged(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, float* part, int M, int N, int K, int n_slices,
+                        int direct, hipStream_t st) {
+  constexpr int NW = kSmStWaves;
+  const int units = K / kSmKUnit;
+  const int max_ks = (units + n_slices - 1) / n_slices * kSmKUnit;
+  const size_t smem = (size_t)NW * 16 * kSmStLd * 2 + (size_t)NB * 16 * (max_ks + 8) * 2;
+  auto kfn = gemm_smallm_staged_kernel<T, NB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("dl_gemm_smallm: cannot raise the dynamic LDS limit to 152 KiB");
+      return DL_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int n_tiles = (N + 15) / 16;
+  int gx = (n_tiles + NW - 1) / NW;
+  const int cap = 2048 / NW / n_slices > 0 ? 2048 / NW / n_slices : 1;  // one workgroup (8 waves) per CU in a single round; tiles beyond that are looped over
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)gx, (unsigned)n_slices), dim3(NW * 64), smem, st, X, ldx, W, Y, ldy, part, M, N, K, n_slices, direct);
   return DL_OK;
 }
 
@@ -213,29 +363,40 @@ using namespace dl;
 
 extern "C" int dl_gemm_smallm_max_m(void) { return kSmMaxM; }
 
-extern "C" int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices) {
+extern "C" int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices, int variant) {
   if (M <= 0 || N <= 0 || K <= 0 || K % kSmKUnit) return 0;
-  const int s = sm_slices(M, N, K, n_slices);
-  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+  const int s = sm_slices(M, N, K, n_slices, variant == 1 ? 1 : 2);
+  return (int64_t)s * M * N * (int64_t)sizeof(float);  // also covers defer_reduce with a single slice
+}
+
+extern "C" int dl_gemm_smallm_slices(int M, int N, int K, int n_slices, int variant) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % kSmKUnit) return 0;
+  return sm_slices(M, N, K, n_slices, variant == 1 ? 1 : 2);
 }
 
 extern "C" int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, void* workspace, int M, int N, int K,
-                              int n_slices, int wg_waves, int dtype, void* stream) {
-  DL_REQUIRE(X && W && Y, "dl_gemm_smallm: NULL pointer");
+                              int n_slices, int wg_waves, int variant, int defer_reduce, int dtype, void* stream) {
+  DL_REQUIRE(X && W && (Y || defer_reduce), "dl_gemm_smallm: NULL pointer");
   DL_REQUIRE(M > 0 && M <= kSmMaxM && N > 0 && K > 0, "dl_gemm_smallm: bad shape M=%d (max %d) N=%d K=%d", M, kSmMaxM, N, K);
   DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, "dl_gemm_smallm: bf16 / f16 only (MFMA path)");
   DL_REQUIRE(K % kSmKUnit == 0 && N % 4 == 0 && ldx % 8 == 0, "dl_gemm_smallm: K %% 256, N %% 4 and ldx %% 8 must be 0");
   DL_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0, "dl_gemm_smallm: X and W must be 16-byte aligned");
   DL_REQUIRE(n_slices >= 0 && n_slices <= 64, "dl_gemm_smallm: n_slices must be in [0, 64]");
   DL_REQUIRE(wg_waves == 0 || wg_waves == 4 || wg_waves == 8, "dl_gemm_smallm: wg_waves must be 0 (auto), 4 or 8");
-  const int s = sm_slices(M, N, K, n_slices);
-  DL_REQUIRE(s == 1 || workspace, "dl_gemm_smallm: workspace required (dl_gemm_smallm_workspace_bytes)");
+  DL_REQUIRE(variant >= 0 && variant <= 2, "dl_gemm_smallm: variant must be 0 (auto), 1 (direct fragments) or 2 (LDS-staged)");
+  if (variant == 0) variant = 2;
+  const int s = sm_slices(M, N, K, n_slices, variant);
+  const int direct = (s == 1 && !defer_reduce) ? 1 : 0;
+  DL_REQUIRE(direct || workspace, "dl_gemm_smallm: workspace required (dl_gemm_smallm_workspace_bytes)");
   hipStream_t st = as_stream(stream);
   float* part = reinterpret_cast<float*>(workspace);
   const bool w8 = wg_waves != 4;
   int rc = DL_OK;
-#define DL_SM_ARGS X, ldx, W, Y, ldy, part, M, N, K, s, st
-  if (dtype == DL_BF16) {
+#define DL_SM_ARGS X, ldx, W, Y, ldy, part, M, N, K, s, direct, st
+  if (variant == 2) {
+    if (dtype == DL_BF16) rc = M <= 16 ? sm_go_staged<bf16_t, 1>(DL_SM_ARGS) : sm_go_staged<bf16_t, 2>(DL_SM_ARGS);
+    else rc = M <= 16 ? sm_go_staged<f16_t, 1>(DL_SM_ARGS) : sm_go_staged<f16_t, 2>(DL_SM_ARGS);
+  } else if (dtype == DL_BF16) {
     if (M <= 16) rc = w8 ? sm_go<bf16_t, 1, 8>(DL_SM_ARGS) : sm_go<bf16_t, 1, 4>(DL_SM_ARGS);
     else rc = w8 ? sm_go<bf16_t, 2, 8>(DL_SM_ARGS) : sm_go<bf16_t, 2, 4>(DL_SM_ARGS);
   } else {
@@ -244,6 +405,9 @@ extern "C" int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y
   }
 #undef DL_SM_ARGS
   if (rc != DL_OK) return rc;
+  if (!defer_reduce) {
+    if (dtype == DL_BF16) sm_reduce<bf16_t>(part, Y, ldy, M, N, s, st); else sm_reduce<f16_t>(part, Y, ldy, M, N, s, st);
+  }
   DL_CHECK_LAUNCH("dl_gemm_smallm");
   return DL_OK;
 }

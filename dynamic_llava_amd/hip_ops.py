@@ -83,8 +83,11 @@ SIGNATURES = {
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
     "dl_gemm_smallm_max_m": (c_int, []),
-    "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
-    "dl_gemm_smallm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "dl_gemm_smallm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_gemm_smallm_slices": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "dl_add_rmsnorm_parts": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_silu_mul_parts": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "dl_quick_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dl_decode_advance": (
@@ -418,7 +421,7 @@ def gemm_smallm_ok(M, N, K, dtype):
     return dtype in (torch.bfloat16, torch.float16) and 0 < M <= 32 and K % 256 == 0 and N % 4 == 0
 
 
-def gemm_smallm(x, w, out=None, workspace=None, n_slices=0, wg_waves=0):
+def gemm_smallm(x, w, out=None, workspace=None, n_slices=0, wg_waves=0, variant=0):
     """out[M,N] = x[M,K] @ w[N,K]^T (nn.Linear, no bias) for M <= 32.  workspace: fp32 scratch for split-K partials (allocated here
     if missing / too small -- pass a persistent one under hipGraph capture)."""
     _dev(x, w, out, workspace)
@@ -428,11 +431,48 @@ def gemm_smallm(x, w, out=None, workspace=None, n_slices=0, wg_waves=0):
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     assert out.stride(1) == 1
-    need = int(lib().dl_gemm_smallm_workspace_bytes(M, N, K, int(n_slices)))
+    need = int(lib().dl_gemm_smallm_workspace_bytes(M, N, K, int(n_slices), int(variant)))
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     _check(
-        lib().dl_gemm_smallm(_p(x), x.stride(0), _p(w), _p(out), out.stride(0), _p(workspace), M, N, K, int(n_slices), int(wg_waves), dtype_code(x.dtype), _stream()),
+        lib().dl_gemm_smallm(_p(x), x.stride(0), _p(w), _p(out), out.stride(0), _p(workspace), M, N, K, int(n_slices), int(wg_waves), int(variant), 0, dtype_code(x.dtype), _stream()),
         "dl_gemm_smallm",
     )
+    return out
+
+
+def gemm_smallm_parts(x, w, workspace, n_slices=0, variant=0):
+    """x @ w^T left as fp32 split-K partials in `workspace` (viewed [slices, M, N]); returns (parts, slices) for add_rmsnorm_parts /
+    silu_mul_parts, which add the slices themselves (no reduce launch)."""
+    _dev(x, w, workspace)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.is_contiguous() and workspace.dtype == torch.float32
+    M, K = x.shape
+    N = w.shape[0]
+    s = int(lib().dl_gemm_smallm_slices(M, N, K, int(n_slices), int(variant)))
+    assert s >= 1 and workspace.numel() >= s * M * N, "workspace too small (dl_gemm_smallm_workspace_bytes)"
+    _check(
+        lib().dl_gemm_smallm(_p(x), x.stride(0), _p(w), None, 0, _p(workspace), M, N, K, int(n_slices), 0, int(variant), 1, dtype_code(x.dtype), _stream()),
+        "dl_gemm_smallm",
+    )
+    return workspace[: s * M * N].view(s, M, N), s
+
+
+def add_rmsnorm_parts(h, parts, w=None, eps=1e-6, out=None):
+    """h += cast(sum_s parts[s]) in place, then RMSNorm(h) * w -> out (w None: the add only).  parts: [slices, rows, H] fp32."""
+    _dev(h, parts, w, out)
+    assert h.is_contiguous() and parts.is_contiguous() and parts.dtype == torch.float32 and parts.shape[1:] == h.shape
+    rows, H = h.shape
+    if w is not None and out is None:
+        out = torch.empty_like(h)
+    _check(lib().dl_add_rmsnorm_parts(_p(h), _p(parts), parts.shape[0], _p(w), _p(out) if w is not None else None, rows, H, eps, dtype_code(h.dtype), _stream()), "dl_add_rmsnorm_parts")
+    return out if w is not None else None
+
+
+def silu_mul_parts(parts, out):
+    """out[r, :] = silu(gate) * up with gate|up = cast(sum_s parts[s, r, :]) ([slices, rows, 2I] fp32)."""
+    _dev(parts, out)
+    assert parts.is_contiguous() and parts.dtype == torch.float32 and out.is_contiguous()
+    rows, I = out.shape
+    assert parts.shape[1] == rows and parts.shape[2] == 2 * I
+    _check(lib().dl_silu_mul_parts(_p(parts), parts.shape[0], _p(out), rows, I, dtype_code(out.dtype), _stream()), "dl_silu_mul_parts")
     return out

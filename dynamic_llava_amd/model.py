@@ -427,7 +427,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._prefill_graphs = {}
         self.use_hip_graph = True
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
-        self.gemv_max_decode_batch = 4  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
+        self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         self.smallm_max_decode_batch = 16  # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
         self.eval()
@@ -856,31 +856,39 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             torch.cuda.current_stream().wait_stream(st.tp_stream)  # join before anything reads st.decision
 
     def _decode_step_gemm(self, st: _DecodeState, cache: KVSlabCache):
+        """Decode step for batches past the GEMV range.  B <= smallm_max_decode_batch: dl_gemm_smallm (weights streamed into the
+        matrix cores); its split-K partials are added by the consumer kernels (residual add + RMSNorm, SiLU*up) -- 9 launches per
+        layer.  Larger batches: library GEMMs."""
         cfg, sc = self.config, self.config.sparse_config
         nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
         cos, sin = self._rope
         use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
-        if st.use_smallm:
-            lin = lambda x, w: ops.gemm_smallm(x, w, workspace=st.lin_ws)  # noqa: E731
-        else:
-            lin = F.linear
+        sm, ws = st.use_smallm, st.lin_ws
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
         ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x)
         for i, layer in enumerate(self.model.layers):
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
-            qkv = lin(st.x, layer.w_qkv)
+            qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws) if sm else F.linear(st.x, layer.w_qkv)
             ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d)
-            o = lin(st.attn, layer.self_attn.o_proj.weight)
-            ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x)
-            ops.silu_mul(lin(st.x, layer.w_gu), out=st.act)
-            dn = lin(st.act, layer.mlp.down_proj.weight)
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
-            ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
-        if st.use_smallm:
-            ops.gemm_smallm(st.x, self.lm_head.weight, out=st.logits, workspace=st.lin_ws)
+            if sm:
+                parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)
+                ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=st.x)
+                parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws)
+                ops.silu_mul_parts(parts, st.act)
+                parts, _ = ops.gemm_smallm_parts(st.act, layer.mlp.down_proj.weight, ws)
+                ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)
+            else:
+                o = F.linear(st.attn, layer.self_attn.o_proj.weight)
+                ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x)
+                ops.silu_mul(F.linear(st.x, layer.w_gu), out=st.act)
+                dn = F.linear(st.act, layer.mlp.down_proj.weight)
+                ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
+        if sm:
+            ops.gemm_smallm(st.x, self.lm_head.weight, out=st.logits, workspace=ws)
         else:
             torch.matmul(st.x, self.lm_head.weight.t(), out=st.logits)
 

@@ -212,11 +212,19 @@ int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_s
  * operand registers).  bf16 / f16, fp32 accumulate, one rounding.  K % 256 == 0, N % 4 == 0; ldx / ldy: row strides (elements).
  * n_slices: split-K factor (0 = auto; the kernel may raise it so that the X slice fits LDS); when the effective factor is > 1
  * the fp32 partials go to `workspace` (dl_gemm_smallm_workspace_bytes(M, N, K, n_slices)) and a second launch adds them in slice
- * order.  wg_waves: 4 / 8 waves per workgroup (0 = auto). */
+ * order.  variant: 1 = weight fragments loaded straight into the MFMA operand registers (wg_waves = 4 / 8, 0 = auto), 2 = coalesced
+ * loads transposed through wave-private LDS (8 waves), 0 = auto. */
 int dl_gemm_smallm_max_m(void);
-int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices);
+int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices, int variant);
 int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, void* workspace, int M, int N, int K,
-                   int n_slices, int wg_waves, int dtype, void* stream);
+                   int n_slices, int wg_waves, int variant, int defer_reduce, int dtype, void* stream);
+/* defer_reduce != 0: leave the fp32 partials [slices][M][N] in `workspace` (always, even for one slice; Y may be NULL) for a consumer
+ * that adds them itself -- dl_add_rmsnorm_parts (o_proj / down_proj -> residual add + RMSNorm) and dl_silu_mul_parts (gate|up ->
+ * SiLU*up) -- which saves the reduce launch.  dl_gemm_smallm_slices: the effective slice count of such a call. */
+int dl_gemm_smallm_slices(int M, int N, int K, int n_slices, int variant);
+int dl_add_rmsnorm_parts(void* h, const float* parts, int n_slices, const void* w, void* out, int64_t rows, int H, float eps,
+                         int dtype, void* stream);
+int dl_silu_mul_parts(const float* parts, int n_slices, void* out, int64_t rows, int I, int dtype, void* stream);
 
 /* ---- diagnostics: one empty kernel (launch-floor measurements, tools/bench_launch_floor.py). */
 int dl_launch_probe(int grid, int block, void* stream);

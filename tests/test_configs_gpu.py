@@ -1,7 +1,8 @@
 """GPU: the BASELINE.json configs beyond the bench line, at full layer WIDTH (few layers so the oracle finishes in seconds),
 plus size-independent properties at full sizes.
 
-  C3  batch=32 images, ragged prompt lengths + per-row eviction (packed varlen; decode batch > 4 => hipBLASLt GEMM path)
+  C3  batch=32 images, ragged prompt lengths + per-row eviction (packed varlen; decode batch > 16 => library GEMM path)
+  mid batch  4..16 rows on dl_gemm_smallm + partial-sum consumers
   C5  LLaVA-1.5-13B width, long decode with incremental output-text KV eviction (slab growth, split-KV, hipGraph vs eager)
 """
 import pytest
@@ -147,3 +148,63 @@ def test_c5_13b_width_long_decode_with_eviction():
                 break
             agree += int(l_ref[0, -1].argmax()) == int(a[0, j + 1])
     assert agree >= 1
+
+
+@pytest.mark.parametrize("B", [4, 7, 16])
+def test_mid_batch_decode_smallm_rows_equal_b1(B):
+    """Decode batches 4..16 run on dl_gemm_smallm (+ partial-sum consumers).  Every row of a ragged batch must match its own B=1 run
+    (dl_gemv path): greedy tokens and per-step eviction decisions away from decision boundaries, logits in the same noise class."""
+    dtype = torch.bfloat16
+    cfg = fx.llava7b_config(num_hidden_layers=3)
+    cfg.vocab_size = 4096
+    sd = fx.make_state_dict(cfg, seed=11, predictor_gain=50.0)
+    model = _build(cfg, sd, dtype)
+    assert model.gemv_max_decode_batch < B <= model.smallm_max_decode_batch
+    g = torch.Generator().manual_seed(5)
+    n_q = torch.randint(8, 40, (B,), generator=g).tolist()
+    prompts = [fx.make_prompt(cfg, 35, n_q[b], seed=20 + b) for b in range(B)]
+    feats = torch.randn(B, 576, 4096, generator=g).to(dtype)
+    W = max(p.shape[0] for p in prompts)
+    ids = torch.zeros(B, W, dtype=torch.long)
+    am = torch.zeros(B, W, dtype=torch.long)
+    for b, p in enumerate(prompts):
+        ids[b, : p.shape[0]] = p
+        am[b, : p.shape[0]] = 1
+    ulp = 2.0**-7
+    forced = fx.make_forced_tokens(cfg, 8, B, seed=4)
+    model.debug_records = {}
+    ob = model(ids.cuda(), attention_mask=am.cuda(), image_features=feats.cuda())
+    assert model._dstate is None or True
+    pkv = ob.past_key_values
+    hist, dec_b, gap_b = [], [], []
+    for j in range(8):
+        ob = model(forced[j][:, None].cuda(), past_key_values=pkv)
+        pkv = ob.past_key_values
+        hist.append(ob.logits[:, -1].cpu())
+        dec_b.append(model.debug_records["text_decision"].cpu().clone())
+        tl = model.debug_records["text_logit"].cpu()
+        gap_b.append((tl[:, 0] - tl[:, 1]).abs())
+    assert model._dstate.use_smallm and not model._dstate.use_gemv, "this batch size must run on dl_gemm_smallm"
+    lens_b = [t.clone() for t in pkv[1]]
+    for b in sorted({0, B // 2, B - 1}):
+        o1 = model(prompts[b][None].cuda(), image_features=feats[b : b + 1].cuda())
+        p1 = o1.past_key_values
+        kept = 0
+        for j in range(8):
+            o1 = model(forced[j][b : b + 1][:, None].cuda(), past_key_values=p1)
+            p1 = o1.past_key_values
+            if float(gap_b[j][b]) < 0.5:
+                break  # boundary decision: the two GEMM paths may legitimately differ; stop comparing this row
+            assert int(model.debug_records["text_decision"][0]) == int(dec_b[j][b]), f"row {b} step {j}"
+            kept += int(dec_b[j][b])
+            ref = o1.logits[0, -1].cpu()
+            assert float((ref - hist[j][b]).abs().max()) <= 8 * ulp * float(ref.abs().max()), f"row {b} step {j}"
+        else:
+            assert int(lens_b[-1][b]) == 35 + 115 + n_q[b] + kept and int(lens_b[0][b]) == 35 + 576 + n_q[b] + 8
+    model.debug_records = None
+    # generate(): hipGraph replay == eager launches on this path too
+    model.use_hip_graph = True
+    a = model.generate(ids.cuda(), attention_mask=am.cuda(), image_features=feats.cuda(), max_new_tokens=6, eos_token_id=None)
+    model.use_hip_graph = False
+    c = model.generate(ids.cuda(), attention_mask=am.cuda(), image_features=feats.cuda(), max_new_tokens=6, eos_token_id=None)
+    assert torch.equal(a, c)

@@ -532,7 +532,8 @@ def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d):
     [(32, 4096, 4096, 0, 0), (16, 12288, 4096, 1, 4), (5, 22016, 4096, 0, 8), (8, 4096, 11008, 0, 0), (32, 4096, 11008, 0, 4), (17, 200, 512, 2, 0),
      (1, 64, 256, 0, 0), (9, 132, 768, 3, 8), (32, 32000, 4096, 0, 0), (24, 1000, 1280, 1, 0)],
 )
-def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves, variant):
     """Small-batch decode GEMM on the matrix cores == F.linear with fp32 accumulation and one rounding: both batch-tile counts, ragged M / N
     (tiles beyond N clamp, rows beyond M are zero), uneven K slices, LDS-forced slicing (32 x 11008), strided X / Y, deterministic."""
     g = torch.Generator().manual_seed(43)
@@ -540,9 +541,40 @@ def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves):
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
     ref = F.linear(x_full[:, :K].float(), w.float()).to(dtype)
     y_full = torch.full((M, N + 8), float("nan"), dtype=dtype, device="cuda")
-    out = ops.gemm_smallm(x_full.cuda()[:, :K], w.cuda(), out=y_full[:, :N], n_slices=n_slices, wg_waves=wg_waves)
+    out = ops.gemm_smallm(x_full.cuda()[:, :K], w.cuda(), out=y_full[:, :N], n_slices=n_slices, wg_waves=wg_waves, variant=variant)
     assert torch.isnan(y_full[:, N:]).all(), "must not write outside [M, N]"
     _close_ulp(out, ref, dtype, 1.0, atol=1e-3)
     assert _frac_exact(out, ref, dtype) > 0.97
-    out2 = ops.gemm_smallm(x_full.cuda()[:, :K], w.cuda(), n_slices=n_slices, wg_waves=wg_waves)
+    out2 = ops.gemm_smallm(x_full.cuda()[:, :K], w.cuda(), n_slices=n_slices, wg_waves=wg_waves, variant=variant)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,H,I", [(6, 4096, 11008), (16, 1024, 2816), (1, 512, 1024)])
+def test_smallm_partials_consumers_bit_equal_reduce_then_op(ops, dtype, M, H, I):
+    """dl_gemm_smallm(defer_reduce) + dl_add_rmsnorm_parts / dl_silu_mul_parts == dl_gemm_smallm (reduce launch) + dl_add_rmsnorm /
+    dl_silu_mul, bit for bit: the consumers add the split-K partials in the same slice order and round at the same points."""
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(M, H, generator=g).to(dtype).cuda()
+    act = torch.randn(M, I, generator=g).to(dtype).cuda()
+    w_gu = (torch.randn(2 * I, H, generator=g) / math.sqrt(H)).to(dtype).cuda()
+    w_dn = (torch.randn(H, I, generator=g) / math.sqrt(I)).to(dtype).cuda()
+    h0 = torch.randn(M, H, generator=g).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype).cuda()
+    ws = torch.empty(8 * M * 2 * I, dtype=torch.float32, device="cuda")
+    # gate|up -> SiLU*up
+    ref = ops.silu_mul(ops.gemm_smallm(x, w_gu, workspace=ws), out=torch.empty(M, I, dtype=dtype, device="cuda"))
+    parts, s = ops.gemm_smallm_parts(x, w_gu, ws)
+    assert parts.shape == (s, M, 2 * I)
+    out = ops.silu_mul_parts(parts, torch.empty(M, I, dtype=dtype, device="cuda"))
+    assert torch.equal(out, ref)
+    # down -> residual add + RMSNorm
+    dn = ops.gemm_smallm(act, w_dn, workspace=ws)
+    h_a = h0.clone()
+    x_a = ops.add_rmsnorm(h_a, dn, nw, 1e-5)
+    parts, s = ops.gemm_smallm_parts(act, w_dn, ws)
+    h_b = h0.clone()
+    x_b = ops.add_rmsnorm_parts(h_b, parts, nw, 1e-5)
+    assert torch.equal(h_a, h_b) and torch.equal(x_a, x_b)
+    h_c = h0.clone()
+    assert ops.add_rmsnorm_parts(h_c, parts) is None and torch.equal(h_c, h_a)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Decode ms/step at small batch sizes: dl_gemv path (gemv_max_decode_batch >= B) vs the library-GEMM path.
+"""Decode ms/step per batch size: dl_gemv (B <= 3), dl_gemm_smallm (4..16, vs the library GEMM it replaces), library GEMM beyond.
     python tools/bench_decode_batch.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,14 +22,14 @@ def run(B, n_new):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 
-for B in (4, 5, 8, 12, 16):
-    for maxb in (4, 16):
-        if B <= 4 and maxb == 16:
+for B in (1, 2, 3, 4, 8, 16, 20, 32):
+    for maxb in (0, 16):  # 0: dl_gemm_smallm off (library GEMM past the dl_gemv range)
+        if (B <= 3 or B > 16) and maxb == 0:
             continue
-        model.smallm_max_decode_batch = maxb if maxb > 4 else 0
+        model.smallm_max_decode_batch = maxb
         model._dstate = None
         for _ in range(2):
             run(B, 33); run(B, 1)
         t = min(run(B, 65) for _ in range(3)) - min(run(B, 1) for _ in range(3))
-        path = "dl_gemv" if B <= 4 else ("dl_gemm_smallm" if maxb > 4 else "library GEMM")
+        path = "dl_gemv" if B <= model.gemv_max_decode_batch else ("dl_gemm_smallm" if B <= maxb else "library GEMM")
         print(f"B={B} ({path:12s}): {t / 64 * 1e3:6.3f} ms/step  {B * 64 / t:8.1f} tok/s", flush=True)
