@@ -10,6 +10,12 @@ def __getattr__(name):  # lazy: importing the package must not require the .so
         from . import model
 
         return getattr(model, name)
+    if name == "LlavaLlamaForCausalLM":  # the name upstream-LLaVA harnesses import (llava/model/__init__.py:1-13 exports both)
+        from . import model
+
+        return model.DynamicLlavaLlamaForCausalLM
+    if name == "LlavaConfig":
+        return DynamicLlavaConfig
     if name in ("load_pretrained_model", "build_random_model", "build_from_state_dict"):
         from . import builder
 

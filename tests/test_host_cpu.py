@@ -73,6 +73,9 @@ def test_config_roundtrip_and_state_dict_keys(tmp_path):
     cfg.save_pretrained(str(tmp_path))
     cfg2 = DynamicLlavaConfig.from_pretrained(str(tmp_path))
     assert cfg2.to_dict() == cfg.to_dict() and cfg2.sparse_config["sparse_layer"] == 2 and cfg2.n_image_tokens == 36
+    import dynamic_llava_amd
+
+    assert dynamic_llava_amd.LlavaLlamaForCausalLM is DynamicLlavaLlamaForCausalLM and dynamic_llava_amd.LlavaConfig is DynamicLlavaConfig
     m = DynamicLlavaLlamaForCausalLM(cfg)
     own = {k for k in m.state_dict() if "vision_tower" not in k}
     ref = set(fx.make_state_dict(ns, seed=0))  # the reference's key names (checked against the reference in oracle/make_golden.py)
