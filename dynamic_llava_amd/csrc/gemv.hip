@@ -234,9 +234,8 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
   }
 }
 
-// tuning knobs (dl_gemv_set_tuning): variant = 0:(R2,U4) 1:(R4,U2) 2:(R2,U8) 3:(R1,U8) 4:(R4,U4); PAIR kernels always use R=2.
+// tuning knob (dl_gemv_set_tuning): the workgroup cap
 static int g_gemv_grid_cap = 512;  // tools/bench_gemv.py sweep: 2 workgroups per CU is at or near the optimum for every decode shape
-static int g_gemv_variant = 0;
 
 template <typename T, int B, int MODE, bool PAIR, int R, int U>
 static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
@@ -266,15 +265,10 @@ template <typename T, int B, int MODE>
 static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
                         const void* nw, float eps, void* y, int64_t y_rs, hipStream_t st) {
 #define DL_ARGS W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st
-  if (pair) return g_gemv_variant == 2 ? gemv_go<T, B, MODE, true, 2, 8>(DL_ARGS) : gemv_go<T, B, MODE, true, 2, 4>(DL_ARGS);
-  if (B > 4) return gemv_go<T, B, MODE, false, 2, 4>(DL_ARGS);  // keep the instantiation count (and VGPRs) bounded for larger B
-  switch (g_gemv_variant) {
-    case 1: return gemv_go<T, B, MODE, false, 4, 2>(DL_ARGS);
-    case 2: return gemv_go<T, B, MODE, false, 2, 8>(DL_ARGS);
-    case 3: return gemv_go<T, B, MODE, false, 1, 8>(DL_ARGS);
-    case 4: return gemv_go<T, B, MODE, false, 4, 4>(DL_ARGS);
-    default: return gemv_go<T, B, MODE, false, 2, 4>(DL_ARGS);
-  }
+  // one load schedule (2 neurons x 4 chunks per wave in flight): the tools/bench_gemv.py sweep over (4x2), (2x8), (1x8), (4x4) found
+  // nothing faster on any decode shape, and every extra schedule costs 72 kernel instantiations of compile time
+  if (pair) return gemv_go<T, B, MODE, true, 2, 4>(DL_ARGS);
+  return gemv_go<T, B, MODE, false, 2, 4>(DL_ARGS);
 #undef DL_ARGS
 }
 
@@ -293,9 +287,8 @@ static int gemv_launch(int mode, const void* W, int N, int K, const void* x, int
 using namespace dl;
 
 extern "C" int dl_gemv_set_tuning(int grid_cap, int variant) {
-  DL_REQUIRE(grid_cap >= 1 && variant >= 0 && variant <= 4, "dl_gemv_set_tuning: bad arguments");
+  DL_REQUIRE(grid_cap >= 1 && variant == 0, "dl_gemv_set_tuning: bad arguments (only load-schedule variant 0 is built)");
   g_gemv_grid_cap = grid_cap;
-  g_gemv_variant = variant;
   return DL_OK;
 }
 

@@ -191,8 +191,8 @@ int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, 
 #define DL_GEMV_SILUMUL 2
 #define DL_GEMV_OUT_SILU_PAIR 16
 int dl_gemv_max_batch(int K, int dtype);
-/* tuning knob (process-global, not thread-safe; defaults are the tuned ones): workgroup cap and load-schedule variant
- * 0:(2 neurons x 4 chunks in flight per wave) 1:(4x2) 2:(2x8) 3:(1x8) 4:(4x4). */
+/* tuning knob (process-global, not thread-safe; the default is the tuned one): workgroup cap.  `variant` must be 0 (the one load
+ * schedule that is built: 2 neurons x 4 chunks in flight per wave). */
 int dl_gemv_set_tuning(int grid_cap, int variant);
 int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_stride, const void* h_in, void* h_out,
             const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, void* stream);

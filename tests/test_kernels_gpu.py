@@ -370,13 +370,13 @@ def test_gemv_modes(ops, dtype, B, N, K):
     _close_ulp(y, ref, dtype, 2.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
     with pytest.raises(ops.HipOpsError):
         ops.gemv(wd, y, mode=ops.GEMV_ADDNORM, h_in=h_out, h_out=h_out, delta=dl.cuda(), norm_w=nw.cuda())  # in-place residual is a race
-    # SILU_PAIR epilogue on a fused gate|up weight: act = silu(W[:I] x) * (W[I:] x), every tuning variant
+    # SILU_PAIR epilogue on a fused gate|up weight: act = silu(W[:I] x) * (W[I:] x), two workgroup caps
     if N % 2 == 0:
         I = N // 2
         gu_ref = F.linear(x.float(), w.float()).to(dtype)
         ref = F.silu(gu_ref[:, :I]) * gu_ref[:, I:]
-        for variant in range(5):
-            ops.lib().dl_gemv_set_tuning(512, variant)
+        for cap in (512, 64):
+            ops.lib().dl_gemv_set_tuning(cap, 0)
             act = torch.empty(B, I, dtype=dtype, device="cuda")
             ops.gemv(wd, act, x=x.cuda(), mode=ops.GEMV_OUT_SILU_PAIR)
             _close_ulp(act, ref, dtype, 4.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
