@@ -192,6 +192,207 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
   }
 }
 
+// ---- software-pipelined variant for rows that span many K/V tiles (max_seqlen > 256).
+// K/V tiles are double-buffered in LDS: while the MFMAs of tile j run, the global loads of tile j+1 are in flight in registers and
+// are written to the other buffer before the single barrier of the iteration (the plain kernel above has three barriers and an
+// exposed global-load round trip per tile).  V is transposed with 8-byte LDS writes of 4 consecutive keys (conflict-free: lanes of
+// a quarter-wave write 128 contiguous bytes) instead of 2-byte scatters.  P is wave-private: no workgroup barrier around it.
+template <typename T, int D, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_pipe_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
+                                                                         const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
+                                                                         void* __restrict__ out_, int64_t out_rs,
+                                                                         const int32_t* __restrict__ cu, int n_rep, float scale,
+                                                                         const int32_t* __restrict__ kv_len, int64_t kv_sb, int64_t kv_sh) {
+  using S = uint16_t;
+  constexpr int KS = D / 32, DT = D / 16, NT = kBN / 16;
+  constexpr int LDK = D + kPad, LDV = kBN + kPad, LDP = kBN + kPad;
+  constexpr int kBM = 16 * NW, NT_ = NW * 64;
+  constexpr int CPR = D / 8;                          // 16-byte chunks per K/V row
+  constexpr int KIT = (kBN * CPR) / NT_;              // K chunks per thread per tile
+  constexpr int VITEMS = (kBN / 4) * CPR;             // V items (4 keys x one chunk) per tile
+  constexpr int VIT = (VITEMS + NT_ - 1) / NT_;       // V items per thread per tile
+  constexpr int kTile = kBN * LDK + D * LDV;          // elements per K|V^T buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S* bufs = reinterpret_cast<S*>(smem);               // [2][kTile]
+  S* Ps = bufs + 2 * kTile;                           // [NW][16][LDP]
+
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  const int q0 = qt * kBM;
+  if (q0 >= L) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kvh = h / n_rep;
+  const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
+  const int off = kv_len ? kv_len[b] : 0;
+  const int Lk = off + L;
+  if (kv_len) kv_rs = D;
+  const S* kb = kv_len ? reinterpret_cast<const S*>(k_) + (int64_t)b * kv_sb + (int64_t)kvh * kv_sh
+                       : reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = kv_len ? reinterpret_cast<const S*>(v_) + (int64_t)b * kv_sb + (int64_t)kvh * kv_sh
+                       : reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+
+  uint4 kreg[KIT], vreg[VIT][4];
+  auto fetch = [&](int key0) {  // tile -> registers (zeros beyond the sequence)
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = it * NT_ + tid;
+      const int key = key0 + idx / CPR, ch = idx % CPR;
+      kreg[it] = make_uint4(0, 0, 0, 0);
+      if (key < Lk) kreg[it] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * kv_rs + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int item = it * NT_ + tid;  // key group fastest: lanes of a quarter-wave own 16 consecutive key groups of one chunk
+      const int kg = item % (kBN / 4), ch = item / (kBN / 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = key0 + kg * 4 + j;
+        vreg[it][j] = make_uint4(0, 0, 0, 0);
+        if (item < VITEMS && key < Lk) vreg[it][j] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * kv_rs + ch * 8);
+      }
+    }
+  };
+  auto stash = [&](S* buf) {  // registers -> K (row-major) | V^T
+    S* Ks = buf;
+    S* Vt = buf + kBN * LDK;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = it * NT_ + tid;
+      *reinterpret_cast<uint4*>(Ks + (idx / CPR) * LDK + (idx % CPR) * 8) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int item = it * NT_ + tid;
+      if (item < VITEMS) {
+        const int kg = item % (kBN / 4), ch = item / (kBN / 4);
+        const uint32_t w0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
+        const uint32_t w1[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+        const uint32_t w2[4] = {vreg[it][2].x, vreg[it][2].y, vreg[it][2].z, vreg[it][2].w};
+        const uint32_t w3[4] = {vreg[it][3].x, vreg[it][3].y, vreg[it][3].z, vreg[it][3].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // dims 2e, 2e+1 of the chunk: 4 keys each -> one 8-byte write per dim
+          uint2 lo, hi;
+          lo.x = (w0[e] & 0xffffu) | (w1[e] << 16);
+          lo.y = (w2[e] & 0xffffu) | (w3[e] << 16);
+          hi.x = (w0[e] >> 16) | (w1[e] & 0xffff0000u);
+          hi.y = (w2[e] >> 16) | (w3[e] & 0xffff0000u);
+          *reinterpret_cast<uint2*>(Vt + (ch * 8 + 2 * e) * LDV + kg * 4) = lo;
+          *reinterpret_cast<uint2*>(Vt + (ch * 8 + 2 * e + 1) * LDV + kg * 4) = hi;
+        }
+      }
+    }
+  };
+
+  const int n_tiles = CAUSAL ? min((Lk + kBN - 1) / kBN, (q0 + kBM - 1 + off) / kBN + 1) : (Lk + kBN - 1) / kBN;
+  fetch(0);  // in flight while the Q fragments are loaded
+  uint4 qf[KS];
+  {
+    const int qrow = q0 + w * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = make_uint4(0, 0, 0, 0);
+      if (qrow < L) qf[ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * q_rs + ks * 32 + lg * 8);
+    }
+  }
+  f32x4_t acc_o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc_o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+  }
+  S* Pw = Ps + w * 16 * LDP;
+  stash(bufs);
+  __syncthreads();
+
+  for (int jt = 0; jt < n_tiles; ++jt) {
+    const int key0 = jt * kBN;
+    const S* Ks = bufs + (jt & 1) * kTile;
+    const S* Vt = Ks + kBN * LDK;
+    const bool more = jt + 1 < n_tiles;
+    if (more) fetch(key0 + kBN);
+    // ---- S = Q K^T ----
+    f32x4_t acc_s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc_s[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (nt * 16 + lr) * LDK + ks * 32 + lg * 8);
+        acc_s[nt] = mfma16<T>(qf[ks], kf, acc_s[nt]);
+      }
+    }
+    // ---- online softmax on the C layout: row = lg*4 + r, col = nt*16 + lr ----
+    float alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = q0 + w * 16 + lg * 4 + r;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ki = key0 + nt * 16 + lr;
+        float sv = acc_s[nt][r] * scale;
+        if (ki >= Lk || (CAUSAL && ki > qi + off)) sv = -INFINITY;
+        acc_s[nt][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mn = fmaxf(m[r], mx);
+      const float ms = mn == -INFINITY ? 0.f : mn;
+      alpha[r] = __expf(m[r] - ms);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float p = __expf(acc_s[nt][r] - ms);
+        acc_s[nt][r] = p;
+        rs += p;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+      l[r] = l[r] * alpha[r] + rs;
+      m[r] = mn;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha[r];
+    // ---- P (C layout) -> wave-private LDS -> A layout: only this wave touches Pw, LDS is in-order per wave ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pw[(lg * 4 + r) * LDP + nt * 16 + lr] = Elem<T>::from_f(acc_s[nt][r]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- O += P V ----
+#pragma unroll
+    for (int ks = 0; ks < kBN / 32; ++ks) {
+      const uint4 pf = *reinterpret_cast<const uint4*>(Pw + lr * LDP + ks * 32 + lg * 8);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(Vt + (dt * 16 + lr) * LDV + ks * 32 + lg * 8);
+        acc_o[dt] = mfma16<T>(pf, vf, acc_o[dt]);
+      }
+    }
+    if (more) stash(bufs + ((jt + 1) & 1) * kTile);  // the other buffer: last read two iterations ago, before the previous barrier
+    __syncthreads();
+  }
+  S* ob = reinterpret_cast<S*>(out_) + (int64_t)tok0 * out_rs + (int64_t)h * D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q0 + w * 16 + lg * 4 + r;
+    if (qi < L) {
+      const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) ob[(int64_t)qi * out_rs + dt * 16 + lr] = Elem<T>::from_f(acc_o[dt][r] * inv);
+    }
+  }
+}
+
 // ---- generic path: one wave per query row, lanes over keys (scores) then over dims (output) ----
 template <typename T>
 __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
@@ -256,12 +457,28 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
   // 4 waves for long ones; 1 wave never wins (each workgroup then stages whole K/V tiles alone)
   int nw = max_seqlen <= 256 ? 2 : 4;
   if (const char* e = getenv("DL_PF_NW")) nw = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 4);  // tuning experiments only
+  // tools/bench_attn_prefill.py: the software-pipelined kernel wins once rows span several K/V tiles (T=631: 61 -> 46 us;
+  // B=32 T=700: 974 -> 708 us), is a wash at T=170 (3 tiles, latency of the dependent S -> softmax -> PV chain dominates) and loses
+  // at B=32 T=215, where 3 resident workgroups per CU hide the loads better than one double-buffered one
+  bool pipe = max_seqlen > 256;
+  if (const char* e = getenv("DL_PF_PIPE")) pipe = atoi(e) != 0;  // tuning experiments only
 #define DL_LAUNCH_PF(NWV, CAUS)                                                                                                          \
   {                                                                                                                                      \
-    const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + NWV * 16 * (kBN + kPad)) * 2;                                     \
     const dim3 grid((unsigned)((max_seqlen + 16 * NWV - 1) / (16 * NWV)), (unsigned)n_heads, (unsigned)B);                              \
-    hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, CAUS, NWV>), grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, \
-                       cu, n_rep, scale, kv_len, kv_sb, kv_sh);                                                                          \
+    if (pipe && NWV > 1) {                                                                                                               \
+      const size_t smem = (size_t)(2 * (kBN * (D + kPad) + D * (kBN + kPad)) + NWV * 16 * (kBN + kPad)) * 2;                             \
+      auto kfn = attn_prefill_mfma_pipe_kernel<T, D, CAUS, (NWV > 1 ? NWV : 2)>;                                                         \
+      static bool attr_set = false;                                                                                                      \
+      if (!attr_set && smem > 64 * 1024) {                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);           \
+        attr_set = true;                                                                                                                 \
+      }                                                                                                                                  \
+      hipLaunchKernelGGL(kfn, grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale, kv_len, kv_sb, kv_sh); \
+    } else {                                                                                                                             \
+      const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + NWV * 16 * (kBN + kPad)) * 2;                                   \
+      hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, CAUS, NWV>), grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, \
+                         cu, n_rep, scale, kv_len, kv_sb, kv_sh);                                                                        \
+    }                                                                                                                                    \
   }
   if (causal) {
     if (nw == 4) DL_LAUNCH_PF(4, true) else if (nw == 2) DL_LAUNCH_PF(2, true) else DL_LAUNCH_PF(1, true)

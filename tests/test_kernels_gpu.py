@@ -225,7 +225,7 @@ def _sdpa_ref(q, k, v, causal):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (4, 2, 128, [129])])
+@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (4, 2, 128, [129]), (4, 2, 128, [300, 631, 17, 257])])
 def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
     g = torch.Generator().manual_seed(8)
     total = sum(lens)
@@ -498,12 +498,12 @@ def test_c_abi_rejects_bad_arguments(ops):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("nH,nKV,d", [(4, 4, 128), (4, 2, 64)])
-def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d):
+@pytest.mark.parametrize("Lq", [[70, 5, 64], [300, 5, 270]])  # short chunks: plain kernel; > 256 queries: software-pipelined kernel
+def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d, Lq):
     """Chunk of queries against the KV slab: query j of row b sees keys [0, kv_len[b] + j]."""
     g = torch.Generator().manual_seed(18)
     kv_len = [0, 37, 200]
-    Lq = [70, 5, 64]
-    B, T_cap = 3, 300
+    B, T_cap = 3, 600
     k_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
     v_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
     total = sum(Lq)
