@@ -460,7 +460,9 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
   // tools/bench_attn_prefill.py: the software-pipelined kernel wins once rows span several K/V tiles (T=631: 61 -> 46 us;
   // B=32 T=700: 974 -> 708 us), is a wash at T=170 (3 tiles, latency of the dependent S -> softmax -> PV chain dominates) and loses
   // at B=32 T=215, where 3 resident workgroups per CU hide the loads better than one double-buffered one
-  bool pipe = max_seqlen > 256;
+  // (head_dim 64 -- CLIP, the vision predictor -- stays on the plain kernel: 31.6 vs 34.6 us at T=577, its tiles are too small to pay
+  // for the second buffer)
+  bool pipe = max_seqlen > 256 && D == 128;
   if (const char* e = getenv("DL_PF_PIPE")) pipe = atoi(e) != 0;  // tuning experiments only
 #define DL_LAUNCH_PF(NWV, CAUS)                                                                                                          \
   {                                                                                                                                      \
