@@ -141,9 +141,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(const void* __rest
 // Here a wave loads its [16 neurons x 256 k] chunk as dl_gemv does -- each instruction two rows x 512 contiguous bytes, non-temporal,
 // two chunks (16 KiB) in flight per wave -- parks it in its own 8 KiB of LDS (no barrier: only the wave itself reads it back) and
 // reads the MFMA A-fragments from there.  8 waves per workgroup; X slice resident as before.
-constexpr int kSmKC = 256;
-constexpr int kSmStLd = kSmKC + 8;
-constexpr int kSmStWaves = 8;
+constexpr int kSmStagePerWaveBytes(int kc) { return 16 * (kc + 8) * 2; }
 
 __device__ __forceinline__ uint4 sm_ldg_nt(const void* p) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -151,12 +149,14 @@ __device__ __forceinline__ uint4 sm_ldg_nt(const void* p) {
   return make_uint4(r.x, r.y, r.z, r.w);
 }
 
-template <typename T, int NB>
-__global__ __launch_bounds__(kSmStWaves * 64) void gemm_smallm_staged_kernel(const void* __restrict__ X_, int64_t ldx,
+// KC: k per chunk (256: one instruction = 2 rows x 512 B; 128: 4 rows x 256 B).  NW: waves per workgroup (staging = NW x 16 x (KC+8) x 2 B).
+template <typename T, int NB, int KC, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_smallm_staged_kernel(const void* __restrict__ X_, int64_t ldx,
                                                                              const void* __restrict__ W_, void* __restrict__ Y_, int64_t ldy,
                                                                              float* __restrict__ part, int M, int N, int K, int n_slices, int direct) {
   using S = uint16_t;
-  constexpr int NW = kSmStWaves;
+  constexpr int kSmKC = KC, kSmStLd = KC + 8;
+  constexpr int LPR = KC / 8, RPI = 64 / LPR, NI = 16 / RPI;  // lanes per row, rows per load instruction, instructions per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char sm_smem[];
   const S* X = reinterpret_cast<const S*>(X_);
   const S* W = reinterpret_cast<const S*>(W_);
@@ -176,19 +176,19 @@ __global__ __launch_bounds__(kSmStWaves * 64) void gemm_smallm_staged_kernel(con
   const int my_tiles = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
   const int total = my_tiles * cpt;
 
-  const int srow = lane >> 5, scol = (lane & 31) * 8;  // staging-load role of this lane: row 2j + srow, 16 bytes at scol
-  auto issue = [&](int t, uint4(&r)[8]) {
+  const int srow = lane / LPR, scol = (lane % LPR) * 8;  // staging-load role of this lane: row RPI*j + srow, 16 bytes at scol
+  auto issue = [&](int t, uint4(&r)[NI]) {
     const int tile_i = t / cpt, c = t - tile_i * cpt;
     const int n0 = (first + tile_i * stride) * 16;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int n = n0 + 2 * j + srow;
+    for (int j = 0; j < NI; ++j) {
+      int n = n0 + RPI * j + srow;
       n = n < N ? n : N - 1;
       r[j] = sm_ldg_nt(W + (int64_t)n * K + k0 + c * kSmKC + scol);
     }
   };
 
-  uint4 ra[8], rb[8];
+  uint4 ra[NI], rb[NI];
   if (total > 0) issue(0, ra);
   if (total > 1) issue(1, rb);
 
@@ -211,9 +211,9 @@ __global__ __launch_bounds__(kSmStWaves * 64) void gemm_smallm_staged_kernel(con
   const S* ab = stg + lr * kSmStLd + lg * 8;
   int ci = 0, ti = 0;  // chunk within the tile, tile index
 
-  auto consume = [&](uint4(&r)[8], int t_next) {
+  auto consume = [&](uint4(&r)[NI], int t_next) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(stg + (2 * j + srow) * kSmStLd + scol) = r[j];
+    for (int j = 0; j < NI; ++j) *reinterpret_cast<uint4*>(stg + (RPI * j + srow) * kSmStLd + scol) = r[j];
     if (t_next < total) issue(t_next, r);
 #pragma unroll
     for (int ks = 0; ks < kSmKC / 32; ++ks) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_reduce_kernel(const float* __
 static int sm_slices(int M, int N, int K, int want, int variant) {
   const int units = K / kSmKUnit;
   const int rows = M <= 16 ? 16 : 32;
-  const int budget = kSmLdsBytes - (variant == 2 ? kSmStWaves * 16 * kSmStLd * 2 : 0);
+  const int budget = kSmLdsBytes - (variant == 2 ? 8 * kSmStagePerWaveBytes(256) : (variant == 3 ? 16 * kSmStagePerWaveBytes(128) : 0));
   const int max_ks = (budget / (rows * 2) - 8) / kSmKUnit * kSmKUnit;
   int s_lds = 1;
   while ((units + s_lds - 1) / s_lds * kSmKUnit > max_ks) ++s_lds;
@@ -290,7 +290,7 @@ static int sm_slices(int M, int N, int K, int want, int variant) {
     const int n_tiles = (N + 15) / 16;
     // tools/bench_gemm_smallm.py: many short weight streams beat few long ones.  Direct fragments: qkv / o / down 8, gate|up 5;
     // LDS-staged (2048 waves in one round): gate|up / lm_head 4, qkv / o / down 8.
-    s = variant == 2 ? (n_tiles >= 1024 ? 4 : 8) : (6144 + n_tiles - 1) / n_tiles;
+    s = variant >= 2 ? (n_tiles >= 1024 ? 4 : 8) : (6144 + n_tiles - 1) / n_tiles;
     if (s > 8) s = 8;
   }
   if (s < s_lds) s = s_lds;
@@ -332,14 +332,13 @@ static void sm_reduce(float* part, void* Y, int64_t ldy, int M, int N, int n_sli
   }
 }
 
-template <typename T, int NB>
+template <typename T, int NB, int KC, int NW>
 static int sm_go_staged(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, float* part, int M, int N, int K, int n_slices,
                         int direct, hipStream_t st) {
-  constexpr int NW = kSmStWaves;
   const int units = K / kSmKUnit;
   const int max_ks = (units + n_slices - 1) / n_slices * kSmKUnit;
-  const size_t smem = (size_t)NW * 16 * kSmStLd * 2 + (size_t)NB * 16 * (max_ks + 8) * 2;
-  auto kfn = gemm_smallm_staged_kernel<T, NB>;
+  const size_t smem = (size_t)NW * kSmStagePerWaveBytes(KC) + (size_t)NB * 16 * (max_ks + 8) * 2;
+  auto kfn = gemm_smallm_staged_kernel<T, NB, KC, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
@@ -351,7 +350,7 @@ static int sm_go_staged(const void* X, int64_t ldx, const void* W, void* Y, int6
   }
   const int n_tiles = (N + 15) / 16;
   int gx = (n_tiles + NW - 1) / NW;
-  const int cap = 2048 / NW / n_slices > 0 ? 2048 / NW / n_slices : 1;  // one workgroup (8 waves) per CU in a single round; tiles beyond that are looped over
+  const int cap = (256 * NW) / NW / n_slices > 0 ? (256 * NW) / NW / n_slices : 1;  // one workgroup per CU in a single round; tiles beyond that are looped over
   if (gx > cap) gx = cap;
   hipLaunchKernelGGL(kfn, dim3((unsigned)gx, (unsigned)n_slices), dim3(NW * 64), smem, st, X, ldx, W, Y, ldy, part, M, N, K, n_slices, direct);
   return DL_OK;
@@ -365,13 +364,13 @@ extern "C" int dl_gemm_smallm_max_m(void) { return kSmMaxM; }
 
 extern "C" int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices, int variant) {
   if (M <= 0 || N <= 0 || K <= 0 || K % kSmKUnit) return 0;
-  const int s = sm_slices(M, N, K, n_slices, variant == 1 ? 1 : 2);
+  const int s = sm_slices(M, N, K, n_slices, variant == 0 ? 2 : variant);
   return (int64_t)s * M * N * (int64_t)sizeof(float);  // also covers defer_reduce with a single slice
 }
 
 extern "C" int dl_gemm_smallm_slices(int M, int N, int K, int n_slices, int variant) {
   if (M <= 0 || N <= 0 || K <= 0 || K % kSmKUnit) return 0;
-  return sm_slices(M, N, K, n_slices, variant == 1 ? 1 : 2);
+  return sm_slices(M, N, K, n_slices, variant == 0 ? 2 : variant);
 }
 
 extern "C" int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, void* workspace, int M, int N, int K,
@@ -383,7 +382,7 @@ extern "C" int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y
   DL_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0, "dl_gemm_smallm: X and W must be 16-byte aligned");
   DL_REQUIRE(n_slices >= 0 && n_slices <= 64, "dl_gemm_smallm: n_slices must be in [0, 64]");
   DL_REQUIRE(wg_waves == 0 || wg_waves == 4 || wg_waves == 8, "dl_gemm_smallm: wg_waves must be 0 (auto), 4 or 8");
-  DL_REQUIRE(variant >= 0 && variant <= 2, "dl_gemm_smallm: variant must be 0 (auto), 1 (direct fragments) or 2 (LDS-staged)");
+  DL_REQUIRE(variant >= 0 && variant <= 3, "dl_gemm_smallm: variant must be 0 (auto), 1 (direct fragments), 2 (LDS-staged, 8 waves x 256 k) or 3 (16 waves x 128 k)");
   if (variant == 0) variant = 2;
   const int s = sm_slices(M, N, K, n_slices, variant);
   const int direct = (s == 1 && !defer_reduce) ? 1 : 0;
@@ -394,8 +393,11 @@ extern "C" int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y
   int rc = DL_OK;
 #define DL_SM_ARGS X, ldx, W, Y, ldy, part, M, N, K, s, direct, st
   if (variant == 2) {
-    if (dtype == DL_BF16) rc = M <= 16 ? sm_go_staged<bf16_t, 1>(DL_SM_ARGS) : sm_go_staged<bf16_t, 2>(DL_SM_ARGS);
-    else rc = M <= 16 ? sm_go_staged<f16_t, 1>(DL_SM_ARGS) : sm_go_staged<f16_t, 2>(DL_SM_ARGS);
+    if (dtype == DL_BF16) rc = M <= 16 ? sm_go_staged<bf16_t, 1, 256, 8>(DL_SM_ARGS) : sm_go_staged<bf16_t, 2, 256, 8>(DL_SM_ARGS);
+    else rc = M <= 16 ? sm_go_staged<f16_t, 1, 256, 8>(DL_SM_ARGS) : sm_go_staged<f16_t, 2, 256, 8>(DL_SM_ARGS);
+  } else if (variant == 3) {
+    if (dtype == DL_BF16) rc = M <= 16 ? sm_go_staged<bf16_t, 1, 128, 16>(DL_SM_ARGS) : sm_go_staged<bf16_t, 2, 128, 16>(DL_SM_ARGS);
+    else rc = M <= 16 ? sm_go_staged<f16_t, 1, 128, 16>(DL_SM_ARGS) : sm_go_staged<f16_t, 2, 128, 16>(DL_SM_ARGS);
   } else if (dtype == DL_BF16) {
     if (M <= 16) rc = w8 ? sm_go<bf16_t, 1, 8>(DL_SM_ARGS) : sm_go<bf16_t, 1, 4>(DL_SM_ARGS);
     else rc = w8 ? sm_go<bf16_t, 2, 8>(DL_SM_ARGS) : sm_go<bf16_t, 2, 4>(DL_SM_ARGS);

@@ -213,7 +213,7 @@ int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_s
  * n_slices: split-K factor (0 = auto; the kernel may raise it so that the X slice fits LDS); when the effective factor is > 1
  * the fp32 partials go to `workspace` (dl_gemm_smallm_workspace_bytes(M, N, K, n_slices)) and a second launch adds them in slice
  * order.  variant: 1 = weight fragments loaded straight into the MFMA operand registers (wg_waves = 4 / 8, 0 = auto), 2 = coalesced
- * loads transposed through wave-private LDS (8 waves), 0 = auto. */
+ * loads transposed through wave-private LDS (8 waves x 256-k chunks), 3 = the same with 16 waves x 128-k chunks, 0 = auto (2). */
 int dl_gemm_smallm_max_m(void);
 int64_t dl_gemm_smallm_workspace_bytes(int M, int N, int K, int n_slices, int variant);
 int dl_gemm_smallm(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, void* workspace, int M, int N, int K,

@@ -532,7 +532,7 @@ def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d, Lq):
     [(32, 4096, 4096, 0, 0), (16, 12288, 4096, 1, 4), (5, 22016, 4096, 0, 8), (8, 4096, 11008, 0, 0), (32, 4096, 11008, 0, 4), (17, 200, 512, 2, 0),
      (1, 64, 256, 0, 0), (9, 132, 768, 3, 8), (32, 32000, 4096, 0, 0), (24, 1000, 1280, 1, 0)],
 )
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves, variant):
     """Small-batch decode GEMM on the matrix cores == F.linear with fp32 accumulation and one rounding: both batch-tile counts, ragged M / N
     (tiles beyond N clamp, rows beyond M are zero), uneven K slices, LDS-forced slicing (32 x 11008), strided X / Y, deterministic."""

@@ -43,11 +43,11 @@ for M in Ms:
 
         t_lib = timed(lib)
         res = []
-        for nw in (4, 8, 2):  # 2 = the LDS-staged variant
+        for nw in (8, 2, 3):  # 8: direct fragments (8 waves); 2 / 3: the LDS-staged variants (8 waves x 256 k / 16 waves x 128 k)
             for sp in (1, 2, 3, 4, 6, 8):
                 def mine():
                     i = it[0] = (it[0] + 1) % NB
-                    ops.gemm_smallm(x, ws[i], out=y, workspace=scratch, n_slices=sp, wg_waves=0 if nw == 2 else nw, variant=2 if nw == 2 else 1)
+                    ops.gemm_smallm(x, ws[i], out=y, workspace=scratch, n_slices=sp, wg_waves=0 if nw in (2, 3) else nw, variant=nw if nw in (2, 3) else 1)
                 try:
                     res.append((timed(mine), nw, sp))
                 except Exception as e:
@@ -61,6 +61,6 @@ for M in Ms:
         res.sort()
         gb = N * K * 2 / 1e3
         tot_lib += t_lib; tot_best += res[0][0]; tot_auto += t_auto
-        print(f"M={M:3d} {name:8s} [{N},{K}] lib {t_lib:6.2f}us ({gb / t_lib:5.0f} GB/s) | auto {t_auto:6.2f}us ({gb / t_auto:5.0f} GB/s) | best " + "  ".join(f"{t:6.2f}us({'st' if nw == 2 else 'w' + str(nw)},s{sp})" for t, nw, sp in res[:4]), flush=True)
+        print(f"M={M:3d} {name:8s} [{N},{K}] lib {t_lib:6.2f}us ({gb / t_lib:5.0f} GB/s) | auto {t_auto:6.2f}us ({gb / t_auto:5.0f} GB/s) | best " + "  ".join(f"{t:6.2f}us({'st8' if nw == 2 else ('st16' if nw == 3 else 'w' + str(nw))},s{sp})" for t, nw, sp in res[:4]), flush=True)
         del ws
     print(f"M={M}: per-layer GEMM time lib {tot_lib:.1f}us, auto {tot_auto:.1f}us, best-of {tot_best:.1f}us")
