@@ -110,32 +110,86 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
     S* h_out = reinterpret_cast<S*>(h_out_);
     const S* dl_ = reinterpret_cast<const S*>(delta_);
     const S* nw = reinterpret_cast<const S*>(nw_);
+    constexpr int MAXC = 4;  // 16-byte chunks per thread held in registers: K <= 256 * 4 * kVec (8192 for the 16-bit dtypes)
+    if (nvec <= kGemvThreads * MAXC) {
+      // every global load of the prologue (residual row, delta row, norm weight) is requested before anything is used: the
+      // prologue is then ONE L2 round trip + the reduction, instead of load -> reduce -> load
+      uint4 wr[MAXC];
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      float ss = 0.f;
-      for (int v = tid; v < nvec; v += kGemvThreads) {
-        float a[V];
-        load16<T>(h + (int64_t)b * K + v * V, a);
-        if (dl_) {
-          float d[V];
-          load16<T>(dl_ + (int64_t)b * K + v * V, d);
-#pragma unroll
-          for (int e = 0; e < V; ++e) a[e] = Elem<T>::round(a[e] + d[e]);
-          // updated residual stream: written once, to a DIFFERENT buffer (other workgroups are still reading h_in)
-          if (blockIdx.x == 0) store16<T>(h_out + (int64_t)b * K + v * V, a);
-        }
-#pragma unroll
-        for (int e = 0; e < V; ++e) ss += a[e] * a[e];
-        store16<T>(xs + b * K + v * V, a);
+      for (int c = 0; c < MAXC; ++c) {
+        const int v = tid + c * kGemvThreads;
+        if (v < nvec) wr[c] = *reinterpret_cast<const uint4*>(nw + v * V);
       }
-      const float rstd = rsqrtf(block_sum<4>(ss, red) / (float)K + eps);
-      for (int v = tid; v < nvec; v += kGemvThreads) {
-        float a[V], w[V];
-        load16<T>(xs + b * K + v * V, a);
-        load16<T>(nw + v * V, w);
 #pragma unroll
-        for (int e = 0; e < V; ++e) a[e] = w[e] * Elem<T>::round(a[e] * rstd);
-        store16<T>(xs + b * K + v * V, a);
+      for (int b = 0; b < B; ++b) {
+        uint4 hr[MAXC], dr[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * kGemvThreads;
+          if (v < nvec) {
+            hr[c] = *reinterpret_cast<const uint4*>(h + (int64_t)b * K + v * V);
+            if (dl_) dr[c] = *reinterpret_cast<const uint4*>(dl_ + (int64_t)b * K + v * V);
+          }
+        }
+        float a[MAXC][V];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * kGemvThreads;
+          if (v < nvec) {
+            unpack16<T>(hr[c], a[c]);
+            if (dl_) {
+              float d[V];
+              unpack16<T>(dr[c], d);
+#pragma unroll
+              for (int e = 0; e < V; ++e) a[c][e] = Elem<T>::round(a[c][e] + d[e]);
+              // updated residual stream: written once, to a DIFFERENT buffer (other workgroups are still reading h_in)
+              if (blockIdx.x == 0) store16<T>(h_out + (int64_t)b * K + v * V, a[c]);
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) ss += a[c][e] * a[c][e];
+          }
+        }
+        const float rstd = rsqrtf(block_sum<4>(ss, red) / (float)K + eps);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * kGemvThreads;
+          if (v < nvec) {
+            float w[V];
+            unpack16<T>(wr[c], w);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[c][e] = w[e] * Elem<T>::round(a[c][e] * rstd);
+            store16<T>(xs + b * K + v * V, a[c]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float ss = 0.f;
+        for (int v = tid; v < nvec; v += kGemvThreads) {
+          float a[V];
+          load16<T>(h + (int64_t)b * K + v * V, a);
+          if (dl_) {
+            float d[V];
+            load16<T>(dl_ + (int64_t)b * K + v * V, d);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] = Elem<T>::round(a[e] + d[e]);
+            if (blockIdx.x == 0) store16<T>(h_out + (int64_t)b * K + v * V, a);
+          }
+#pragma unroll
+          for (int e = 0; e < V; ++e) ss += a[e] * a[e];
+          store16<T>(xs + b * K + v * V, a);
+        }
+        const float rstd = rsqrtf(block_sum<4>(ss, red) / (float)K + eps);
+        for (int v = tid; v < nvec; v += kGemvThreads) {
+          float a[V], w[V];
+          load16<T>(xs + b * K + v * V, a);
+          load16<T>(nw + v * V, w);
+#pragma unroll
+          for (int e = 0; e < V; ++e) a[e] = w[e] * Elem<T>::round(a[e] * rstd);
+          store16<T>(xs + b * K + v * V, a);
+        }
       }
     }
   } else if constexpr (MODE == 2) {  // SILUMUL: x_ = gate_up [B, 2K]
