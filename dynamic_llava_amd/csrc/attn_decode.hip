@@ -38,6 +38,21 @@ __device__ __forceinline__ void rope16(const float (&own)[Elem<T>::kVec], const 
     out[i] = Elem<T>::round(Elem<T>::round(own[i] * cs[i]) + Elem<T>::round((UPPER ? par[i] : -par[i]) * sn[i]));
 }
 
+// sum over the LPK lanes that share one key (8, 16 or 32 lanes, aligned): DPP inside a 16-lane row, one crossbar step beyond it
+template <int LPK>
+__device__ __forceinline__ float lpk_sum(float a) {
+  if constexpr (LPK == 8) return row8_sum(a);
+  else if constexpr (LPK == 16) return row16_sum(a);
+  else if constexpr (LPK == 32) {
+    a = row16_sum(a);
+    return a + __shfl_xor(a, 16, 64);
+  } else {
+#pragma unroll
+    for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
+    return a;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack_kv(const uint4& r, float (&f)[Elem<T>::kVec]) {
   if constexpr (Elem<T>::kVec == 4) {
@@ -169,8 +184,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
       float a = 0.f;
 #pragma unroll
       for (int i = 0; i < V; ++i) a += qv[i] * kx[i];
-#pragma unroll
-      for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
+      a = lpk_sum<LPK>(a);
       s[u] = ok[u] ? a * scale : -INFINITY;
     }
     float mn = m;
@@ -206,8 +220,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
       float a = 0.f;
 #pragma unroll
       for (int i = 0; i < V; ++i) a += qv[i] * kn[i];
-#pragma unroll
-      for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
+      a = lpk_sum<LPK>(a);
       const float sc_ = a * scale;
       const float mn = fmaxf(m, sc_);
       const float alpha = __expf(m - mn);

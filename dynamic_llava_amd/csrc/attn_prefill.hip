@@ -140,8 +140,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
         acc_s[nt][r] = s;
         mx = fmaxf(mx, s);
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = row16_max(mx);
       const float mn = fmaxf(m[r], mx);
       const float ms = mn == -INFINITY ? 0.f : mn;
       alpha[r] = __expf(m[r] - ms);
@@ -152,8 +151,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
         acc_s[nt][r] = p;
         rs += p;
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+      rs = row16_sum(rs);
       l[r] = l[r] * alpha[r] + rs;
       m[r] = mn;
     }
@@ -340,8 +338,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_pipe_kernel(const v
         acc_s[nt][r] = sv;
         mx = fmaxf(mx, sv);
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = row16_max(mx);
       const float mn = fmaxf(m[r], mx);
       const float ms = mn == -INFINITY ? 0.f : mn;
       alpha[r] = __expf(m[r] - ms);
@@ -352,8 +349,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_pipe_kernel(const v
         acc_s[nt][r] = p;
         rs += p;
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+      rs = row16_sum(rs);
       l[r] = l[r] * alpha[r] + rs;
       m[r] = mn;
     }

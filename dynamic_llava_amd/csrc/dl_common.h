@@ -164,14 +164,50 @@ __device__ __forceinline__ void store1(void* base, int64_t idx, float f) {
 // ---------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64)
 // ---------------------------------------------------------------------------------------------
+// Cross-lane reductions inside an aligned group of 16 lanes (one DPP "row") as VALU DPP modifiers -- a few cycles per step.
+// __shfl_xor compiles to ds_bpermute_b32 (the LDS crossbar: ~100 cycles of latency per step and a slot in the LDS pipe), which made
+// the 4-step reductions of the attention kernels (per-key dot products, softmax row max / sum) their longest dependency chains.
+// Steps: xor 1 and xor 2 as quad permutes, then the two mirrors: after the quad steps every lane of a quad holds the quad's value, so
+// mirroring within 8 and within 16 lanes pairs each quad / half with its partner.  All 16 lanes end up with bit-identical results
+// (fp add / max are commutative; the association differs from the xor butterfly by rounding only).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // row_half_mirror
+constexpr int kDppMirror = 0x140;       // row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<kDppXor1>(v);
+  v += dpp_f32<kDppXor2>(v);
+  v += dpp_f32<kDppHalfMirror>(v);
+  v += dpp_f32<kDppMirror>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<kDppXor1>(v));
+  v = fmaxf(v, dpp_f32<kDppXor2>(v));
+  v = fmaxf(v, dpp_f32<kDppHalfMirror>(v));
+  v = fmaxf(v, dpp_f32<kDppMirror>(v));
+  return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {  // aligned groups of 8 lanes
+  v += dpp_f32<kDppXor1>(v);
+  v += dpp_f32<kDppXor2>(v);
+  v += dpp_f32<kDppHalfMirror>(v);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 // sum over a block of NW waves; `red` is LDS scratch of >= NW floats; result broadcast to all threads.
