@@ -198,17 +198,18 @@ __device__ __forceinline__ float row8_sum(float v) {  // aligned groups of 8 lan
   v += dpp_f32<kDppHalfMirror>(v);
   return v;
 }
+// whole wave (all 64 lanes active): DPP inside the four 16-lane rows, then the four row results through v_readlane (scalar
+// registers, wave-uniform) -- no LDS crossbar at all.  Every lane gets the same value.
+__device__ __forceinline__ float wave_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  return (wave_lane(v, 0) + wave_lane(v, 16)) + (wave_lane(v, 32) + wave_lane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = row16_max(v);
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+  return fmaxf(fmaxf(wave_lane(v, 0), wave_lane(v, 16)), fmaxf(wave_lane(v, 32), wave_lane(v, 48)));
 }
 // sum over a block of NW waves; `red` is LDS scratch of >= NW floats; result broadcast to all threads.
 template <int NW>
