@@ -15,6 +15,17 @@
 
 namespace dl {
 
+// tools/gemv_timing.hip compiles this file with -DDL_GEMV_TIMING to stamp the phases of workgroup 0 (100 MHz wall clock).
+#ifdef DL_GEMV_TIMING
+__device__ long long g_gemv_stamps[8];
+#define DL_GSTAMP(i)                                                                                \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_gemv_stamps[i] = wall_clock64();                     \
+  } while (0)
+#else
+#define DL_GSTAMP(i)
+#endif
+
 constexpr int kGemvThreads = 256;
 constexpr int kGemvR = 2;       // neurons per wave per pass
 constexpr int kGemvMaxB = 8;
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S* xs = reinterpret_cast<S*>(smem);  // [B][K] in the model dtype
   __shared__ float red[4];
+  DL_GSTAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nvec = K / V;
 
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
         *reinterpret_cast<uint4*>(xs + b * K + v * V) = *reinterpret_cast<const uint4*>(x + (int64_t)b * x_rs + v * V);
   }
   __syncthreads();
+  DL_GSTAMP(1);  // x is in LDS
 
   // ---- stream the weights ----
   bool first = have_pre;
@@ -264,6 +277,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
         for (int r = 0; r < R; ++r) acc[r][b] = dot16<T>(raw[r], xv, acc[r][b]);
       }
     }
+    if (grp == (int)blockIdx.x) DL_GSTAMP(2);  // first neuron group streamed
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -286,10 +300,13 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
       }
     }
   }
+  DL_GSTAMP(3);
 }
 
 // tuning knob (dl_gemv_set_tuning): the workgroup cap
-static int g_gemv_grid_cap = 512;  // tools/bench_gemv.py sweep: 2 workgroups per CU is at or near the optimum for every decode shape
+// tools/bench_gemv.py sweep (after the prologue became one round trip): 4 workgroups per CU beat 2 on the add+norm shapes (qkv 19.6 ->
+// 17.3 us, gate|up 31.6 -> 29.2 us); the vocabulary projection (4000 neuron groups) likes 8 (45.2 -> 40.7 us); o / down have 512 groups
+static int g_gemv_grid_cap = 1024;
 
 template <typename T, int B, int MODE, bool PAIR, int R, int U>
 static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
@@ -298,7 +315,9 @@ static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, con
   const int n_out = PAIR ? N / 2 : N;
   const int per = 4 * (PAIR ? 1 : R);
   const int groups = (n_out + per - 1) / per;
-  const int grid = groups < g_gemv_grid_cap ? groups : g_gemv_grid_cap;
+  // B >= 2: the extra workgroups only add x-staging and VALU pressure (B=2: 3.23 -> 3.49 ms/step with the B=1 cap): half the cap
+  const int cap = B == 1 ? (groups >= 3584 ? 2 * g_gemv_grid_cap : g_gemv_grid_cap) : g_gemv_grid_cap / 2 > 0 ? g_gemv_grid_cap / 2 : 1;
+  const int grid = groups < cap ? groups : cap;
   auto kfn = gemv_kernel<T, B, MODE, PAIR, R, U>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;

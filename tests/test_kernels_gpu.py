@@ -382,7 +382,7 @@ def test_gemv_modes(ops, dtype, B, N, K):
             _close_ulp(act, ref, dtype, 4.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
             ops.gemv(wd, y, x=x.cuda())
             _close_ulp(y, gu_ref, dtype, 1.0, atol=1e-4 if dtype == torch.float32 else 2e-3)
-        ops.lib().dl_gemv_set_tuning(512, 0)
+        ops.lib().dl_gemv_set_tuning(1024, 0)
 
 
 def _vp_sd(cfg, seed, gain):
