@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
 
 // tuning knob (dl_gemv_set_tuning): the workgroup cap
 // tools/bench_gemv.py sweep (after the prologue became one round trip): 4 workgroups per CU beat 2 on the add+norm shapes (qkv 19.6 ->
-// 17.3 us, gate|up 31.6 -> 29.2 us); the vocabulary projection (4000 neuron groups) likes 8 (45.2 -> 40.7 us); o / down have 512 groups
+// 17.3 us, gate|up 31.6 -> 29.2 us, vocabulary projection 45.2 -> 40.9 us); o / down have only 512 neuron groups
 static int g_gemv_grid_cap = 1024;
 
 template <typename T, int B, int MODE, bool PAIR, int R, int U>
@@ -316,7 +316,7 @@ static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, con
   const int per = 4 * (PAIR ? 1 : R);
   const int groups = (n_out + per - 1) / per;
   // B >= 2: the extra workgroups only add x-staging and VALU pressure (B=2: 3.23 -> 3.49 ms/step with the B=1 cap): half the cap
-  const int cap = B == 1 ? (groups >= 3584 ? 2 * g_gemv_grid_cap : g_gemv_grid_cap) : g_gemv_grid_cap / 2 > 0 ? g_gemv_grid_cap / 2 : 1;
+  const int cap = B == 1 ? g_gemv_grid_cap : (g_gemv_grid_cap / 2 > 0 ? g_gemv_grid_cap / 2 : 1);
   const int grid = groups < cap ? groups : cap;
   auto kfn = gemv_kernel<T, B, MODE, PAIR, R, U>;
   if (smem > 64 * 1024) {
