@@ -213,22 +213,47 @@ __device__ __forceinline__ void tp_dense(const float* in, float* out, const void
   __syncthreads();
 }
 
-// ---- text predictor, stage 2: D -> D/2 -> D/4 -> 2 and the keep/evict decision.  grid (B) ----
-// (one workgroup has to pull all 328 KB of weights through one CU; requesting them all at kernel entry was measured no faster:
-// 11.7-27.8 us, 20.8 avg vs 18.8)
+// ---- text predictor, stage 2a: Linear(D -> D/2) + GELU spread over the chip.  grid (ceil(D/16), B): a wave owns 2 neurons ----
+// (as one workgroup per row this layer had to pull its 262 KB of weights through a single CU: 18.8 us for all of stage 2)
 template <typename T>
-__global__ __launch_bounds__(1024) void tp_stage2_kernel(const float* __restrict__ h1, const void* w3, const void* b3, const void* w5,
-                                                         const void* b5, const void* w7, const void* b7, float* __restrict__ logits,
-                                                         int32_t* __restrict__ decision, int D) {
-  extern __shared__ float sm[];  // [D] + [D/2] + [D/4] + [2]
-  float* a0 = sm;
-  float* a1 = a0 + D;
+__global__ __launch_bounds__(256) void tp_stage2a_kernel(const float* __restrict__ h1, const void* __restrict__ w3, const void* __restrict__ b3,
+                                                          float* __restrict__ a1, int D) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int N3 = D / 2, nvec = D / V;
+  const int nb = blockIdx.x * 8 + wid * 2;
+  float acc[2] = {0.f, 0.f};
+  for (int v = lane; v < nvec; v += 64) {
+    float wv[2][V], xv[V];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) load16<T>(reinterpret_cast<const S*>(w3) + (int64_t)(nb + j < N3 ? nb + j : N3 - 1) * D + v * V, wv[j]);
+#pragma unroll
+    for (int e = 0; e < V; ++e) xv[e] = h1[(int64_t)b * D + v * V + e];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[j] = fmaf(wv[j][e], xv[e], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float a = wave_sum(acc[j]);
+    const int n = nb + j;
+    if (lane == 0 && n < N3) a1[(int64_t)b * N3 + n] = Elem<T>::round(gelu_erf(Elem<T>::round(a + load1<T>(b3, n))));
+  }
+}
+
+// ---- text predictor, stage 2b: D/2 -> D/4 -> 2 and the keep/evict decision.  grid (B) ----
+template <typename T>
+__global__ __launch_bounds__(512) void tp_stage2b_kernel(const float* __restrict__ a1g, const void* w5, const void* b5, const void* w7,
+                                                          const void* b7, float* __restrict__ logits, int32_t* __restrict__ decision, int D) {
+  extern __shared__ float sm[];  // [D/2] + [D/4] + [2]
+  float* a1 = sm;
   float* a2 = a1 + D / 2;
   float* a3 = a2 + D / 4;
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < D; i += blockDim.x) a0[i] = h1[(int64_t)b * D + i];
+  for (int i = threadIdx.x; i < D / 2; i += blockDim.x) a1[i] = a1g[(int64_t)b * (D / 2) + i];
   __syncthreads();
-  tp_dense<T>(a0, a1, w3, b3, D, D / 2, true);
   tp_dense<T>(a1, a2, w5, b5, D / 2, D / 4, true);
   tp_dense<T>(a2, a3, w7, b7, D / 4, 2, false);
   if (threadIdx.x == 0) {
@@ -421,6 +446,10 @@ extern "C" int dl_vision_predictor(const void* hidden, const int32_t* cu_seqlens
   return DL_OK;
 }
 
+extern "C" int64_t dl_text_predictor_workspace_bytes(int B, int d_model) {
+  return B > 0 && d_model > 0 ? (int64_t)B * (d_model + d_model / 2) * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, int d_model, const dl_tp_weights* w,
                                         void* workspace, float* logits_out, int32_t* decision, int dtype, void* stream) {
   DL_REQUIRE(x && w && workspace && decision, "dl_text_predictor_decide: NULL pointer");
@@ -433,8 +462,10 @@ extern "C" int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int
     DL_REQUIRE(x_row_stride % Elem<T>::kVec == 0 && H % Elem<T>::kVec == 0, "dl_text_predictor_decide: H / row stride must be multiples of %d", Elem<T>::kVec);
     hipLaunchKernelGGL((tp_stage1_kernel<T>), dim3((unsigned)((D + 7) / 8), (unsigned)B), dim3(256), (size_t)H * sizeof(float), st, x,
                        x_row_stride, w->ln_w, w->ln_b, w->l1_w, w->l1_b, h1, H, D);
-    hipLaunchKernelGGL((tp_stage2_kernel<T>), dim3((unsigned)B), dim3(1024), (size_t)(D + D / 2 + D / 4 + 2) * sizeof(float), st, h1,
-                       w->l3_w, w->l3_b, w->l5_w, w->l5_b, w->l7_w, w->l7_b, logits_out, decision, D);
+    float* a1 = h1 + (size_t)B * D;
+    hipLaunchKernelGGL((tp_stage2a_kernel<T>), dim3((unsigned)((D / 2 + 7) / 8), (unsigned)B), dim3(256), 0, st, h1, w->l3_w, w->l3_b, a1, D);
+    hipLaunchKernelGGL((tp_stage2b_kernel<T>), dim3((unsigned)B), dim3(512), (size_t)(D / 2 + D / 4 + 2) * sizeof(float), st, a1, w->l5_w,
+                       w->l5_b, w->l7_w, w->l7_b, logits_out, decision, D);
   });
   DL_CHECK_LAUNCH("dl_text_predictor_decide");
   return DL_OK;

@@ -78,6 +78,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(VpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     ),
     "dl_text_predictor_decide": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, POINTER(TpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dl_text_predictor_workspace_bytes": (c_int64, [c_int, c_int]),
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv_set_tuning": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -359,11 +360,16 @@ def vision_predictor(hidden, cu_seqlens, img_start, n_img, weights: VpWeights, d
     return logits, score
 
 
+def text_predictor_workspace(B, d_model, device):
+    return torch.empty(max(int(lib().dl_text_predictor_workspace_bytes(int(B), int(d_model))) // 4, 1), dtype=torch.float32, device=device)
+
+
 def text_predictor_decide(x, weights: TpWeights, d_model, workspace, logits_out, decision):
     """x [B,H] (row stride x.stride(0)) -> decision int32 [B] (1 = keep this token's KV), logits fp32 [B,2]."""
     _dev(x, workspace, decision)
     assert x.stride(1) == 1 and decision.dtype == torch.int32
     B, H = x.shape
+    assert workspace.dtype == torch.float32 and workspace.numel() * 4 >= lib().dl_text_predictor_workspace_bytes(B, d_model), "workspace too small (text_predictor_workspace)"
     _check(
         lib().dl_text_predictor_decide(_p(x), x.stride(0), B, H, d_model, ctypes.byref(weights), _p(workspace), _p(logits_out), _p(decision), dtype_code(x.dtype), _stream()),
         "dl_text_predictor_decide",

@@ -193,7 +193,7 @@ class TextPredictor(nn.Module):
         shp = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         B = x2.shape[0]
-        ws = torch.empty(B * self.d_model, dtype=torch.float32, device=x.device)
+        ws = ops.text_predictor_workspace(B, self.d_model, x.device)
         lg = torch.empty((B, 2), dtype=torch.float32, device=x.device)
         dec = torch.empty(B, dtype=torch.int32, device=x.device)
         self.decide(x2, ws, lg, dec)
@@ -384,7 +384,7 @@ class _DecodeState:
         self.finished = torch.zeros(B, dtype=torch.int32, device=device)
         self.decision = torch.ones(B, dtype=torch.int32, device=device)
         self.tp_logits = torch.zeros((B, 2), dtype=torch.float32, device=device)
-        self.tp_ws = torch.empty(B * cfg.sparse_config["d_model"], dtype=torch.float32, device=device)
+        self.tp_ws = ops.text_predictor_workspace(B, cfg.sparse_config["d_model"], device)
         self.tp_x = torch.empty((B, H), dtype=dtype, device=device)  # snapshot of the hidden state entering layer `sparse_layer`
         self.tp_stream = torch.cuda.Stream(device=device)  # the predictor runs beside layers >= sparse_layer (graph fork/join)
         self.cu = torch.arange(0, B + 1, dtype=torch.int32, device=device)
@@ -695,7 +695,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     tp = self.model.instruct_score_predictor
                     dec = torch.empty(n_span, dtype=torch.int32, device=dev)
                     lg = torch.empty((n_span, 2), dtype=torch.float32, device=dev)
-                    tp.decide(h[li0 : li1 - 1], torch.empty(n_span * tp.d_model, dtype=torch.float32, device=dev), lg, dec)
+                    tp.decide(h[li0 : li1 - 1], ops.text_predictor_workspace(n_span, tp.d_model, dev), lg, dec)
                     keep_rel = torch.nonzero(dec).flatten()
                     idx = torch.cat([torch.arange(0, li0, device=dev), keep_rel + li0, torch.arange(li1 - 1, total, device=dev)])
                     if pos is None:
@@ -726,7 +726,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     rows = (torch.tensor(cu_list[:-1], device=dev)[:, None] + ai + torch.arange(n_span, device=dev)[None, :]).reshape(-1)
                     dec = torch.empty(B * n_span, dtype=torch.int32, device=dev)
                     lg = torch.empty((B * n_span, 2), dtype=torch.float32, device=dev)
-                    tp.decide(h.index_select(0, rows), torch.empty(B * n_span * tp.d_model, dtype=torch.float32, device=dev), lg, dec)
+                    tp.decide(h.index_select(0, rows), ops.text_predictor_workspace(B * n_span, tp.d_model, dev), lg, dec)
                     num_keep = int(dec.view(B, n_span).sum(dim=1).max().item())
                     if num_keep > 0:
                         keep = ops.topk_select(lg[:, 0].to(dt).view(B, n_span).contiguous(), num_keep)
@@ -1060,7 +1060,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 tp = self.model.instruct_score_predictor
                 dec = torch.empty(total, dtype=torch.int32, device=dev)
                 lg = torch.empty((total, 2), dtype=torch.float32, device=dev)
-                tp.decide(h, torch.empty(total * tp.d_model, dtype=torch.float32, device=dev), lg, dec)
+                tp.decide(h, ops.text_predictor_workspace(total, tp.d_model, dev), lg, dec)
                 dec = dec.view(B, T)
                 dec[:, -1] = 1  # DML:2521
                 keep_idx = [torch.nonzero(dec[b]).flatten() for b in range(B)]

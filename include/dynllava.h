@@ -168,10 +168,13 @@ int dl_vision_predictor(const void* hidden, const int32_t* cu_seqlens, const int
 
 /* ---- F6: TextPredictor.forward DML:1385-1387 + decision DML:2388-2391.
  * x [B,H] (hidden state entering layer `sparse_layer`); logits_out [B,2] float (may be NULL);
- * decision[b] = logit0 > logit1 (strict, raw logits).  workspace: B*d_model floats. */
+ * decision[b] = logit0 > logit1 (strict, raw logits).  workspace: dl_text_predictor_workspace_bytes(B, d_model)
+ * (1.5*B*d_model floats).  Three launches: LN + Linear(H -> d) over d/8 workgroups, Linear(d -> d/2) over d/16 workgroups, the
+ * d/2 -> d/4 -> 2 tail in one workgroup per row. */
 typedef struct dl_tp_weights {
   const void *ln_w, *ln_b, *l1_w, *l1_b, *l3_w, *l3_b, *l5_w, *l5_b, *l7_w, *l7_b; /* output_mlp.0/1/3/5/7 */
 } dl_tp_weights;
+int64_t dl_text_predictor_workspace_bytes(int B, int d_model);
 int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, int d_model, const dl_tp_weights* w,
                              void* workspace, float* logits_out, int32_t* decision, int dtype, void* stream);
 

@@ -443,7 +443,7 @@ def test_text_predictor_vs_oracle(ops, dtype, H, D, B):
     tp = TextPredictor(H, D)
     tp.load_state_dict({k[len("model.output_text_score_predictor.") :]: v for k, v in sd.items() if "output_text" in k})
     tp = tp.to(device="cuda", dtype=dtype)
-    ws = torch.empty(B * D, dtype=torch.float32, device="cuda")
+    ws = ops.text_predictor_workspace(B, D, "cuda")
     lg = torch.empty(B, 2, dtype=torch.float32, device="cuda")
     dec = torch.empty(B, dtype=torch.int32, device="cuda")
     tp.decide(x.cuda(), ws, lg, dec)
