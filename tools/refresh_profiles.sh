@@ -5,15 +5,16 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 R=${1:-r01}
-mkdir -p gpurun_out
+RAW=/tmp/dl_prof_raw   # raw rocprofv3 databases stay off gpurun_out/ (64 MiB merge limit): only the summaries go there
+rm -rf "$RAW"; mkdir -p gpurun_out "$RAW"
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ref-gpu > gpurun_out/bench_prof.json 2>/dev/null
-python tools/prof_summary.py "$(find gpurun_out/prof_bench -name '*.db' | head -1)" 45 > gpurun_out/kernel_stats.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o p -- python tools/pmc_probe.py > gpurun_out/pmc_fetch.log 2>/dev/null
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o p -- python tools/pmc_probe.py > gpurun_out/pmc_write.log 2>/dev/null
-python tools/pmc_report.py "$(find gpurun_out/pmc_fetch -name '*.db' | head -1)" "$(find gpurun_out/pmc_write -name '*.db' | head -1)" gpurun_out/pmc_fetch.log > gpurun_out/pmc_report.txt
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_mfma -o m -- python tools/prefill_kernels.py > /dev/null 2>&1
-python tools/mfma_report.py "$(find gpurun_out/pmc_mfma -name '*.db' | head -1)" > gpurun_out/mfma_report.txt
+rocprofv3 --kernel-trace --stats -d $RAW/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ref-gpu > gpurun_out/bench_prof.json 2>/dev/null
+python tools/prof_summary.py "$(find $RAW/prof_bench -name '*.db' | head -1)" 45 > gpurun_out/kernel_stats.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $RAW/pmc_fetch -o p -- python tools/pmc_probe.py > gpurun_out/pmc_fetch.log 2>/dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $RAW/pmc_write -o p -- python tools/pmc_probe.py > gpurun_out/pmc_write.log 2>/dev/null
+python tools/pmc_report.py "$(find $RAW/pmc_fetch -name '*.db' | head -1)" "$(find $RAW/pmc_write -name '*.db' | head -1)" gpurun_out/pmc_fetch.log > gpurun_out/pmc_report.txt
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $RAW/pmc_mfma -o m -- python tools/prefill_kernels.py > /dev/null 2>&1
+python tools/mfma_report.py "$(find $RAW/pmc_mfma -name '*.db' | head -1)" > gpurun_out/mfma_report.txt
 # then, back in the development container (gpurun merges gpurun_out/):
 #   cp gpurun_out/bench_default.json profiles/${R}_bench_b1.json; cp gpurun_out/kernel_stats.txt profiles/${R}_bench_kernel_stats.txt
 #   grep -v '^JSON' gpurun_out/pmc_report.txt > profiles/${R}_pmc_traffic.txt; grep '^JSON' gpurun_out/pmc_report.txt | sed 's/^JSON //' > profiles/${R}_pmc_traffic.json
