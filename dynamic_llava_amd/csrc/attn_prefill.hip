@@ -29,9 +29,10 @@ __device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b,
 
 constexpr int kBN = 64, kPad = 8;
 
+// BN keys per K/V tile (64; 128 halves the tile count of the head_dim-64 towers).
 // NW waves per workgroup, 16 query rows per wave (BM = 16 * NW): small prompts use fewer waves per workgroup so that the
 // grid still covers the chip (T=170, 32 heads: NW=4 -> 96 workgroups, NW=1 -> 352).
-template <typename T, int D, bool CAUSAL, int NW>
+template <typename T, int D, bool CAUSAL, int NW, int BN>
 __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
                                                                  const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
                                                                  void* __restrict__ out_, int64_t out_rs,
@@ -40,13 +41,13 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
   using S = uint16_t;
   constexpr int KS = D / 32;   // MFMA k-steps over the head dim
   constexpr int DT = D / 16;   // 16-wide output column tiles
-  constexpr int NT = kBN / 16; // 16-key tiles per KV tile
+  constexpr int NT = BN / 16; // 16-key tiles per KV tile
   constexpr int LDK = D + kPad;
-  constexpr int LDV = kBN + kPad;
-  constexpr int LDP = kBN + kPad;
+  constexpr int LDV = BN + kPad;
+  constexpr int LDP = BN + kPad;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  S* Ks = reinterpret_cast<S*>(smem);   // [kBN][LDK]
-  S* Vt = Ks + kBN * LDK;               // [D][LDV]
+  S* Ks = reinterpret_cast<S*>(smem);   // [BN][LDK]
+  S* Vt = Ks + BN * LDK;               // [D][LDV]
   S* Ps = Vt + D * LDV;                 // [NW][16][LDP]
   constexpr int kBM = 16 * NW;
   constexpr int NT_ = NW * 64;
@@ -91,13 +92,13 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
   }
   S* Pw = Ps + w * 16 * LDP;
 
-  const int n_tiles = CAUSAL ? min((Lk + kBN - 1) / kBN, (q0 + kBM - 1 + off) / kBN + 1) : (Lk + kBN - 1) / kBN;
+  const int n_tiles = CAUSAL ? min((Lk + BN - 1) / BN, (q0 + kBM - 1 + off) / BN + 1) : (Lk + BN - 1) / BN;
   for (int jt = 0; jt < n_tiles; ++jt) {
-    const int key0 = jt * kBN;
+    const int key0 = jt * BN;
     // ---- stage K (row-major) and V (transposed) tiles ----
     constexpr int CPR = D / 8;  // 16-byte chunks per row
 #pragma unroll
-    for (int it = 0; it < (kBN * CPR) / NT_; ++it) {
+    for (int it = 0; it < (BN * CPR) / NT_; ++it) {
       const int idx = it * NT_ + tid;
       const int key = idx / CPR, ch = idx % CPR;
       uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
     __syncthreads();
     // ---- O += P V ----
 #pragma unroll
-    for (int ks = 0; ks < kBN / 32; ++ks) {
+    for (int ks = 0; ks < BN / 32; ++ks) {
       const uint4 pf = *reinterpret_cast<const uint4*>(Pw + lr * LDP + ks * 32 + lg * 8);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -460,6 +461,30 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
   // for the second buffer)
   bool pipe = max_seqlen > 256 && D == 128;
   if (const char* e = getenv("DL_PF_PIPE")) pipe = atoi(e) != 0;  // tuning experiments only
+  // K/V tile size of the plain kernel: 128 keys for the head_dim-64 towers (CLIP T=577: 27.3 -> 22 us per layer), else 64.  (One 192-key
+  // tile for the T=170 decoder rows was no faster at B=1 -- 15.4 vs 15.1 us -- and 2x slower at B=8: 116 KB of LDS, one workgroup per CU.)
+  const int bn = (D == 64 && max_seqlen > 128) ? 128 : 64;
+#define DL_LAUNCH_PLAIN_BN(NWV, CAUS, BNV)                                                                                               \
+  {                                                                                                                                      \
+    const size_t smem = (size_t)(BNV * (D + kPad) + D * (BNV + kPad) + NWV * 16 * (BNV + kPad)) * 2;                                     \
+    auto kfn = attn_prefill_mfma_kernel<T, D, CAUS, NWV, BNV>;                                                                           \
+    static bool attr_set = false;                                                                                                        \
+    if (!attr_set && smem > 64 * 1024) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);             \
+      attr_set = true;                                                                                                                   \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL(kfn, grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale, kv_len, kv_sb, kv_sh);   \
+  }
+#define DL_LAUNCH_PLAIN(NWV, CAUS)                                                                                                       \
+  {                                                                                                                                      \
+    bool done = false;                                                                                                                   \
+    if constexpr (D == 64 && NWV == 4) {                                                                                                 \
+      if (bn == 128) {                                                                                                                   \
+        DL_LAUNCH_PLAIN_BN(4, CAUS, 128) done = true;                                                                                    \
+      }                                                                                                                                  \
+    }                                                                                                                                    \
+    if (!done) DL_LAUNCH_PLAIN_BN(NWV, CAUS, 64)                                                                                         \
+  }
 #define DL_LAUNCH_PF(NWV, CAUS)                                                                                                          \
   {                                                                                                                                      \
     const dim3 grid((unsigned)((max_seqlen + 16 * NWV - 1) / (16 * NWV)), (unsigned)n_heads, (unsigned)B);                              \
@@ -473,9 +498,7 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
       }                                                                                                                                  \
       hipLaunchKernelGGL(kfn, grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale, kv_len, kv_sb, kv_sh); \
     } else {                                                                                                                             \
-      const size_t smem = (size_t)(kBN * (D + kPad) + D * (kBN + kPad) + NWV * 16 * (kBN + kPad)) * 2;                                   \
-      hipLaunchKernelGGL((attn_prefill_mfma_kernel<T, D, CAUS, NWV>), grid, dim3(NWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, \
-                         cu, n_rep, scale, kv_len, kv_sb, kv_sh);                                                                        \
+      DL_LAUNCH_PLAIN(NWV, CAUS)                                                                                                         \
     }                                                                                                                                    \
   }
   if (causal) {
@@ -484,6 +507,8 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
     if (nw == 4) DL_LAUNCH_PF(4, false) else if (nw == 2) DL_LAUNCH_PF(2, false) else DL_LAUNCH_PF(1, false)
   }
 #undef DL_LAUNCH_PF
+#undef DL_LAUNCH_PLAIN
+#undef DL_LAUNCH_PLAIN_BN
 }
 
 }  // namespace dl
