@@ -29,6 +29,18 @@ __device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b,
 
 constexpr int kBN = 64, kPad = 8;
 
+// tools/pf_timing.hip compiles this file with -DDL_PF_TIMING to stamp the phases of the LAST query tile of head 0 (100 MHz wall clock).
+#ifdef DL_PF_TIMING
+__device__ long long g_pf_stamps[16];
+#define DL_PSTAMP(i)                                                                                          \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_pf_stamps[i] = wall_clock64(); \
+  } while (0)
+#else
+#define DL_PSTAMP(i)
+#endif
+
 // BN keys per K/V tile (64; 128 halves the tile count of the head_dim-64 towers).
 // NW waves per workgroup, 16 query rows per wave (BM = 16 * NW): small prompts use fewer waves per workgroup so that the
 // grid still covers the chip (T=170, 32 heads: NW=4 -> 96 workgroups, NW=1 -> 352).
@@ -52,6 +64,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
   constexpr int kBM = 16 * NW;
   constexpr int NT_ = NW * 64;
 
+  DL_PSTAMP(0);
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tok0 = cu[b];
   const int L = cu[b + 1] - tok0;
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
       }
     }
     __syncthreads();
+    if (jt == 0) DL_PSTAMP(1);  // Q fragments + first K/V tile staged
 
     // ---- S = Q K^T ----
     f32x4_t acc_s[NT];
@@ -127,6 +141,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
         acc_s[nt] = mfma16<T>(qf[ks], kf, acc_s[nt]);
       }
     }
+    if (jt == 0) DL_PSTAMP(2);  // S done
     // ---- online softmax on the C layout: row = lg*4 + r, col = nt*16 + lr ----
     float alpha[4];
 #pragma unroll
@@ -160,12 +175,14 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha[r];
+    if (jt == 0) DL_PSTAMP(3);  // softmax done
     // ---- P (C layout) -> LDS -> A layout ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Pw[(lg * 4 + r) * LDP + nt * 16 + lr] = Elem<T>::from_f(acc_s[nt][r]);
     __syncthreads();
+    if (jt == 0) DL_PSTAMP(4);  // P in LDS (barrier)
     // ---- O += P V ----
 #pragma unroll
     for (int ks = 0; ks < BN / 32; ++ks) {
@@ -177,6 +194,8 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
       }
     }
     __syncthreads();
+    if (jt == 0) DL_PSTAMP(5);  // PV done, tile 0 complete
+    if (jt == n_tiles - 1) DL_PSTAMP(6);  // all tiles
   }
   // ---- epilogue ----
   S* ob = reinterpret_cast<S*>(out_) + (int64_t)tok0 * out_rs + (int64_t)h * D;
@@ -189,6 +208,7 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_kernel(const void* 
       for (int dt = 0; dt < DT; ++dt) ob[(int64_t)qi * out_rs + dt * 16 + lr] = Elem<T>::from_f(acc_o[dt][r] * inv);
     }
   }
+  DL_PSTAMP(7);
 }
 
 // ---- software-pipelined variant for rows that span many K/V tiles (max_seqlen > 256).
