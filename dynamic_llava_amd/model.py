@@ -617,6 +617,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         dev = self.device
         B = len(lens)
         vision_on = bool(sc["use_vision_predictor"]) and indices is not None and all(i is not None for i in indices) and len(indices) == B
+        vision_on = vision_on and sc["sparse_layer"] < cfg.num_hidden_layers  # the layer loop never reaches the sparsification point otherwise (DML:1826)
         n_img = k = 0
         if vision_on:
             n_img = indices[0]["image"][1] - indices[0]["image"][0]

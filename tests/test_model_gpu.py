@@ -431,3 +431,24 @@ def test_clip_tower_packed_path_matches_eager_module(dtype):
     # unused last layer is really skipped, CLS token dropped
     t.select_feature = "cls_patch"
     assert t(x).shape == (2, 577, 1024)
+
+
+def test_sparse_layer_beyond_depth_is_dense():
+    """A model shallower than `sparse_layer` never reaches the sparsification point (DML:1826 sits inside the layer loop): nothing is
+    dropped, logits cover all N positions and equal the dense oracle."""
+    dtype = torch.float32
+    cfg = fx.tiny_config()
+    cfg.num_hidden_layers = 2  # sparse_layer = 2 is never reached
+    sd = fx.make_state_dict(cfg, seed=3, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1, dtype=dtype)
+    model = _build(cfg, sd, clip, dtype)
+    ids = fx.make_prompt(cfg, 5, 7, seed=1)[None]
+    imgs = fx.make_images(cfg, 1, seed=2)
+    out = model(ids.cuda(), images=imgs.cuda().to(dtype))
+    n = ids.shape[1] - 1 + fx.n_image_tokens(cfg)
+    assert out.logits.shape[1] == n and out.past_key_values[0][-1][0].shape[-2] == n
+    o = Oracle(cfg, sd, dtype, clip=clip)
+    with torch.no_grad():
+        l_ref, _ = o.forward(ids, images=imgs)
+    assert l_ref.shape == out.logits.shape
+    assert float((out.logits.cpu() - l_ref).abs().max()) < 1e-3
