@@ -452,3 +452,37 @@ def test_sparse_layer_beyond_depth_is_dense():
         l_ref, _ = o.forward(ids, images=imgs)
     assert l_ref.shape == out.logits.shape
     assert float((out.logits.cpu() - l_ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("sparse_layer", [1, 3])  # 0 is not a valid reference setting: DML:1026-1043 reads the cache of layer sparse_layer-1
+def test_other_sparse_layers_vs_oracle(sparse_layer):
+    """`sparse_config["sparse_layer"]` is a runtime toggle of the reference (BIMG:63-65 flips such keys between runs): the vision block,
+    the text-predictor decision and the two KV-length groups follow it.  Prefill + 6 teacher-forced decode steps against the oracle."""
+    dtype = torch.float32
+    cfg = fx.tiny_config()
+    cfg.sparse_config = dict(cfg.sparse_config, sparse_layer=sparse_layer)
+    sd = fx.make_state_dict(cfg, seed=4, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1, dtype=dtype)
+    model = _build(cfg, sd, clip, dtype)
+    assert model.config.sparse_config["sparse_layer"] == sparse_layer
+    ids = fx.make_prompt(cfg, 5, 9, seed=2)[None]
+    imgs = fx.make_images(cfg, 1, seed=3)
+    forced = fx.make_forced_tokens(cfg, 6, 1, seed=5)
+    o = Oracle(cfg, sd, dtype, clip=clip)
+    model.debug_records = {}
+    out = model(ids.cuda(), images=imgs.cuda().to(dtype))
+    with torch.no_grad():
+        l_ref, p_ref = o.forward(ids, images=imgs)
+    assert out.logits.shape == l_ref.shape and float((out.logits.cpu() - l_ref).abs().max()) < 1e-3
+    assert torch.equal(model.debug_records["keep_index"].cpu(), o.records["keep_index"])
+    pkv = out.past_key_values
+    for j in range(6):
+        out = model(forced[j][:, None].cuda(), past_key_values=pkv)
+        pkv = out.past_key_values
+        with torch.no_grad():
+            l_ref, p_ref = o.forward(forced[j][:, None], past_key_values=p_ref)
+        assert float((out.logits.cpu() - l_ref).abs().max()) < 1e-3, f"step {j}"
+        assert int(model.debug_records["text_decision"][0]) == int(o.records["text_decision"][0, 0]), f"step {j}"
+        for layer in range(cfg.num_hidden_layers):
+            assert pkv[0][layer][0].shape[-2] == p_ref[0][layer][0].shape[-2], (j, layer)
+    model.debug_records = None
