@@ -303,6 +303,45 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
   DL_GSTAMP(3);
 }
 
+// ---- batch 1, plain prologue (o_proj, down_proj): x lives in REGISTERS ----
+// Every row a wave processes needs the same x chunks (lane + 64 c), so each lane loads its XB*8 chunks of x once, together with the first
+// weight chunks: no LDS staging, no barrier -- the prologue of the generic kernel (copy x to LDS, 3 us cold) disappears into the same
+// round trip as the first weights.  One row per wave, all of its chunks requested before the first dot product.
+template <typename T, int XB>
+__global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_kernel(const void* __restrict__ W_, int N, int K, const void* __restrict__ x_,
+                                                                     void* __restrict__ y_) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nvec = K / V;
+  const S* W = reinterpret_cast<const S*>(W_);
+  const S* x = reinterpret_cast<const S*>(x_);
+  const int groups = (N + 3) / 4;
+  uint4 xr[XB * 8];
+#pragma unroll
+  for (int c = 0; c < XB * 8; ++c) {
+    const int v = lane + 64 * c;
+    xr[c] = v < nvec ? *reinterpret_cast<const uint4*>(x + (int64_t)v * V) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    int n = grp * 4 + wid;
+    const bool live = n < N;
+    n = live ? n : N - 1;
+    const S* wp = W + (int64_t)n * K;
+    uint4 w[XB * 8];
+#pragma unroll
+    for (int c = 0; c < XB * 8; ++c) {
+      const int v = lane + 64 * c;
+      w[c] = v < nvec ? ldg_nt(wp + (int64_t)v * V) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < XB * 8; ++c) acc = dot16<T>(w[c], xr[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0 && live) store1<T>(y_, n, acc);
+  }
+}
+
 // tuning knob (dl_gemv_set_tuning): the workgroup cap
 // tools/bench_gemv.py sweep (after the prologue became one round trip): 4 workgroups per CU beat 2 on the add+norm shapes (qkv 19.6 ->
 // 17.3 us, gate|up 31.6 -> 29.2 us, vocabulary projection 45.2 -> 40.9 us); o / down have only 512 neuron groups
@@ -341,8 +380,21 @@ static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, i
   // one load schedule (2 neurons x 4 chunks per wave in flight): the tools/bench_gemv.py sweep over (4x2), (2x8), (1x8), (4x4) found
   // nothing faster on any decode shape, and every extra schedule costs 72 kernel instantiations of compile time
   if (pair) return gemv_go<T, B, MODE, true, 2, 4>(DL_ARGS);
-  // batch 1, plain prologue (o_proj / down_proj: only 4096 output rows): one row x 8 chunks per wave doubles the neuron groups, so these
-  // launches also reach 4 workgroups per CU (o 7.70 -> 7.42 us, down 19.0 -> 18.3 us)
+  // batch 1, plain prologue (o_proj / down_proj), 16-bit dtypes: x in registers, no LDS / barrier (down 18.3 -> 17.1 us, decode step
+  // 2.709 -> 2.675 ms).  Otherwise one row x 8 chunks per wave, which doubles the neuron groups of these 4096-row projections so that
+  // they also reach 4 workgroups per CU (o 7.70 -> 7.42 us, down 19.0 -> 18.3 us).
+  if constexpr (B == 1 && MODE == 0 && Elem<T>::kVec == 8) {
+    if (K / 8 <= 64 * 24) {  // x fits the register file: 8 / 16 / 24 chunks per lane (K <= 12288)
+      const int groups = (N + 3) / 4;
+      const int cap = g_gemv_grid_cap / 2 > 0 ? g_gemv_grid_cap / 2 : 1;  // two rows per wave reuse the x registers
+      const int grid = groups < cap ? groups : cap;
+      const int xb = (K / 8 + 511) / 512;
+      if (xb <= 1) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 1>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      else if (xb == 2) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 2>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      else hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 3>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      return DL_OK;
+    }
+  }
   if constexpr (B == 1 && MODE == 0) return gemv_go<T, B, MODE, false, 1, 8>(DL_ARGS);
   return gemv_go<T, B, MODE, false, 2, 4>(DL_ARGS);
 #undef DL_ARGS

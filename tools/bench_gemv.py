@@ -48,7 +48,7 @@ for name, N, K, mode in SHAPES:
     nw = torch.ones(K, device=dev, dtype=dt)
     best = None
     for variant in (0,):
-        for cap in (256, 512, 768, 1024, 1536, 2048, 4096):
+        for cap in (512, 1024, 2048, 4096):
             ops.lib().dl_gemv_set_tuning(cap, variant)
             if (mode & 3) == ops.GEMV_ADDNORM:
                 fns = [lambda w=w: ops.gemv(w, y, mode=mode, h_in=h, h_out=h2, delta=dl, norm_w=nw, eps=1e-5) for w in ws]
