@@ -1104,10 +1104,56 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, eos_first, self._pad, None, None, None)
 
     @torch.no_grad()
+    def _generate_sample(self, inputs, images, **kwargs):
+        """do_sample=True: temperature / top_k / top_p sampling as HF's logits warpers define them (TemperatureLogitsWarper,
+        TopKLogitsWarper, TopPLogitsWarper: the smallest set of most probable tokens whose mass reaches top_p is kept), drawn with
+        torch's generator -- a plain loop over forward() (no hipGraph: this is the convenience path, the harness default is greedy).
+        Token streams cannot match HF's draw for draw (different RNG consumption); the distribution per step is the same."""
+        max_new = kwargs.get("max_new_tokens") or 20
+        temperature = float(kwargs.get("temperature", 1.0) or 1.0)
+        top_k = int(kwargs.get("top_k", 0) or 0)
+        top_p = kwargs.get("top_p")
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        pad = kwargs.get("pad_token_id", self.config.pad_token_id) or 0
+        gen = kwargs.get("generator")
+        out = self.forward(inputs.to(self.device), attention_mask=kwargs.get("attention_mask"), images=images, image_features=kwargs.get("image_features"))
+        cache = out.past_key_values
+        # last VALID position of every row: the returned logits are right-padded with zeros when rows differ in length, and the
+        # last layer's KV length is the (compacted) row length
+        last = cache[1][-1].to(self.device).long() - 1
+        logits = out.logits[torch.arange(out.logits.shape[0], device=self.device), last]
+        B = logits.shape[0]
+        finished = torch.zeros(B, dtype=torch.bool, device=self.device)
+        toks = []
+        for step in range(max_new):
+            z = logits.float() / temperature
+            if top_k > 0:
+                kth = torch.topk(z, min(top_k, z.shape[-1]), dim=-1).values[:, -1:]
+                z = z.masked_fill(z < kth, float("-inf"))
+            if top_p is not None and float(top_p) < 1.0:
+                sz, si = torch.sort(z, dim=-1, descending=False)
+                cum = sz.softmax(dim=-1).cumsum(dim=-1)
+                remove = cum <= (1.0 - float(top_p))
+                remove[:, -1] = False  # always keep the most probable token
+                z = z.masked_fill(remove.scatter(1, si, remove), float("-inf"))
+            nxt = torch.multinomial(z.softmax(dim=-1), 1, generator=gen)[:, 0]
+            nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
+            toks.append(nxt)
+            if eos is not None:
+                finished = finished | (nxt == int(eos))
+                if bool(finished.all()):
+                    break
+            if step + 1 < max_new:
+                out = self.forward(nxt[:, None], past_key_values=cache)
+                cache = out.past_key_values
+                logits = out.logits[:, -1]
+        return torch.stack(toks, dim=1)
+
+    @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, **kwargs):
         """dynamic_llava_llama.py:117-152: greedy decoding; returns the NEW tokens only [B, T_new] (HF behaviour when
-        generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens, min_new_tokens, do_sample(False),
-        num_beams(1), use_cache(True), eos_token_id, pad_token_id, attention_mask, return_dict_in_generate,
+        generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens, min_new_tokens, do_sample (True: temperature /
+        top_k / top_p sampling through _generate_sample), num_beams(1), use_cache(True), eos_token_id, pad_token_id, attention_mask, return_dict_in_generate,
         image_features (pre-computed projector output, testing).
         Steady state (same prompt SHAPE as a previous call): the whole prefill -- CLIP, projector, embedding assembly,
         32 layers, first-token argmax -- is one hipGraph replay and every decode step is another; the host only copies
@@ -1115,8 +1161,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._check_ready()
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
-        if kwargs.get("do_sample", False):
-            raise NotImplementedError("sampling is not built; the eval harness uses temperature 0 / greedy (model_vqa_loader.py:162-175)")
+        if kwargs.get("do_sample", False):  # model_vqa_loader.py:162-175 passes do_sample = temperature > 0 (default 0: greedy)
+            return self._generate_sample(inputs, images, **kwargs)
         if kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is not built (harness default num_beams=1)")
         max_new = kwargs.get("max_new_tokens")

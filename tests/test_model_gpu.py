@@ -486,3 +486,27 @@ def test_other_sparse_layers_vs_oracle(sparse_layer):
         for layer in range(cfg.num_hidden_layers):
             assert pkv[0][layer][0].shape[-2] == p_ref[0][layer][0].shape[-2], (j, layer)
     model.debug_records = None
+
+
+def test_generate_sampling_path():
+    """generate(do_sample=True, temperature, top_p, top_k) -- what the harness passes when temperature > 0 (model_vqa_loader.py:162-175).
+    Draws cannot match HF's RNG; the warpers' semantics can be pinned: top_k=1 or a tiny top_p keep only the argmax, i.e. greedy."""
+    dtype = torch.float32
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1, dtype=dtype)
+    model = _build(cfg, sd, clip, dtype)
+    ids = torch.stack([fx.make_prompt(cfg, 5, 9, seed=2), fx.make_prompt(cfg, 5, 9, seed=3)])
+    imgs = fx.make_images(cfg, 2, seed=3).cuda()
+    greedy = model.generate(ids.cuda(), images=imgs, max_new_tokens=8, eos_token_id=None)
+    a = model.generate(ids.cuda(), images=imgs, max_new_tokens=8, eos_token_id=None, do_sample=True, temperature=0.7, top_k=1)
+    b = model.generate(ids.cuda(), images=imgs, max_new_tokens=8, eos_token_id=None, do_sample=True, temperature=1.3, top_p=1e-6)
+    assert torch.equal(a, greedy) and torch.equal(b, greedy)
+    g1 = torch.Generator(device="cuda").manual_seed(7)
+    g2 = torch.Generator(device="cuda").manual_seed(7)
+    c1 = model.generate(ids.cuda(), images=imgs, max_new_tokens=8, eos_token_id=None, do_sample=True, temperature=5.0, top_p=0.95, generator=g1)
+    c2 = model.generate(ids.cuda(), images=imgs, max_new_tokens=8, eos_token_id=None, do_sample=True, temperature=5.0, top_p=0.95, generator=g2)
+    assert c1.shape == (2, 8) and torch.equal(c1, c2), "same generator state -> same draws"
+    assert not torch.equal(c1, greedy), "a hot temperature on near-uniform random-init logits must leave the greedy path"
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.cuda(), images=imgs, max_new_tokens=2, num_beams=2)
