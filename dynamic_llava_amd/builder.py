@@ -81,7 +81,7 @@ def _load_checkpoint_tensors(model_path):
     if not files:
         raise FileNotFoundError(f"no *.safetensors / pytorch_model*.bin under {model_path}")
     for f in files:
-        yield from torch.load(f, map_location="cpu").items()
+        yield from torch.load(f, map_location="cpu", weights_only=True).items()
 
 
 @torch.no_grad()

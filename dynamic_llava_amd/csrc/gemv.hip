@@ -11,6 +11,8 @@
 // 64 lanes stride the K dimension in 16-byte chunks (one wave-instruction = 1 KiB of one weight row, fully
 // coalesced, non-temporal: every weight byte is used exactly once per step).  fp32 accumulate, 6-step wave
 // reduction, one rounding to the model dtype -- the same contract as the GEMM it replaces.
+#include <mutex>
+
 #include "dl_common.h"
 
 namespace dl {
@@ -342,31 +344,32 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_kernel(const void*
   }
 }
 
-// tuning knob (dl_gemv_set_tuning): the workgroup cap
+// workgroup cap (per call: `grid_cap` of dl_gemv, 0 = this default; no process-global state)
 // tools/bench_gemv.py sweep (after the prologue became one round trip): 4 workgroups per CU beat 2 on the add+norm shapes (qkv 19.6 ->
 // 17.3 us, gate|up 31.6 -> 29.2 us, vocabulary projection 45.2 -> 40.9 us); o / down have only 512 neuron groups
-static int g_gemv_grid_cap = 1024;
+constexpr int kGemvGridCap = 1024;
 
 template <typename T, int B, int MODE, bool PAIR, int R, int U>
 static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
-                   const void* nw, float eps, void* y, int64_t y_rs, hipStream_t st) {
+                   const void* nw, float eps, void* y, int64_t y_rs, int grid_cap, hipStream_t st) {
   const size_t smem = (size_t)B * K * Elem<T>::kBytes;
   const int n_out = PAIR ? N / 2 : N;
   const int per = 4 * (PAIR ? 1 : R);
   const int groups = (n_out + per - 1) / per;
   // B >= 2: the extra workgroups only add x-staging and VALU pressure (B=2: 3.23 -> 3.49 ms/step with the B=1 cap): half the cap
-  const int cap = B == 1 ? g_gemv_grid_cap : (g_gemv_grid_cap / 2 > 0 ? g_gemv_grid_cap / 2 : 1);
+  const int cap = B == 1 ? grid_cap : (grid_cap / 2 > 0 ? grid_cap / 2 : 1);
   const int grid = groups < cap ? groups : cap;
   auto kfn = gemv_kernel<T, B, MODE, PAIR, R, U>;
   if (smem > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
-        (void)hipGetLastError();  // do not leave a sticky error behind
-        set_error("dl_gemv: cannot raise the dynamic LDS limit to 152 KiB");
-        return DL_ERR_LAUNCH;
-      }
-      attr_set = true;
+    static std::once_flag once;  // one per kernel instantiation; concurrent host threads are fine
+    static bool attr_ok = false;
+    std::call_once(once, [&] {
+      attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess;
+      if (!attr_ok) (void)hipGetLastError();  // do not leave a sticky error behind
+    });
+    if (!attr_ok) {
+      set_error("dl_gemv: cannot raise the dynamic LDS limit to 152 KiB");
+      return DL_ERR_LAUNCH;
     }
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(kGemvThreads), smem, st, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs);
@@ -375,8 +378,8 @@ static int gemv_go(const void* W, int N, int K, const void* x, int64_t x_rs, con
 
 template <typename T, int B, int MODE>
 static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta,
-                        const void* nw, float eps, void* y, int64_t y_rs, hipStream_t st) {
-#define DL_ARGS W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st
+                        const void* nw, float eps, void* y, int64_t y_rs, int grid_cap, hipStream_t st) {
+#define DL_ARGS W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, grid_cap, st
   // one load schedule (2 neurons x 4 chunks per wave in flight): the tools/bench_gemv.py sweep over (4x2), (2x8), (1x8), (4x4) found
   // nothing faster on any decode shape, and every extra schedule costs 72 kernel instantiations of compile time
   if (pair) return gemv_go<T, B, MODE, true, 2, 4>(DL_ARGS);
@@ -386,7 +389,7 @@ static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, i
   if constexpr (B == 1 && MODE == 0 && Elem<T>::kVec == 8) {
     if (K / 8 <= 64 * 24) {  // x fits the register file: 8 / 16 / 24 chunks per lane (K <= 12288)
       const int groups = (N + 3) / 4;
-      const int cap = g_gemv_grid_cap / 2 > 0 ? g_gemv_grid_cap / 2 : 1;  // two rows per wave reuse the x registers
+      const int cap = grid_cap / 2 > 0 ? grid_cap / 2 : 1;  // two rows per wave reuse the x registers
       const int grid = groups < cap ? groups : cap;
       const int xb = (K / 8 + 511) / 512;
       if (xb <= 1) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 1>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
@@ -402,23 +405,17 @@ static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, i
 
 template <typename T, int B>
 static int gemv_launch(int mode, const void* W, int N, int K, const void* x, int64_t x_rs, const void* h, void* h_out, const void* delta, const void* nw,
-                       float eps, void* y, int64_t y_rs, hipStream_t st) {
+                       float eps, void* y, int64_t y_rs, int grid_cap, hipStream_t st) {
   const bool pair = (mode & DL_GEMV_OUT_SILU_PAIR) != 0;
   const int pro = mode & 3;
-  if (pro == DL_GEMV_ADDNORM) return gemv_variant<T, B, 1>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st);
-  if (pro == DL_GEMV_SILUMUL) return gemv_variant<T, B, 2>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st);
-  return gemv_variant<T, B, 0>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, st);
+  if (pro == DL_GEMV_ADDNORM) return gemv_variant<T, B, 1>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, grid_cap, st);
+  if (pro == DL_GEMV_SILUMUL) return gemv_variant<T, B, 2>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, grid_cap, st);
+  return gemv_variant<T, B, 0>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, grid_cap, st);
 }
 
 }  // namespace dl
 
 using namespace dl;
-
-extern "C" int dl_gemv_set_tuning(int grid_cap, int variant) {
-  DL_REQUIRE(grid_cap >= 1 && variant == 0, "dl_gemv_set_tuning: bad arguments (only load-schedule variant 0 is built)");
-  g_gemv_grid_cap = grid_cap;
-  return DL_OK;
-}
 
 __global__ void launch_probe_kernel() {}
 
@@ -436,10 +433,12 @@ extern "C" int dl_gemv_max_batch(int K, int dtype) {
 }
 
 extern "C" int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_stride, const void* h_in, void* h_out,
-                       const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, void* stream) {
+                       const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, int grid_cap,
+                       void* stream) {
   const void* h = h_in;
   DL_REQUIRE(W && y, "dl_gemv: NULL pointer");
-  DL_REQUIRE(N > 0 && K > 0 && B > 0, "dl_gemv: bad shape");
+  DL_REQUIRE(N > 0 && K > 0 && B > 0 && grid_cap >= 0, "dl_gemv: bad shape");
+  if (grid_cap == 0) grid_cap = kGemvGridCap;
   const int pro = mode & 3;
   DL_REQUIRE((mode & ~(3 | DL_GEMV_OUT_SILU_PAIR)) == 0 && pro <= DL_GEMV_SILUMUL, "dl_gemv: bad mode %d", mode);
   DL_REQUIRE(!(mode & DL_GEMV_OUT_SILU_PAIR) || N % 2 == 0, "dl_gemv: SILU_PAIR needs an even N");
@@ -451,14 +450,14 @@ extern "C" int dl_gemv(int mode, const void* W, int N, int K, const void* x, int
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(K % Elem<T>::kVec == 0 && (pro == DL_GEMV_ADDNORM || x_row_stride % Elem<T>::kVec == 0), "dl_gemv: K / strides must be multiples of %d", Elem<T>::kVec);
     switch (B) {
-      case 1: rc = gemv_launch<T, 1>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      case 2: rc = gemv_launch<T, 2>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      case 3: rc = gemv_launch<T, 3>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      case 4: rc = gemv_launch<T, 4>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      case 5: rc = gemv_launch<T, 5>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      case 6: rc = gemv_launch<T, 6>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      case 7: rc = gemv_launch<T, 7>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
-      default: rc = gemv_launch<T, 8>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, st); break;
+      case 1: rc = gemv_launch<T, 1>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      case 2: rc = gemv_launch<T, 2>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      case 3: rc = gemv_launch<T, 3>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      case 4: rc = gemv_launch<T, 4>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      case 5: rc = gemv_launch<T, 5>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      case 6: rc = gemv_launch<T, 6>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      case 7: rc = gemv_launch<T, 7>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
+      default: rc = gemv_launch<T, 8>(mode, W, N, K, x, x_row_stride, h, h_out, delta, norm_w, eps, y, y_row_stride, grid_cap, st); break;
     }
   });
   if (rc != DL_OK) return rc;

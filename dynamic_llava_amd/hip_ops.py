@@ -80,8 +80,7 @@ SIGNATURES = {
     "dl_text_predictor_decide": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, POINTER(TpWeights), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dl_text_predictor_workspace_bytes": (c_int64, [c_int, c_int]),
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
-    "dl_gemv_set_tuning": (c_int, [c_int, c_int]),
-    "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
     "dl_gemm_smallm_max_m": (c_int, []),
     "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
@@ -93,7 +92,7 @@ SIGNATURES = {
     "dl_quick_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     ),
 }
 
@@ -384,7 +383,7 @@ def gemv_max_batch(K, dtype):
     return int(lib().dl_gemv_max_batch(int(K), dtype_code(dtype)))
 
 
-def gemv(w, y, x=None, mode=GEMV_PLAIN, h_in=None, h_out=None, delta=None, norm_w=None, eps=0.0):
+def gemv(w, y, x=None, mode=GEMV_PLAIN, h_in=None, h_out=None, delta=None, norm_w=None, eps=0.0, grid_cap=0):
     """y[b,:] = W @ prologue(x)[b,:] (see include/dynllava.h).  w [N,K]; y [B,N] (row stride y.stride(0))."""
     _dev(w, y, x, h_in, h_out, delta, norm_w)
     assert w.is_contiguous() and y.stride(1) == 1
@@ -397,13 +396,13 @@ def gemv(w, y, x=None, mode=GEMV_PLAIN, h_in=None, h_out=None, delta=None, norm_
         assert x.stride(1) == 1 and x.shape[0] == B
         xs = x.stride(0)
     _check(
-        lib().dl_gemv(mode, _p(w), N, K, _p(x), xs, _p(h_in), _p(h_out), _p(delta), _p(norm_w), eps, _p(y), y.stride(0), B, dtype_code(w.dtype), _stream()),
+        lib().dl_gemv(mode, _p(w), N, K, _p(x), xs, _p(h_in), _p(h_out), _p(delta), _p(norm_w), eps, _p(y), y.stride(0), B, dtype_code(w.dtype), int(grid_cap), _stream()),
         "dl_gemv",
     )
     return y
 
 
-def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos_id=-1, pad_id=0, kv_len_full=None, kv_len_sparse=None, decision=None):
+def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos_id=-1, pad_id=0, kv_len_full=None, kv_len_sparse=None, decision=None, min_new_tokens=0):
     _dev(logits, next_ids)
     assert logits.dim() == 2 and logits.stride(1) == 1 and next_ids.dtype == torch.int64
     B, V = logits.shape
@@ -411,7 +410,7 @@ def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos
     _check(
         lib().dl_decode_advance(
             _p(logits), dtype_code(logits.dtype), logits.stride(0), V, B, _p(next_ids), _p(out_ids), out_cap, _p(step), _p(finished), int(eos_id), int(pad_id),
-            _p(kv_len_full), _p(kv_len_sparse), _p(decision), _stream(),
+            _p(kv_len_full), _p(kv_len_sparse), _p(decision), int(min_new_tokens), _stream(),
         ),
         "dl_decode_advance",
     )

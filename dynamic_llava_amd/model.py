@@ -538,7 +538,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             raise NotImplementedError("truncation to tokenizer_model_max_length (ARCH:493-506) is not built")
         if all(i is None for i in indices):
             indices = None
-        sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, tuple(text_src[:1] + text_src[-1:]), len(text_src))
+        sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, hash(tuple(text_src)), len(text_src))
         return dict(sig=sig, B=B, lens=lens, indices=indices, text_src=text_src, text_dst=text_dst, img_dst=img_dst, img_rows=img_rows, total=base, n_feat=n_feat)
 
     def _assemble(self, lay, dev_idx, input_ids, image_features):
@@ -815,7 +815,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and sc["sparse_layer"] < self.config.num_hidden_layers
             ops.decode_advance(
                 st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, cache.len_full, cache.len_sparse,
-                st.decision if use_tp else None,
+                st.decision if use_tp else None, min_new_tokens=getattr(self, "_min_new", 0),
             )
 
     def _decode_step_gemv(self, st: _DecodeState, cache: KVSlabCache):
@@ -927,7 +927,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
     def _run_decode_steps(self, st, cache, n_steps):
         """Enqueue n greedy steps (graph replay when enabled)."""
-        key = (cache.slab.data_ptr(), cache.t_cap, cache.sparse_cap, self._rope[0].data_ptr(), self._eos, self._pad, repr(self.config.sparse_config))
+        key = (cache.slab.data_ptr(), cache.t_cap, cache.sparse_cap, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0), repr(self.config.sparse_config))
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)
@@ -980,7 +980,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
             self._decode_step_kernels(st, cache, False)
-            use_tp = self.config.sparse_config["use_text_predictor"] and self.config.sparse_config["use_output_text_predictor"]
+            sc_ = self.config.sparse_config
+            use_tp = bool(sc_["use_text_predictor"] and sc_["use_output_text_predictor"]) and sc_["sparse_layer"] < self.config.num_hidden_layers
             cache.lens[0] += 1
             cache.lens[1] += st.decision if use_tp else 1
             cache.full_len_host = [n + 1 for n in cache.full_len_host]
@@ -1099,9 +1100,32 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     def _first_token(self, st, x_last, min_new):
         torch.matmul(x_last, self.lm_head.weight.t(), out=st.logits)
         self._prefill_logits_buf.copy_(st.logits)
-        # first token: argmax only (the prompt's KV lengths are already in place)
-        eos_first = self._eos if min_new <= 0 else -1
-        ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, eos_first, self._pad, None, None, None)
+        # first token: argmax only (the prompt's KV lengths are already in place); EOS is banned while step < min_new (HF semantics)
+        ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, None, None, None, min_new_tokens=min_new)
+
+    def _gen_kwargs(self, kwargs, lens):
+        """Shared parsing of the HF generate() kwargs this path honours (DLL:117-152 forwards **kwargs to HF): rejects what is not
+        built instead of silently ignoring it."""
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
+        if kwargs.get("past_key_values") is not None:
+            raise NotImplementedError("generate(past_key_values=...) is not built: drive multi-round dialogue through forward() (BLTM:326-337)")
+        if (kwargs.get("num_beams", 1) or 1) != 1:
+            raise NotImplementedError("beam search is not built (harness default num_beams=1)")
+        max_new = kwargs.get("max_new_tokens")
+        if max_new is None:
+            max_new = 20 if kwargs.get("max_length") is None else int(kwargs["max_length"]) - max(lens)
+        if max_new < 1:
+            raise ValueError(f"max_new_tokens must be >= 1 (got {max_new})")
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        if isinstance(eos, (list, tuple)):
+            eos = [int(e) for e in eos]
+            eos = None if not eos else (eos[0] if len(eos) == 1 else eos)
+        elif eos is not None:
+            eos = int(eos)
+        pad = kwargs.get("pad_token_id", self.config.pad_token_id)
+        min_new = int(kwargs.get("min_new_tokens", 0) or 0)
+        return int(max_new), min(min_new, int(max_new)), eos, (0 if pad is None else int(pad))
 
     @torch.no_grad()
     def _generate_sample(self, inputs, images, **kwargs):
@@ -1109,24 +1133,26 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         TopKLogitsWarper, TopPLogitsWarper: the smallest set of most probable tokens whose mass reaches top_p is kept), drawn with
         torch's generator -- a plain loop over forward() (no hipGraph: this is the convenience path, the harness default is greedy).
         Token streams cannot match HF's draw for draw (different RNG consumption); the distribution per step is the same."""
-        max_new = kwargs.get("max_new_tokens") or 20
         temperature = float(kwargs.get("temperature", 1.0) or 1.0)
         top_k = int(kwargs.get("top_k", 0) or 0)
         top_p = kwargs.get("top_p")
-        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
-        pad = kwargs.get("pad_token_id", self.config.pad_token_id) or 0
         gen = kwargs.get("generator")
         out = self.forward(inputs.to(self.device), attention_mask=kwargs.get("attention_mask"), images=images, image_features=kwargs.get("image_features"))
         cache = out.past_key_values
+        max_new, min_new, eos, pad = self._gen_kwargs(kwargs, cache.full_len_host)
+        eos_set = [] if eos is None else (eos if isinstance(eos, list) else [eos])
         # last VALID position of every row: the returned logits are right-padded with zeros when rows differ in length, and the
         # last layer's KV length is the (compacted) row length
         last = cache[1][-1].to(self.device).long() - 1
         logits = out.logits[torch.arange(out.logits.shape[0], device=self.device), last]
+        self.last_prefill_logits = logits.float().clone()
         B = logits.shape[0]
         finished = torch.zeros(B, dtype=torch.bool, device=self.device)
-        toks = []
+        toks, scores = [], []
         for step in range(max_new):
             z = logits.float() / temperature
+            if step < min_new and eos_set:
+                z[:, eos_set] = float("-inf")
             if top_k > 0:
                 kth = torch.topk(z, min(top_k, z.shape[-1]), dim=-1).values[:, -1:]
                 z = z.masked_fill(z < kth, float("-inf"))
@@ -1136,53 +1162,60 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 remove = cum <= (1.0 - float(top_p))
                 remove[:, -1] = False  # always keep the most probable token
                 z = z.masked_fill(remove.scatter(1, si, remove), float("-inf"))
+            scores.append(z)
             nxt = torch.multinomial(z.softmax(dim=-1), 1, generator=gen)[:, 0]
-            nxt = torch.where(finished, torch.full_like(nxt, int(pad)), nxt)
+            nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
             toks.append(nxt)
-            if eos is not None:
-                finished = finished | (nxt == int(eos))
-                if bool(finished.all()):
-                    break
+            for e in eos_set:
+                finished = finished | (nxt == e)
+            if eos_set and bool(finished.all()):
+                break
             if step + 1 < max_new:
                 out = self.forward(nxt[:, None], past_key_values=cache)
                 cache = out.past_key_values
                 logits = out.logits[:, -1]
-        return torch.stack(toks, dim=1)
+        seq = torch.stack(toks, dim=1)
+        self.last_cache = cache
+        if kwargs.get("return_dict_in_generate"):
+            res = {"sequences": seq, "past_key_values": cache}
+            if kwargs.get("output_scores"):
+                res["scores"] = tuple(scores)
+            return res
+        return seq
 
     @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, **kwargs):
         """dynamic_llava_llama.py:117-152: greedy decoding; returns the NEW tokens only [B, T_new] (HF behaviour when
-        generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens, min_new_tokens, do_sample (True: temperature /
-        top_k / top_p sampling through _generate_sample), num_beams(1), use_cache(True), eos_token_id, pad_token_id, attention_mask, return_dict_in_generate,
-        image_features (pre-computed projector output, testing).
+        generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens / max_length, min_new_tokens (EOS banned from
+        the argmax until then, as HF's MinNewTokensLengthLogitsProcessor), do_sample (True: temperature / top_k / top_p sampling
+        through _generate_sample), num_beams(1), use_cache(True), eos_token_id, pad_token_id, attention_mask,
+        return_dict_in_generate (+ output_scores), image_features (pre-computed projector output, testing).
         Steady state (same prompt SHAPE as a previous call): the whole prefill -- CLIP, projector, embedding assembly,
         32 layers, first-token argmax -- is one hipGraph replay and every decode step is another; the host only copies
         the new token ids / pixels into static buffers."""
         self._check_ready()
-        if "inputs_embeds" in kwargs:
-            raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
         if kwargs.get("do_sample", False):  # model_vqa_loader.py:162-175 passes do_sample = temperature > 0 (default 0: greedy)
+            if "inputs_embeds" in kwargs:
+                raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
             return self._generate_sample(inputs, images, **kwargs)
-        if kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("beam search is not built (harness default num_beams=1)")
-        max_new = kwargs.get("max_new_tokens")
-        min_new = kwargs.get("min_new_tokens", 0) or 0
-        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
-        pad = kwargs.get("pad_token_id", self.config.pad_token_id)
         attention_mask = kwargs.get("attention_mask")
         image_features = kwargs.get("image_features")
         sync_every = int(kwargs.get("sync_every", 16))
+        want_dict = bool(kwargs.get("return_dict_in_generate"))
+        want_scores = want_dict and bool(kwargs.get("output_scores"))
         inputs = inputs.to(self.device)
         lay = self._layout(inputs, attention_mask, None, self._n_feat(images, image_features))
         lens, indices, B = lay["lens"], lay["indices"], lay["B"]
-        if max_new is None:
-            max_new = 20 if kwargs.get("max_length") is None else kwargs["max_length"] - max(lens)
+        max_new, min_new, eos, pad = self._gen_kwargs(kwargs, lens)
+        if isinstance(eos, list):
+            raise NotImplementedError("several eos_token_ids on the greedy device path (one id is compared on the device)")
         cache = self._pooled_cache(B, max(lens) + max_new + 1)
         self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)
         st.step.zero_(); st.finished.zero_(); st.decision.fill_(1)
-        self._eos = -1 if eos is None else int(eos)
-        self._pad = 0 if pad is None else int(pad)
+        self._eos = -1 if eos is None else eos
+        self._pad = pad
+        self._min_new = min_new
         if getattr(self, "_prefill_logits_buf", None) is None or self._prefill_logits_buf.shape != st.logits.shape:
             self._prefill_logits_buf = torch.empty(st.logits.shape, dtype=torch.float32, device=self.device)
         vp = getattr(self.model, "image_score_predictor", None)
@@ -1190,7 +1223,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         graphable = self.use_hip_graph and self.debug_records is None and not hooked and not self._instruct_on(indices, B)  # data-dependent shapes
         if graphable:
             key = (lay["sig"], None if images is None else tuple(images.shape), None if image_features is None else tuple(image_features.shape),
-                   cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new > 0, repr(self.config.sparse_config), lay["text_src"][0] if lay["text_src"] else -1)
+                   cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new, repr(self.config.sparse_config))
             ent = self._prefill_graphs.get(key)
             if ent is None:
                 if len(self._prefill_graphs) >= 8:
@@ -1222,13 +1255,29 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             x, cache, _, _ = self._prefill(embeds, lens, indices, cache, reserve=max_new + 1, last_only=True)
             self._first_token(st, x, min_new)
         self.last_prefill_logits = self._prefill_logits_buf
+        scores = []
+
+        def _score(step_idx):  # HF `scores`: the processed logits of that step (EOS at -inf while step < min_new_tokens)
+            z = (self._prefill_logits_buf if step_idx == 0 else st.logits).float().clone()
+            if step_idx < min_new and self._eos >= 0:
+                z[:, self._eos] = float("-inf")
+            scores.append(z)
+
+        if want_scores:
+            _score(0)
+            sync_every = 1
         produced = 1
         while produced < max_new:
             n = min(sync_every, max_new - produced)
             self._run_decode_steps(st, cache, n)
             produced += n
+            if want_scores:
+                _score(produced - 1)
             if self._eos >= 0 and produced < max_new and bool(st.finished.min().item()):
                 break
+        # host mirrors of what the device loop advanced: every row's un-evicted length grows by one per decode step
+        cache.full_len_host = [n + produced - 1 for n in cache.full_len_host]
+        cache.seen_tokens += produced - 1
         out = st.out_ids[:, :produced].clone()
         if self._eos >= 0:  # HF stops as soon as every row has emitted EOS: trim the columns produced after that
             fin = (out == self._eos).int().cumsum(dim=1).clamp(max=1)
@@ -1236,7 +1285,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if bool(all_done.any().item()):
                 first = int(torch.argmax(all_done).item())
                 out = out[:, : first + 1]
+                scores = scores[: first + 1]
         self.last_cache = cache
-        if kwargs.get("return_dict_in_generate"):
-            return {"sequences": out, "past_key_values": cache}
+        if want_dict:
+            # the caller keeps this cache (the reference returns an independent one per call): detach it from the pool, the next
+            # generate() allocates a fresh slab instead of overwriting this one
+            self._cache_pool = None
+            res = {"sequences": out, "past_key_values": cache}
+            if want_scores:
+                res["scores"] = tuple(scores)
+            return res
         return out

@@ -194,21 +194,21 @@ int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int B, int H, 
 #define DL_GEMV_SILUMUL 2
 #define DL_GEMV_OUT_SILU_PAIR 16
 int dl_gemv_max_batch(int K, int dtype);
-/* tuning knob (process-global, not thread-safe; the default is the tuned one): workgroup cap.  `variant` must be 0 (the one load
- * schedule that is built: 2 neurons x 4 chunks in flight per wave). */
-int dl_gemv_set_tuning(int grid_cap, int variant);
+/* grid_cap: workgroup cap of this call (0 = the tuned default, 4 workgroups per CU); there is no process-global tuning state. */
 int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_stride, const void* h_in, void* h_out,
-            const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, void* stream);
+            const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, int grid_cap,
+            void* stream);
 
 /* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
  * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;
  * out_ids[b, step[b]] = next[b]; ++step[b]; kv_len_full[b] += 1; kv_len_sparse[b] += decision ? decision[b] : 1.
  * logits: [B,V] in `logits_dtype` (DL_F32 or the model dtype).  step/finished: int32[B].  All state lives on
- * the device; out_ids / step / finished / kv_len_* / decision may be NULL to skip that piece of bookkeeping. */
+ * the device; out_ids / step / finished / kv_len_* / decision may be NULL to skip that piece of bookkeeping.
+ * min_new_tokens > 0: eos_id is excluded from the argmax while step[b] < min_new_tokens (HF MinNewTokensLengthLogitsProcessor). */
 int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_stride, int V, int B,
                       int64_t* next_ids, int64_t* out_ids, int out_cap, int32_t* step, int32_t* finished,
                       int eos_id, int pad_id, int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision,
-                      void* stream);
+                      int min_new_tokens, void* stream);
 
 /* ---- decode GEMM for 5..32 rows: Y[M,N] = X[M,K] @ W[N,K]^T (nn.Linear without bias: DML:1011-1013, 1127, 328, 2709), M <=
  * dl_gemm_smallm_max_m().  Weight-streaming like dl_gemv, products on the matrix cores (X resident in LDS, weights HBM -> MFMA

@@ -45,9 +45,30 @@ CASES = {
     # instruct predictor off the same call is plain chunked prefill on a cache
     "tiny_fp32_multiround": dict(dtype="float32", sparse=dict(use_instruct_predictor=True), prompts=[(5, 9)], steps=0, gain=50.0, rounds=[3, ("chunk", 8), 4, ("chunk", 5), 3]),
     "tiny_fp32_chunked": dict(dtype="float32", sparse={}, prompts=[(5, 9)], steps=0, gain=50.0, rounds=[2, ("chunk", 7), 3]),
+    # ARCH:418-454 pinned against the reference itself: vocab >= 29902 so the "USER:" ids (11889, 29901) exist; two matches inside the
+    # instruct span, the instruct predictor (on) only drops tokens after the LAST one
+    "tiny_fp32_userprompt": dict(dtype="float32", sparse=dict(use_instruct_predictor=True), prompts=[(5, 26)], steps=3, gain=50.0, vocab=30000, user_at=[3, 14]),
     "tiny_fp32_nocache": dict(dtype="float32", sparse={}, prompts=[(5, 7)], steps=10, gain=50.0, nocache=True),
     "tiny_fp32_nocache_b2": dict(dtype="float32", sparse={}, prompts=[(5, 7), (5, 7)], steps=6, gain=50.0, nocache=True),
 }
+
+
+def case_config(c):
+    """The config of a golden case (tiny model; `vocab` overrides the 320-entry test vocabulary)."""
+    cfg = fx.tiny_config(**c["sparse"])
+    if "vocab" in c:
+        cfg.vocab_size = c["vocab"]
+    return cfg
+
+
+def case_prompts(c, cfg):
+    """Seeded prompts of a golden case; `user_at`: offsets inside the question where the "USER:" id pair (ARCH:36) is planted."""
+    prompts = [fx.make_prompt(cfg, ns, nq, seed=i) for i, (ns, nq) in enumerate(c["prompts"])]
+    for off in c.get("user_at", []):
+        for p, (ns, _) in zip(prompts, c["prompts"]):
+            p[ns + 1 + off] = 11889
+            p[ns + 2 + off] = 29901
+    return prompts
 
 
 def build_reference_model(dll, cfg, sd, clip, dtype):
@@ -206,10 +227,10 @@ def main():
             continue
         torch.manual_seed(0)
         dtype = getattr(torch, c["dtype"])
-        cfg = fx.tiny_config(**c["sparse"])
+        cfg = case_config(c)
         sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
         clip = fx.build_clip(cfg, seed=1)
-        prompts = [fx.make_prompt(cfg, ns, nq, seed=i) for i, (ns, nq) in enumerate(c["prompts"])]
+        prompts = case_prompts(c, cfg)
         input_ids = pad_prompts(prompts)
         images = fx.make_images(cfg, len(prompts), seed=0)
         forced = None

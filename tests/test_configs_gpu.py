@@ -124,30 +124,42 @@ def test_c5_13b_width_long_decode_with_eviction():
     tok = out.logits[:, -1].argmax(-1)
     dec = []
     n_check = 300
+    n_oracle = 8
+    hip_logits = [out.logits[0, -1].float().cpu()]
     for j in range(n_check):
         assert int(tok[0]) == int(a[0, j]), f"forward-loop token {j}"
         out = model(tok[:, None], past_key_values=pkv)
         pkv = out.past_key_values
         dec.append(int(model.debug_records["text_decision"][0]))
+        if j < n_oracle:
+            hip_logits.append(out.logits[0, -1].float().cpu())
         tok = out.logits[:, -1].argmax(-1)
     assert pkv.t_cap > cap0, "slab must have grown"
     assert int(pkv[1][-1][0]) == 179 + sum(dec) and int(pkv[1][0][0]) == 640 + n_check
     assert pkv[0][-1][0].shape[-2] == 179 + sum(dec) and pkv[0][0][0].shape[-2] == 640 + n_check
     model.debug_records = None
-    # oracle: prefill + 8 decode steps, teacher-forced with the tokens the HIP path generated
+    # oracle at 13B width: prefill + 8 decode steps, teacher-forced with the tokens the HIP path generated.  Logits in the
+    # reference's own noise class (|hip - fp32 truth| <= 2 |reference(bf16) - fp32 truth| + 2 ulp), eviction decisions equal
+    # away from the decision boundary.
+    ulp = 2.0**-7
     o = Oracle(cfg, sd, dtype)
+    o32 = Oracle(cfg, {k: v.to(dtype) for k, v in sd.items()}, torch.float32)
     with torch.no_grad():
         l_ref, p_ref = o.forward(ids, image_features=feats)
-        agree = int(l_ref[0, -1].argmax()) == int(a[0, 0])
-        for j in range(8):
-            l_ref, p_ref = o.forward(a[:, j : j + 1].cpu(), past_key_values=p_ref)
-            gap = float((o.records["text_logit"][0, 0, 0] - o.records["text_logit"][0, 0, 1]).abs())
-            if gap > 0.5:
-                assert int(o.records["text_decision"][0, 0]) == dec[j], f"eviction decision, step {j}"
-            else:
+        l_32, p_32 = o32.forward(ids, image_features=feats.float())
+        for j in range(n_oracle + 1):
+            e_hip = float((hip_logits[j] - l_32[0, -1]).abs().max())
+            e_ref = float((l_ref[0, -1].float() - l_32[0, -1]).abs().max())
+            assert e_hip <= 2.0 * e_ref + 2 * ulp * float(l_32[0, -1].abs().max()), (j, e_hip, e_ref)
+            if j == n_oracle:
                 break
-            agree += int(l_ref[0, -1].argmax()) == int(a[0, j + 1])
-    assert agree >= 1
+            l_ref, p_ref = o.forward(a[:, j : j + 1].cpu(), past_key_values=p_ref)
+            l_32, p_32 = o32.forward(a[:, j : j + 1].cpu(), past_key_values=p_32)
+            gap = float((o32.records["text_logit"][0, 0, 0] - o32.records["text_logit"][0, 0, 1]).abs())
+            if gap > 0.5:
+                assert int(o.records["text_decision"][0, 0]) == dec[j] == int(o32.records["text_decision"][0, 0]), f"eviction decision, step {j}"
+            else:
+                break  # a boundary decision may flip between summation orders: the caches diverge from here on
 
 
 @pytest.mark.parametrize("B", [4, 7, 16])

@@ -1,0 +1,99 @@
+"""GPU: the data-parallel path with the REAL model (BASELINE configs[3]'s per-rank shape).  Two ranks share the one
+GPU of the test box (gloo backend + the DL_FORCE_DEVICE hook; on the 8-GPU node the same code runs one rank per GPU over RCCL):
+64 ragged requests are split by the reference's contiguous-chunk rule (model_vqa_loader.py:30-38) into 32 per rank, each rank
+runs sparsified prefill + greedy decode with eviction on its chunk, and ONE all-gather returns last-token logits + generated ids.
+The gathered result must equal, bit for bit, the same chunks run one after the other by a single process."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_REQ, PER_RANK, STEPS = 64, 32, 10
+
+
+def _requests(cfg, dtype):
+    from oracle import fixtures as fx
+
+    g = torch.Generator().manual_seed(1)
+    n_q = torch.randint(8, 65, (N_REQ,), generator=g).tolist()  # question lengths ~U[8,64]
+    prompts = [fx.make_prompt(cfg, 35, n_q[b], seed=b) for b in range(N_REQ)]
+    feats = torch.randn(N_REQ, 576, cfg.hidden_size, generator=g).to(dtype)
+    return prompts, feats
+
+
+def _run_chunk(model, prompts, feats, idx):
+    W = max(prompts[i].shape[0] for i in idx)
+    ids = torch.zeros(len(idx), W, dtype=torch.long)
+    am = torch.zeros(len(idx), W, dtype=torch.long)
+    for r, i in enumerate(idx):
+        ids[r, : prompts[i].shape[0]] = prompts[i]
+        am[r, : prompts[i].shape[0]] = 1
+    out = model.generate(ids.cuda(), attention_mask=am.cuda(), image_features=feats[list(idx)].cuda(), max_new_tokens=STEPS, eos_token_id=None)
+    return out.cpu(), model.last_prefill_logits.float().cpu().clone(), model.last_cache[1][-1].clone()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      DL_FORCE_DEVICE="0", DL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from dynamic_llava_amd import dist as dd
+    from dynamic_llava_amd.builder import build_from_state_dict, build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+    from oracle import fixtures as fx
+
+    r, w, local = dd.init_distributed()
+    torch.cuda.set_device(local)
+    dtype = torch.bfloat16
+    cfg = fx.llava7b_config(num_hidden_layers=3)
+    cfg.vocab_size = 4096
+    sd = fx.make_state_dict(cfg, seed=11, predictor_gain=50.0)
+    model = build_from_state_dict(DynamicLlavaConfig.from_namespace(cfg), sd, None, dtype=dtype, device="cuda")
+    prompts, feats = _requests(cfg, dtype)
+    mine = dd.get_chunk(list(range(N_REQ)), w, r)
+    assert len(mine) == PER_RANK
+    ids, logits, lens = _run_chunk(model, prompts, feats, mine)
+    all_ids = dd.all_gather_rows(ids)
+    all_logits = dd.all_gather_rows(logits)
+    all_lens = dd.all_gather_rows(lens)
+    # bench.py's builder: every rank must hold identical random-init weights (seeded device generator)
+    rm = build_random_model(DynamicLlavaConfig(num_hidden_layers=1, vocab_size=512), dtype=dtype, device="cuda", seed=0, predictor_gain=50.0)
+    digest = torch.stack([p.detach().double().sum().cpu() for p in rm.parameters()])
+    digests = dd.all_gather_rows(digest[None])
+    dd.barrier()
+    if rank == 0:
+        ok_w = bool(torch.equal(digests[0], digests[1]))
+        # single process, same chunks one after the other (the reference's share-nothing processes, concatenated)
+        ref = [_run_chunk(model, prompts, feats, dd.get_chunk(list(range(N_REQ)), w, k)) for k in range(w)]
+        ref_ids = torch.cat([x[0] for x in ref])
+        ref_logits = torch.cat([x[1] for x in ref])
+        ref_lens = torch.cat([x[2] for x in ref])
+        kept = (ref_lens - torch.tensor([35 + 115 + p.shape[0] - 36 for p in prompts])).tolist()
+        q.put(dict(ids=bool(torch.equal(all_ids, ref_ids)), logits=bool(torch.equal(all_logits, ref_logits)), lens=bool(torch.equal(all_lens, ref_lens)),
+                   shape=tuple(all_ids.shape), weights=ok_w, evicted_some=bool(0 < sum(kept) < N_REQ * (STEPS - 1))))
+    dd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_dp2_real_model_equals_single_process_bit_exact():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert res["shape"] == (N_REQ, STEPS)
+    assert res["weights"], "build_random_model must give every rank identical weights"
+    assert res["ids"] and res["logits"] and res["lens"], res
+    assert res["evicted_some"], "the per-row eviction must be exercised both ways"

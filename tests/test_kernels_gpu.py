@@ -337,7 +337,8 @@ def test_linear_epilogues(ops, dtype, M, N, K, flags):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B", [1, 3])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (22016, 4096), (4096, 11008), (1000, 256), (37, 512)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (22016, 4096), (4096, 11008), (1000, 256), (37, 512),
+                                 (15360, 5120), (5120, 5120), (27648, 5120), (5120, 13824)])  # last four: LLaVA-1.5-13B (configs[4])
 def test_gemv_modes(ops, dtype, B, N, K):
     """dl_gemv against the eager op sequence it replaces (fp32 evaluation of the same rounded operands)."""
     g = torch.Generator().manual_seed(16)
@@ -375,14 +376,12 @@ def test_gemv_modes(ops, dtype, B, N, K):
         I = N // 2
         gu_ref = F.linear(x.float(), w.float()).to(dtype)
         ref = F.silu(gu_ref[:, :I]) * gu_ref[:, I:]
-        for cap in (512, 64):
-            ops.lib().dl_gemv_set_tuning(cap, 0)
+        for cap in (512, 64):  # per-call workgroup cap (no process-global tuning state in the ABI)
             act = torch.empty(B, I, dtype=dtype, device="cuda")
-            ops.gemv(wd, act, x=x.cuda(), mode=ops.GEMV_OUT_SILU_PAIR)
+            ops.gemv(wd, act, x=x.cuda(), mode=ops.GEMV_OUT_SILU_PAIR, grid_cap=cap)
             _close_ulp(act, ref, dtype, 4.0, atol=2e-4 if dtype == torch.float32 else 2e-2)
-            ops.gemv(wd, y, x=x.cuda())
+            ops.gemv(wd, y, x=x.cuda(), grid_cap=cap)
             _close_ulp(y, gu_ref, dtype, 1.0, atol=1e-4 if dtype == torch.float32 else 2e-3)
-        ops.lib().dl_gemv_set_tuning(1024, 0)
 
 
 def _vp_sd(cfg, seed, gain):
@@ -530,7 +529,8 @@ def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d, Lq):
 @pytest.mark.parametrize(
     "M,N,K,n_slices,wg_waves",
     [(32, 4096, 4096, 0, 0), (16, 12288, 4096, 1, 4), (5, 22016, 4096, 0, 8), (8, 4096, 11008, 0, 0), (32, 4096, 11008, 0, 4), (17, 200, 512, 2, 0),
-     (1, 64, 256, 0, 0), (9, 132, 768, 3, 8), (32, 32000, 4096, 0, 0), (24, 1000, 1280, 1, 0)],
+     (1, 64, 256, 0, 0), (9, 132, 768, 3, 8), (32, 32000, 4096, 0, 0), (24, 1000, 1280, 1, 0),
+     (8, 15360, 5120, 0, 0), (16, 27648, 5120, 0, 0), (6, 5120, 13824, 0, 0)],  # last three: LLaVA-1.5-13B projections
 )
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves, variant):

@@ -17,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import fixtures as fx  # noqa: E402
-from oracle.make_golden import CASES, SD_SEED  # noqa: E402
+from oracle.make_golden import CASES, SD_SEED, case_config  # noqa: E402
 from oracle.ref_cpu import Oracle  # noqa: E402
 
 ULP = {torch.float32: 2.0**-23, torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
@@ -34,7 +34,7 @@ def _build(cfg_ns, sd, clip, dtype):
 def _golden_setup(name):
     c = CASES[name]
     dtype = getattr(torch, c["dtype"])
-    cfg = fx.tiny_config(**c["sparse"])
+    cfg = case_config(c)
     sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
     clip = fx.build_clip(cfg, seed=1)
     return c, dtype, cfg, sd, clip
@@ -510,3 +510,48 @@ def test_generate_sampling_path():
     assert not torch.equal(c1, greedy), "a hot temperature on near-uniform random-init logits must leave the greedy path"
     with pytest.raises(NotImplementedError):
         model.generate(ids.cuda(), images=imgs, max_new_tokens=2, num_beams=2)
+
+
+def test_generate_then_forward_on_returned_cache_vs_oracle():
+    """the cache generate() hands back must be consistent on the HOST side too (un-evicted length mirrors), so that a
+    follow-up forward(past_key_values=cache) -- the multi-round driver of BLTM:326-337 -- attends to the whole cache, a returned
+    cache is not overwritten by the next generate(), and HF kwargs that are not built fail loudly."""
+    c, dtype, cfg, sd, clip = _golden_setup("tiny_fp32_b1_gain50")
+    model = _build(cfg, sd, clip, dtype)
+    ids = fx.make_prompt(cfg, 5, 7)[None]
+    images = fx.make_images(cfg, 1, seed=0)
+    n = 7
+    res = model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=n, eos_token_id=None, return_dict_in_generate=True, output_scores=True)
+    seq, cache = res["sequences"], res["past_key_values"]
+    n_prompt = ids.shape[1] - 1 + fx.n_image_tokens(cfg)
+    assert cache.full_len_host == [n_prompt + n - 1] and cache.get_seq_length(0) == n_prompt + n - 1
+    assert cache[0][0][0].shape[-2] == n_prompt + n - 1 == int(cache[1][0][0])
+    assert len(res["scores"]) == n and all(s.shape == (1, cfg.vocab_size) for s in res["scores"])
+    assert [int(s.argmax(-1)) for s in res["scores"]] == seq[0].tolist()
+    o = Oracle(cfg, sd, dtype, clip=clip)
+    with torch.no_grad():
+        ref, pkv = o.greedy(ids, images=images, max_new_tokens=n, eos_token_id=None)
+        assert seq.cpu().tolist() == ref.tolist()
+        l_ref, pkv = o.forward(ref[:, -1:], past_key_values=pkv)
+    # another generate() in between must NOT touch the returned cache (it was detached from the pool)
+    k_before = cache.k[3][:, :, : n_prompt, :].clone()
+    model.generate(fx.make_prompt(cfg, 4, 9, seed=3)[None].cuda(), images=images.cuda(), max_new_tokens=3, eos_token_id=None)
+    assert torch.equal(cache.k[3][:, :, : n_prompt, :], k_before)
+    out = model(seq[:, -1:], past_key_values=cache)
+    assert float((out.logits[0, -1].cpu() - l_ref[0, -1]).abs().max()) < 1e-3
+    np.testing.assert_array_equal(out.past_key_values[1][-1].numpy(), pkv[1][-1].numpy())
+    np.testing.assert_array_equal(out.past_key_values[1][0].numpy(), pkv[1][0].numpy())
+    # min_new_tokens: EOS cannot be emitted before that many tokens exist (HF MinNewTokensLengthLogitsProcessor), then it stops
+    eos = int(ref[0, 0])
+    a = model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=4, eos_token_id=eos)
+    assert a.cpu().tolist() == [[eos]]
+    b = model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=4, min_new_tokens=2, eos_token_id=eos)
+    assert b.shape[1] >= 2 and eos not in b[0, :2].tolist()
+    first_logits = model.last_prefill_logits[0].clone()
+    first_logits[eos] = float("-inf")
+    assert int(b[0, 0]) == int(first_logits.argmax())
+    for bad in (dict(past_key_values=cache), dict(num_beams=2), dict(inputs_embeds=torch.zeros(1))):
+        with pytest.raises(NotImplementedError):
+            model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=2, **bad)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=2, do_sample=True, num_beams=3)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import fixtures as fx
-from oracle.make_golden import CASES, SD_SEED
+from oracle.make_golden import CASES, SD_SEED, case_config
 from oracle.ref_cpu import Oracle, topk_keep_index
 
 
@@ -15,7 +15,7 @@ def _run_case(name, golden_dir, tie_break):
     c = CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     dtype = getattr(torch, c["dtype"])
-    cfg = fx.tiny_config(**c["sparse"])
+    cfg = case_config(c)
     sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
     clip = fx.build_clip(cfg, seed=1)
     o = Oracle(cfg, sd, dtype, clip=clip, tie_break=tie_break)
@@ -57,7 +57,7 @@ def test_oracle_multiround_matches_reference_golden(name, golden_dir):
     c = CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     dtype = getattr(torch, c["dtype"])
-    cfg = fx.tiny_config(**c["sparse"])
+    cfg = case_config(c)
     sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
     o = Oracle(cfg, sd, dtype, clip=fx.build_clip(cfg, seed=1), tie_break="torch")
     images = fx.make_images(cfg, 1, seed=0).to(dtype)
@@ -82,7 +82,7 @@ def test_oracle_nocache_matches_reference_golden(name, golden_dir):
     c = CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     dtype = getattr(torch, c["dtype"])
-    cfg = fx.tiny_config(**c["sparse"])
+    cfg = case_config(c)
     sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=c["gain"])
     o = Oracle(cfg, sd, dtype, clip=fx.build_clip(cfg, seed=1), tie_break="torch")
     total = torch.from_numpy(g["input_ids"])

@@ -49,11 +49,10 @@ for name, N, K, mode in SHAPES:
     best = None
     for variant in (0,):
         for cap in (512, 1024, 2048, 4096):
-            ops.lib().dl_gemv_set_tuning(cap, variant)
             if (mode & 3) == ops.GEMV_ADDNORM:
-                fns = [lambda w=w: ops.gemv(w, y, mode=mode, h_in=h, h_out=h2, delta=dl, norm_w=nw, eps=1e-5) for w in ws]
+                fns = [lambda w=w: ops.gemv(w, y, mode=mode, h_in=h, h_out=h2, delta=dl, norm_w=nw, eps=1e-5, grid_cap=cap) for w in ws]
             else:
-                fns = [lambda w=w: ops.gemv(w, y, x=x, mode=mode) for w in ws]
+                fns = [lambda w=w: ops.gemv(w, y, x=x, mode=mode, grid_cap=cap) for w in ws]
             us = timed(fns)
             gbs = N * K * 2 / us / 1e3
             print(f"{name:20s} N={N:6d} K={K:6d} B={B} variant={variant} cap={cap:6d}  {us:8.2f} us  {gbs:8.1f} GB/s")
