@@ -31,7 +31,7 @@ def _digest(paths):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = _sources()
-    deps = srcs + [os.path.join(CSRC, "dl_common.h"), os.path.join(os.path.dirname(HERE), "include", "dynllava.h")]
+    deps = srcs + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(HERE), "include", "dynllava.h")]
     stamp = os.path.join(OBJ, "stamp")
     dig = _digest(deps)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:

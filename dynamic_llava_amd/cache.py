@@ -65,12 +65,15 @@ class KVSlabCache:
         # exact host mirror of lens[0] (advances by one per token for every row) -> capacity checks without a sync
         self.full_len_host: List[int] = [0] * batch
         self.seen_tokens = 0
-        self.sparse_cap = self.t_cap  # host-known upper bound of lens[1] (set by the prefill: t_cap minus the dropped image tokens)
+        # `logical_cap`: the capacity the REQUEST asked for (prompt + new tokens + 1).  A pooled slab may be larger; everything that
+        # shapes the computation (split-KV factor) is derived from the logical capacity, so results do not depend on pooling history
+        self.logical_cap = self.t_cap
+        self.sparse_cap = self.t_cap  # host-known upper bound of lens[1] (set by the prefill: logical_cap minus the dropped image tokens)
 
     def n_splits(self, layer_idx: int, rows_times_heads: int, max_splits: int = 32) -> int:
         """Split-KV factor of the decode attention (tools/bench_attn_decode.py sweep): enough workgroups to cover the 256 CUs
         (rows x heads x splits >= 256), never fewer than ~64 keys per workgroup, judged on the host-known length bound."""
-        cap = self.t_cap if self.group(layer_idx) == 0 else min(self.sparse_cap, self.t_cap)
+        cap = self.logical_cap if self.group(layer_idx) == 0 else min(self.sparse_cap, self.logical_cap)
         want = max(1, 256 // max(1, rows_times_heads))
         return max(1, min(max_splits, want, -(-cap // 64)))
 
@@ -99,6 +102,7 @@ class KVSlabCache:
         new[:, :, :, :, : self.t_cap, :] = self.slab
         self.slab = new
         self.sparse_cap += new_cap - self.t_cap
+        self.logical_cap += new_cap - self.t_cap
         self.t_cap = new_cap
         self.k = [self.slab[i, 0] for i in range(self.n_layers)]
         self.v = [self.slab[i, 1] for i in range(self.n_layers)]

@@ -8,7 +8,7 @@
 // groups merge through LDS once per workgroup, splits merge in attn_decode_combine_kernel.
 // Per-row lengths are read from the device (kv_len[b] + extra): no host sync, graph-capturable,
 // and a slot beyond the true length (an evicted token) is simply never read.
-#include "dl_common.h"
+#include "attn_decode_body.h"
 
 namespace dl {
 
@@ -30,239 +30,33 @@ __device__ long long g_attn_stamps[8];
 // FUSED: the RoPE of q and of the new key (DML:260-285) and the KV-slab append (CU:109-268) happen inside the attention
 // kernel: q|k|v are read un-rotated from the projection output, the new token's rotated key / value are used from
 // registers by the one lane group that owns key index kv_len[b] and written to slab slot kv_len[b] for later steps.
-template <typename T, bool UPPER>
-__device__ __forceinline__ void rope16(const float (&own)[Elem<T>::kVec], const float (&par)[Elem<T>::kVec], const float (&cs)[Elem<T>::kVec],
-                                       const float (&sn)[Elem<T>::kVec], float (&out)[Elem<T>::kVec]) {
-#pragma unroll
-  for (int i = 0; i < Elem<T>::kVec; ++i)  // x*cos + rotate_half(x)*sin, each op rounded (DML:283-284); rotate_half = cat(-x2, x1)
-    out[i] = Elem<T>::round(Elem<T>::round(own[i] * cs[i]) + Elem<T>::round((UPPER ? par[i] : -par[i]) * sn[i]));
-}
-
-// sum over the LPK lanes that share one key (8, 16 or 32 lanes, aligned): DPP inside a 16-lane row, one crossbar step beyond it
-template <int LPK>
-__device__ __forceinline__ float lpk_sum(float a) {
-  if constexpr (LPK == 8) return row8_sum(a);
-  else if constexpr (LPK == 16) return row16_sum(a);
-  else if constexpr (LPK == 32) {
-    a = row16_sum(a);
-    return a + __shfl_xor(a, 16, 64);
-  } else {
-#pragma unroll
-    for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
-    return a;
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void unpack_kv(const uint4& r, float (&f)[Elem<T>::kVec]) {
-  if constexpr (Elem<T>::kVec == 4) {
-    f[0] = __uint_as_float(r.x);
-    f[1] = __uint_as_float(r.y);
-    f[2] = __uint_as_float(r.z);
-    f[3] = __uint_as_float(r.w);
-  } else {
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = Elem<T>::to_f((uint16_t)(w[i] & 0xffffu));
-      f[2 * i + 1] = Elem<T>::to_f((uint16_t)(w[i] >> 16));
-    }
-  }
-}
-
+// The body lives in attn_decode_body.h (shared with the persistent decode step).
 template <typename T, int D, int NW, bool FUSED, int U>
 __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     const void* __restrict__ q_, int64_t q_row_stride, const void* k_slab_, const void* v_slab_, int64_t stride_b, int64_t stride_h,
     const int32_t* __restrict__ kv_len, int extra, float* __restrict__ ws, void* __restrict__ out_, int64_t out_row_stride, int n_rep,
     float scale, const void* __restrict__ cos_, const void* __restrict__ sin_, int n_pos, const int32_t* __restrict__ pos_base, int T_cap,
     int n_kv_heads, int chunk_keys) {
-  constexpr int V = Elem<T>::kVec;
-  constexpr int LPK = D / V;          // lanes per key
-  constexpr int KPW = 64 / LPK;       // keys per wave per load instruction
-  constexpr int NG = NW * KPW;        // lane groups per workgroup
+  using St = AttnSplitState<T, D, NW, U>;
   using S = typename Elem<T>::storage;
+  constexpr int NG = St::NG;
   __shared__ float sm_m[NG], sm_l[NG];
-  __shared__ float sm_o[NG][D];
+  __shared__ float sm_o[NG * D];
 
   DL_STAMP(0, false);
   const int split = blockIdx.x, n_splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
   const int n_heads = gridDim.y;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int g = lane / LPK, c = (lane % LPK) * V;
+  const int tid = threadIdx.x;
   const int kvh = h / n_rep;
   const S* row = reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride;
-  const S* kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
-  const S* vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + c;
-  constexpr int HALF = D / 2;
-  const int cpar = c < HALF ? c + HALF : c - HALF;
-
-  // ---- every load that does not depend on another load is issued up front, K/V first: a dependent HBM round trip costs
-  // ~1.5 us here, so the kernel's latency is (number of round trips), not bytes.
-  // With a host-provided chunk (chunk_keys > 0, needs T_cap) the key range of this split does not depend on kv_len either: the
-  // K/V rows are requested speculatively (any slot < T_cap is readable) and masked once kv_len[b] has arrived. ----
   const int T_old = kv_len[b];
-  const bool spec = chunk_keys > 0 && T_cap > 0;
-  uint4 kraw[U], vraw[U];
-  int chunk = 0, k0 = 0;
-  if (spec) {
-    chunk = (chunk_keys + NG - 1) / NG * NG;
-    k0 = split * chunk;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = min(k0 + (u * NW + wid) * KPW + g, T_cap - 1);
-      kraw[u] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * D);
-      vraw[u] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * D);
-    }
-  }
-  const int Tn = T_old + (FUSED ? 1 : extra);
-  if (!spec) {
-    chunk = (Tn + n_splits - 1) / n_splits;
-    chunk = (chunk + NG - 1) / NG * NG;
-    k0 = split * chunk;
-  }
-  // this split's keys [k0, k1s); with a host chunk the last split also takes whatever the host's length bound missed
-  const int k1s = (spec && split == n_splits - 1) ? Tn : min(Tn, k0 + chunk);
-  const int k1 = FUSED ? min(k1s, T_old) : k1s;      // ... of which [k0, k1) are read from the slab
-  bool ok[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int key = k0 + (u * NW + wid) * KPW + g;
-    ok[u] = key < k1;
-    if (!spec) {
-      const int64_t off = (int64_t)(ok[u] ? key : (k0 < k1 ? k0 : 0)) * D;
-      kraw[u] = *reinterpret_cast<const uint4*>(kb + off);
-      vraw[u] = *reinterpret_cast<const uint4*>(vb + off);
-    }
-  }
-  float qv[V], cs[V], sn[V];
-  const bool owns_new = FUSED && T_old >= k0 && T_old < k1s && wid == 0 && g == 0;
-  float kn[V], vn[V];
-  if constexpr (FUSED) {
-    int p = pos_base[b];
-    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
-    float own[V], par[V], kown[V], kpar[V];
-    load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
-    load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
-    load16<T>(row + (int64_t)h * D + c, own);
-    load16<T>(row + (int64_t)h * D + cpar, par);
-    if (owns_new) {
-      const S* krow = row + (int64_t)(n_heads + kvh) * D;
-      load16<T>(krow + c, kown);
-      load16<T>(krow + cpar, kpar);
-      load16<T>(row + (int64_t)(n_heads + n_kv_heads + kvh) * D + c, vn);
-    }
-    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
-    if (owns_new) {
-      if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
-    }
-  } else {
-    load16<T>(row + (int64_t)h * D + c, qv);
-  }
-
-  DL_STAMP(1, true);  // every up-front load has landed
-  float m = -INFINITY, l = 0.f, o[V];
-#pragma unroll
-  for (int i = 0; i < V; ++i) o[i] = 0.f;
-
-  // keys of this workgroup are dealt round-robin: key = base + (u * NW + wid) * KPW + g
-  for (int base = k0; base < k1; base += NG * U) {
-    if (base != k0) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int key = base + (u * NW + wid) * KPW + g;
-        ok[u] = key < k1;
-        const int64_t off = (int64_t)(ok[u] ? key : k0) * D;
-        kraw[u] = *reinterpret_cast<const uint4*>(kb + off);
-        vraw[u] = *reinterpret_cast<const uint4*>(vb + off);
-      }
-    }
-    float s[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float kx[V];
-      unpack_kv<T>(kraw[u], kx);
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < V; ++i) a += qv[i] * kx[i];
-      a = lpk_sum<LPK>(a);
-      s[u] = ok[u] ? a * scale : -INFINITY;
-    }
-    float mn = m;
-#pragma unroll
-    for (int u = 0; u < U; ++u) mn = fmaxf(mn, s[u]);
-    if (mn > -INFINITY) {
-      const float alpha = __expf(m - mn);  // m = -inf -> 0
-      l *= alpha;
-#pragma unroll
-      for (int i = 0; i < V; ++i) o[i] *= alpha;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float vx[V];
-        unpack_kv<T>(vraw[u], vx);
-        const float p = __expf(s[u] - mn);  // masked key: exp(-inf) = 0
-        l += p;
-#pragma unroll
-        for (int i = 0; i < V; ++i) o[i] += ok[u] ? p * vx[i] : 0.f;  // a speculatively read slot past the length may hold NaN bits
-      }
-      m = mn;
-    }
-  }
-
-  if constexpr (FUSED) {
-    // the new token (key index T_old): owned by lane group (wave 0, g 0) of the split whose range contains it
-    if (owns_new) {
-      if (h % n_rep == 0 && T_old < T_cap) {  // one writer per kv head; eviction = the length is simply not advanced later
-        S* kd = const_cast<S*>(kb) + (int64_t)T_old * D;
-        S* vd = const_cast<S*>(vb) + (int64_t)T_old * D;
-        store16<T>(kd, kn);
-        store16<T>(vd, vn);
-      }
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < V; ++i) a += qv[i] * kn[i];
-      a = lpk_sum<LPK>(a);
-      const float sc_ = a * scale;
-      const float mn = fmaxf(m, sc_);
-      const float alpha = __expf(m - mn);
-      const float p = __expf(sc_ - mn);
-      l = l * alpha + p;
-#pragma unroll
-      for (int i = 0; i < V; ++i) o[i] = o[i] * alpha + p * vn[i];
-      m = mn;
-    }
-  }
-
-  DL_STAMP(2, true);  // scores / softmax / PV (and the appended token) done
-  // merge the NG lane groups of this workgroup
-  const int gg = wid * KPW + g;
-  if ((lane % LPK) == 0) {
-    sm_m[gg] = m;
-    sm_l[gg] = l;
-  }
-#pragma unroll
-  for (int i = 0; i < V; ++i) sm_o[gg][c + i] = o[i];
-  __syncthreads();
+  St st;
+  attn_split_issue<T, D, NW, FUSED, U>(st, tid, k_slab_, v_slab_, stride_b, stride_h, T_old, extra, b, kvh, split, n_splits, T_cap, chunk_keys);
+  float M, L, O;
+  attn_split_finish<T, D, NW, FUSED, U>(st, tid, row + (int64_t)h * D, row + (int64_t)(n_heads + kvh) * D,
+                                        row + (int64_t)(n_heads + n_kv_heads + kvh) * D, cos_, sin_, n_pos, FUSED ? pos_base[b] : 0, scale,
+                                        h % n_rep == 0, T_cap, sm_m, sm_l, sm_o, M, L, O);
   if (tid < D) {
-    // NG <= 32 partials: every LDS read is issued before the first use (a rolled loop pays the LDS latency NG times over)
-    float mg[NG], lg[NG], og[NG];
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      mg[i] = sm_m[i];
-      lg[i] = sm_l[i];
-      og[i] = sm_o[i][tid];
-    }
-    float M = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) M = fmaxf(M, mg[i]);
-    float L = 0.f, O = 0.f;
-    if (M > -INFINITY) {
-#pragma unroll
-      for (int i = 0; i < NG; ++i) {
-        const float w = __expf(mg[i] - M);  // empty group: exp(-inf) = 0
-        L += lg[i] * w;
-        O += og[i] * w;
-      }
-    }
     DL_STAMP(3, false);  // workgroup merge done
     if (n_splits == 1) {
       store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + tid, L > 0.f ? O / L : 0.f);

@@ -1,0 +1,278 @@
+// Body of the split-KV decode attention (F9 decode + F11: RoPE of q / new key, KV-slab append, ragged attention over an evicted
+// slab), shared by the launch path (attn_decode.hip: one 256-thread workgroup per (split, head, row)) and by the persistent decode
+// step (decode_persistent.hip: a 512-thread workgroup runs two such splits side by side).  Sharing the code is what makes the two
+// paths bit-identical: same key -> lane-group dealing, same online-softmax batching, same merge orders.
+//
+// Two parts, so that a caller can have the K/V rows in flight before the query exists:
+//   attn_split_issue  -- needs only kv_len / the slab: key range of the split, first K/V rows requested
+//   attn_split_finish -- needs the q (and, for the split that owns the new token, k / v) rows: RoPE, scores, online softmax,
+//                        P.V, the appended token, merge of the workgroup's lane groups -> (M, L, O[d]) for thread d < D
+#pragma once
+#include "dl_common.h"
+
+namespace dl {
+
+template <typename T, bool UPPER>
+__device__ __forceinline__ void rope16(const float (&own)[Elem<T>::kVec], const float (&par)[Elem<T>::kVec], const float (&cs)[Elem<T>::kVec],
+                                       const float (&sn)[Elem<T>::kVec], float (&out)[Elem<T>::kVec]) {
+#pragma unroll
+  for (int i = 0; i < Elem<T>::kVec; ++i)  // x*cos + rotate_half(x)*sin, each op rounded (DML:283-284); rotate_half = cat(-x2, x1)
+    out[i] = Elem<T>::round(Elem<T>::round(own[i] * cs[i]) + Elem<T>::round((UPPER ? par[i] : -par[i]) * sn[i]));
+}
+
+// sum over the LPK lanes that share one key (8, 16 or 32 lanes, aligned): DPP inside a 16-lane row, one crossbar step beyond it
+template <int LPK>
+__device__ __forceinline__ float lpk_sum(float a) {
+  if constexpr (LPK == 8) return row8_sum(a);
+  else if constexpr (LPK == 16) return row16_sum(a);
+  else if constexpr (LPK == 32) {
+    a = row16_sum(a);
+    return a + __shfl_xor(a, 16, 64);
+  } else {
+#pragma unroll
+    for (int w = LPK / 2; w > 0; w >>= 1) a += __shfl_xor(a, w, 64);
+    return a;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack_kv(const uint4& r, float (&f)[Elem<T>::kVec]) {
+  if constexpr (Elem<T>::kVec == 4) {
+    f[0] = __uint_as_float(r.x);
+    f[1] = __uint_as_float(r.y);
+    f[2] = __uint_as_float(r.z);
+    f[3] = __uint_as_float(r.w);
+  } else {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = Elem<T>::to_f((uint16_t)(w[i] & 0xffffu));
+      f[2 * i + 1] = Elem<T>::to_f((uint16_t)(w[i] >> 16));
+    }
+  }
+}
+
+// Geometry of one split: D/kVec lanes cooperate on one key (16 lanes x 16 B = one 256-byte K row for D=128 bf16), so a wave-wide load
+// is KPW full rows; NW waves = NG lane groups; U key rows per lane group are requested per loop trip.
+template <typename T, int D, int NW, int U>
+struct AttnSplitState {
+  static constexpr int V = Elem<T>::kVec;
+  static constexpr int LPK = D / V;
+  static constexpr int KPW = 64 / LPK;
+  static constexpr int NG = NW * KPW;
+  using S = typename Elem<T>::storage;
+  const S* kb;
+  const S* vb;
+  int T_old, Tn, chunk, k0, k1s, k1;
+  int wid, lane, g, c;  // wave inside the (virtual) workgroup, lane, lane group inside the wave, first head dim of this lane
+  bool spec;
+  bool ok[U];
+  uint4 kraw[U], vraw[U];
+};
+
+// Part 1.  `vtid`: thread index inside the (virtual) workgroup of NW waves.  Every load that does not depend on another load is
+// issued here, K/V first: a dependent HBM round trip costs ~1.5 us, so the latency is (number of round trips), not bytes.  With a
+// host-provided chunk (chunk_keys > 0, needs T_cap) the key range does not depend on kv_len either: the rows are requested
+// speculatively (any slot < T_cap is readable) and masked once kv_len[b] has arrived.
+template <typename T, int D, int NW, bool FUSED, int U>
+__device__ __forceinline__ void attn_split_issue(AttnSplitState<T, D, NW, U>& s, int vtid, const void* k_slab_, const void* v_slab_,
+                                                 int64_t stride_b, int64_t stride_h, int T_old, int extra, int b, int kvh, int split,
+                                                 int n_splits, int T_cap, int chunk_keys) {
+  using St = AttnSplitState<T, D, NW, U>;
+  using S = typename St::S;
+  constexpr int V = St::V, LPK = St::LPK, KPW = St::KPW, NG = St::NG;
+  s.lane = vtid & 63;
+  s.wid = vtid >> 6;
+  s.g = s.lane / LPK;
+  s.c = (s.lane % LPK) * V;
+  s.kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + s.c;
+  s.vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + s.c;
+  s.T_old = T_old;
+  s.spec = chunk_keys > 0 && T_cap > 0;
+  s.chunk = 0;
+  s.k0 = 0;
+  if (s.spec) {
+    s.chunk = (chunk_keys + NG - 1) / NG * NG;
+    s.k0 = split * s.chunk;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = min(s.k0 + (u * NW + s.wid) * KPW + s.g, T_cap - 1);
+      s.kraw[u] = *reinterpret_cast<const uint4*>(s.kb + (int64_t)key * D);
+      s.vraw[u] = *reinterpret_cast<const uint4*>(s.vb + (int64_t)key * D);
+    }
+  }
+  s.Tn = T_old + (FUSED ? 1 : extra);
+  if (!s.spec) {
+    s.chunk = (s.Tn + n_splits - 1) / n_splits;
+    s.chunk = (s.chunk + NG - 1) / NG * NG;
+    s.k0 = split * s.chunk;
+  }
+  // this split's keys [k0, k1s); with a host chunk the last split also takes whatever the host's length bound missed
+  s.k1s = (s.spec && split == n_splits - 1) ? s.Tn : min(s.Tn, s.k0 + s.chunk);
+  s.k1 = FUSED ? min(s.k1s, T_old) : s.k1s;  // ... of which [k0, k1) are read from the slab
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int key = s.k0 + (u * NW + s.wid) * KPW + s.g;
+    s.ok[u] = key < s.k1;
+    if (!s.spec) {
+      const int64_t off = (int64_t)(s.ok[u] ? key : (s.k0 < s.k1 ? s.k0 : 0)) * D;
+      s.kraw[u] = *reinterpret_cast<const uint4*>(s.kb + off);
+      s.vraw[u] = *reinterpret_cast<const uint4*>(s.vb + off);
+    }
+  }
+}
+
+// Part 2.  qrow / krow / vrow: the D-element q, k, v vectors of this head (un-rotated when FUSED; any address space).  cos_/sin_:
+// RoPE tables [n_pos, D]; pos: the new token's position.  sm_m/sm_l [NG], sm_o [NG][D]: LDS scratch of this (virtual) workgroup.
+// `write_kv`: this workgroup stores the new token's rotated key / value at slab slot T_old (one writer per kv head).
+// Contains ONE __syncthreads(): every wave of the real workgroup must call it.  Result for threads vtid < D: M, L (same for all)
+// and O = un-normalised output of head dim vtid.
+template <typename T, int D, int NW, bool FUSED, int U>
+__device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s, int vtid, const void* qrow_, const void* krow_,
+                                                  const void* vrow_, const void* cos_, const void* sin_, int n_pos, int pos, float scale,
+                                                  bool write_kv, int T_cap, float* sm_m, float* sm_l, float* sm_o, float& M_out, float& L_out,
+                                                  float& O_out) {
+  using St = AttnSplitState<T, D, NW, U>;
+  using S = typename St::S;
+  constexpr int V = St::V, LPK = St::LPK, KPW = St::KPW, NG = St::NG;
+  constexpr int HALF = D / 2;
+  const int c = s.c, g = s.g, wid = s.wid, lane = s.lane;
+  const int cpar = c < HALF ? c + HALF : c - HALF;
+  const S* qrow = reinterpret_cast<const S*>(qrow_);
+  float qv[V], cs[V], sn[V];
+  const bool owns_new = FUSED && s.T_old >= s.k0 && s.T_old < s.k1s && wid == 0 && g == 0;
+  float kn[V], vn[V];
+  if constexpr (FUSED) {
+    int p = pos;
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    float own[V], par[V], kown[V], kpar[V];
+    load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
+    load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
+    load16<T>(qrow + c, own);
+    load16<T>(qrow + cpar, par);
+    if (owns_new) {
+      const S* krow = reinterpret_cast<const S*>(krow_);
+      load16<T>(krow + c, kown);
+      load16<T>(krow + cpar, kpar);
+      load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
+    }
+    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
+    if (owns_new) {
+      if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
+    }
+  } else {
+    load16<T>(qrow + c, qv);
+  }
+
+  float m = -INFINITY, l = 0.f, o[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) o[i] = 0.f;
+
+  // keys of this workgroup are dealt round-robin: key = base + (u * NW + wid) * KPW + g
+  for (int base = s.k0; base < s.k1; base += NG * U) {
+    if (base != s.k0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int key = base + (u * NW + wid) * KPW + g;
+        s.ok[u] = key < s.k1;
+        const int64_t off = (int64_t)(s.ok[u] ? key : s.k0) * D;
+        s.kraw[u] = *reinterpret_cast<const uint4*>(s.kb + off);
+        s.vraw[u] = *reinterpret_cast<const uint4*>(s.vb + off);
+      }
+    }
+    float sc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kx[V];
+      unpack_kv<T>(s.kraw[u], kx);
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) a += qv[i] * kx[i];
+      a = lpk_sum<LPK>(a);
+      sc[u] = s.ok[u] ? a * scale : -INFINITY;
+    }
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u]);
+    if (mn > -INFINITY) {
+      const float alpha = __expf(m - mn);  // m = -inf -> 0
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] *= alpha;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float vx[V];
+        unpack_kv<T>(s.vraw[u], vx);
+        const float p = __expf(sc[u] - mn);  // masked key: exp(-inf) = 0
+        l += p;
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] += s.ok[u] ? p * vx[i] : 0.f;  // a speculatively read slot past the length may hold NaN bits
+      }
+      m = mn;
+    }
+  }
+
+  if constexpr (FUSED) {
+    // the new token (key index T_old): owned by lane group (wave 0, g 0) of the split whose range contains it
+    if (owns_new) {
+      if (write_kv && s.T_old < T_cap) {  // one writer per kv head; eviction = the length is simply not advanced later
+        S* kd = const_cast<S*>(s.kb) + (int64_t)s.T_old * D;
+        S* vd = const_cast<S*>(s.vb) + (int64_t)s.T_old * D;
+        store16<T>(kd, kn);
+        store16<T>(vd, vn);
+      }
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) a += qv[i] * kn[i];
+      a = lpk_sum<LPK>(a);
+      const float sc_ = a * scale;
+      const float mn = fmaxf(m, sc_);
+      const float alpha = __expf(m - mn);
+      const float p = __expf(sc_ - mn);
+      l = l * alpha + p;
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = o[i] * alpha + p * vn[i];
+      m = mn;
+    }
+  }
+
+  // merge the NG lane groups of this (virtual) workgroup
+  const int gg = wid * KPW + g;
+  if ((lane % LPK) == 0) {
+    sm_m[gg] = m;
+    sm_l[gg] = l;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) sm_o[gg * D + c + i] = o[i];
+  __syncthreads();
+  M_out = -INFINITY;
+  L_out = 0.f;
+  O_out = 0.f;
+  if (vtid < D) {
+    // NG <= 32 partials: every LDS read is issued before the first use (a rolled loop pays the LDS latency NG times over)
+    float mg[NG], lg[NG], og[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      mg[i] = sm_m[i];
+      lg[i] = sm_l[i];
+      og[i] = sm_o[i * D + vtid];
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) M = fmaxf(M, mg[i]);
+    float L = 0.f, O = 0.f;
+    if (M > -INFINITY) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const float w = __expf(mg[i] - M);  // empty group: exp(-inf) = 0
+        L += lg[i] * w;
+        O += og[i] * w;
+      }
+    }
+    M_out = M;
+    L_out = L;
+    O_out = O;
+  }
+}
+
+}  // namespace dl

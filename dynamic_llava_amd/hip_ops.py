@@ -35,6 +35,21 @@ class VpWeights(Structure):
     ]
 
 
+class DecodePhase(Structure):
+    """Mirror of DlDecodePhase (include/dynllava.h): one phase of the persistent decode step."""
+
+    _fields_ = [
+        ("kind", c_int32), ("flags", c_int32), ("N", c_int32), ("K", c_int32), ("in_region", c_int64), ("out_region", c_int64),
+        ("in_expect", c_int32), ("n_splits", c_int32), ("len_group", c_int32), ("reserved", c_int32),
+        ("W", c_void_p), ("norm_w", c_void_p), ("out", c_void_p), ("dump", c_void_p), ("k_slab", c_void_p), ("v_slab", c_void_p),
+    ]
+
+
+PHASE_EMBED, PHASE_GEMV, PHASE_ATTN = 0, 1, 2
+PHASE_ADDNORM, PHASE_OUT_SILU_PAIR, PHASE_OUT_GLOBAL, PHASE_HAS_DELTA = 1, 2, 4, 8
+REGION_QKV, REGION_ATTN, REGION_O, REGION_ACT, REGION_DN = 0, 1, 2, 3, 4
+
+
 class TpWeights(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln_w", "ln_b", "l1_w", "l1_b", "l3_w", "l3_b", "l5_w", "l5_b", "l7_w", "l7_b")]
 
@@ -82,6 +97,13 @@ SIGNATURES = {
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
+    "dl_decode_persistent_sync_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dl_decode_persistent_region": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int64)]),
+    "dl_decode_persistent": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    ),
     "dl_gemm_smallm_max_m": (c_int, []),
     "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "dl_gemm_smallm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -481,3 +503,37 @@ def silu_mul_parts(parts, out):
     assert parts.shape[1] == rows and parts.shape[2] == 2 * I
     _check(lib().dl_silu_mul_parts(_p(parts), parts.shape[0], _p(out), rows, I, dtype_code(out.dtype), _stream()), "dl_silu_mul_parts")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# persistent decode step (one launch per batch-1 decode step; include/dynllava.h)
+# ------------------------------------------------------------------------------------------------
+def decode_persistent_sync_bytes(n_phases, H, I, n_heads, n_kv_heads, head_dim, max_splits):
+    return int(lib().dl_decode_persistent_sync_bytes(int(n_phases), int(H), int(I), int(n_heads), int(n_kv_heads), int(head_dim), int(max_splits)))
+
+
+def decode_persistent_region(which, n_phases, H, I, n_heads, n_kv_heads, max_splits):
+    off = c_int64(0)
+    _check(lib().dl_decode_persistent_region(int(which), int(n_phases), int(H), int(I), int(n_heads), int(n_kv_heads), int(max_splits), ctypes.byref(off)), "dl_decode_persistent_region")
+    return int(off.value)
+
+
+def decode_phase_table(phases, device):
+    """list[DecodePhase] -> uint8 device tensor holding the packed table."""
+    arr = (DecodePhase * len(phases))(*phases)
+    buf = bytes(arr)
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
+
+
+def decode_persistent(table, n_phases, sync_buf, H, I, n_heads, n_kv_heads, head_dim, max_splits, eps, cos, sin, pos_base, kv_len0, kv_len1, cur_ids,
+                      slab_stride_h, T_cap, n_workgroups, dtype, spin_limit=0):
+    _dev(table, sync_buf, cos, sin, pos_base, kv_len0, kv_len1, cur_ids)
+    assert pos_base.dtype == torch.int32 and kv_len0.dtype == torch.int32 and kv_len1.dtype == torch.int32 and cur_ids.dtype == torch.int64
+    _check(
+        lib().dl_decode_persistent(
+            _p(table), int(n_phases), _p(sync_buf), sync_buf.numel() * sync_buf.element_size(), int(H), int(I), int(n_heads), int(n_kv_heads), int(head_dim),
+            int(max_splits), float(eps), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len0), _p(kv_len1), _p(cur_ids), int(slab_stride_h), int(T_cap),
+            int(n_workgroups), int(spin_limit), dtype_code(dtype), _stream(),
+        ),
+        "dl_decode_persistent",
+    )

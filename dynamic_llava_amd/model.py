@@ -410,6 +410,11 @@ class _DecodeState:
         self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
         self.graph = None
         self.graph_key = None
+        # persistent decode step (one launch per step): batch 1, 16-bit dtypes, head_dim 128
+        self.ptable = None
+        self.ptable_key = None
+        self.psync = None
+        self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
 
 
 class DynamicLlavaLlamaForCausalLM(nn.Module):
@@ -427,6 +432,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._prefill_graphs = {}
         self.use_hip_graph = True
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
+        self.use_persistent_decode = True  # batch-1 decode step as one persistent launch (falls back to the launch path where it does not apply)
         self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         self.smallm_max_decode_batch = 16  # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
@@ -773,7 +779,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         """Host mirrors of what `_prefill_run` did on the device (also the reference's in-place index shift, DML:1986-1994)."""
         cache.full_len_host = list(p["lens"])
         cache.seen_tokens = max(p["lens"])
-        cache.sparse_cap = cache.t_cap - (max(p["lens"]) - max(p["lens2"])) - p["instruct_drop"]  # host-known upper bound of the evicted group's lengths
+        cache.sparse_cap = cache.logical_cap - (max(p["lens"]) - max(p["lens2"])) - p["instruct_drop"]  # host-known upper bound of the evicted group's lengths
         if p["instruct_drop"]:  # DML:2365-2375
             for ix in indices:
                 ix["instruct"][1] -= p["instruct_drop"]
@@ -805,8 +811,84 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
+    def _persistent_ok(self, st: _DecodeState, cache: KVSlabCache) -> bool:
+        """Shapes the persistent decode step takes (everything else runs the launch path, which computes the same bits)."""
+        cfg = self.config
+        if not (self.use_persistent_decode and st.B == 1 and st.use_gemv and self.dtype in (torch.bfloat16, torch.float16)):
+            return False
+        nH, d, H, I = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
+        if d != 128 or H % 8 or I % 8 or H > 8192 or nH * d != H or st.n_cu < 8:
+            return False
+        ms = max(cache.n_splits(i, nH) for i in range(cfg.num_hidden_layers))
+        return ms <= 32 and nH * ((ms + 1) // 2) <= st.n_cu
+
+    def _persistent_table(self, st: _DecodeState, cache: KVSlabCache):
+        """Phase table of one decode step (device memory; rebuilt when the slab / split factors / buffers change)."""
+        cfg, sc = self.config, self.config.sparse_config
+        nH, nKV, d, H, I, V = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
+        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
+        splits = [cache.n_splits(i, nH) for i in range(L)]
+        key = (cache.slab.data_ptr(), cache.t_cap, tuple(splits), st.logits.data_ptr(), st.tp_x.data_ptr(), use_tp, SL)
+        if st.ptable is not None and st.ptable_key == key:
+            return st.ptable
+        n_ph = 2 + 5 * L
+        ms = max(splits)
+        reg = {k: ops.decode_persistent_region(k, n_ph, H, I, nH, nKV, ms) for k in (ops.REGION_QKV, ops.REGION_ATTN, ops.REGION_O, ops.REGION_ACT, ops.REGION_DN)}
+        G = st.n_cu
+        ph = []
+
+        def add(**kw):
+            e = ops.DecodePhase()
+            for k_, v_ in kw.items():
+                setattr(e, k_, v_)
+            ph.append(e)
+
+        add(kind=ops.PHASE_EMBED, W=self.model.embed_tokens.weight.data_ptr())
+        A, HD, PAIR, OUTG = ops.PHASE_ADDNORM, ops.PHASE_HAS_DELTA, ops.PHASE_OUT_SILU_PAIR, ops.PHASE_OUT_GLOBAL
+        for i, layer in enumerate(self.model.layers):
+            add(kind=ops.PHASE_GEMV, flags=A | (HD if i > 0 else 0), N=layer.w_qkv.shape[0], K=H, in_region=reg[ops.REGION_DN], in_expect=G, out_region=reg[ops.REGION_QKV],
+                W=layer.w_qkv.data_ptr(), norm_w=layer.input_layernorm.weight.data_ptr(), dump=st.tp_x.data_ptr() if (use_tp and i == SL) else None)
+            add(kind=ops.PHASE_ATTN, n_splits=splits[i], len_group=cache.group(i), k_slab=cache.k[i].data_ptr(), v_slab=cache.v[i].data_ptr())
+            add(kind=ops.PHASE_GEMV, flags=0, N=H, K=nH * d, in_region=reg[ops.REGION_ATTN], in_expect=nH, out_region=reg[ops.REGION_O], W=layer.self_attn.o_proj.weight.data_ptr())
+            add(kind=ops.PHASE_GEMV, flags=A | HD | PAIR, N=2 * I, K=H, in_region=reg[ops.REGION_O], in_expect=G, out_region=reg[ops.REGION_ACT], W=layer.w_gu.data_ptr(),
+                norm_w=layer.post_attention_layernorm.weight.data_ptr())
+            add(kind=ops.PHASE_GEMV, flags=0, N=H, K=I, in_region=reg[ops.REGION_ACT], in_expect=G, out_region=reg[ops.REGION_DN], W=layer.mlp.down_proj.weight.data_ptr())
+        add(kind=ops.PHASE_GEMV, flags=A | (HD if L > 0 else 0) | OUTG, N=V, K=H, in_region=reg[ops.REGION_DN], in_expect=G, W=self.lm_head.weight.data_ptr(),
+            norm_w=self.model.norm.weight.data_ptr(), out=st.logits.data_ptr())
+        assert len(ph) == n_ph
+        st.ptable = ops.decode_phase_table(ph, self.device)
+        st.ptable_key = key
+        st.p_n_phases, st.p_max_splits = n_ph, ms
+        nbytes = ops.decode_persistent_sync_bytes(n_ph, H, I, nH, nKV, d, ms)
+        if st.psync is None or st.psync.numel() * 4 < nbytes:
+            st.psync = torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
+        return st.ptable
+
+    def _decode_step_persistent(self, st: _DecodeState, cache: KVSlabCache):
+        """Batch-1 decode step as ONE persistent launch (csrc/decode_persistent.hip): same arithmetic as _decode_step_gemv, bit for bit."""
+        cfg, sc = self.config, self.config.sparse_config
+        tab = self._persistent_table(st, cache)
+        cos, sin = self._rope
+        ops.decode_persistent(tab, st.p_n_phases, st.psync, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                              st.p_max_splits, cfg.rms_norm_eps, cos, sin, cache.len_full, cache.lens[0], cache.lens[1], st.cur_ids, cache.k[0].stride(1), cache.t_cap,
+                              st.n_cu, self.dtype)
+        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and sc["sparse_layer"] < cfg.num_hidden_layers
+        if use_tp:  # F6 on the hidden state entering layer SL (dumped by the kernel); only the end-of-step length advance consumes it
+            self.model.output_text_score_predictor.decide(st.tp_x, st.tp_ws, st.tp_logits, st.decision)
+
+    def check_persistent(self):
+        """Raises if a persistent decode step gave up on an in-kernel wait (word 0 of its sync buffer; costs one device->host copy)."""
+        st = self._dstate
+        if st is not None and st.psync is not None:
+            code = int(st.psync[0].item())
+            if code != 0:
+                raise ops.HipOpsError(f"persistent decode step aborted (code {code:#x}): a workgroup was not resident or a producer never published")
+
     def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
-        if st.use_gemv:
+        if self._persistent_ok(st, cache):
+            self._decode_step_persistent(st, cache)
+        elif st.use_gemv:
             self._decode_step_gemv(st, cache)
         else:
             self._decode_step_gemm(st, cache)
@@ -903,6 +985,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         c.lens.zero_()
         c.full_len_host = [0] * B
         c.seen_tokens = 0
+        c.logical_cap = int(t_need)  # a pooled (possibly larger) slab must compute exactly like a fresh one of the requested size
+        c.sparse_cap = c.logical_cap
         return c
 
     def _get_dstate(self, B, out_cap):
@@ -927,7 +1011,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
     def _run_decode_steps(self, st, cache, n_steps):
         """Enqueue n greedy steps (graph replay when enabled)."""
-        key = (cache.slab.data_ptr(), cache.t_cap, cache.sparse_cap, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0), repr(self.config.sparse_config))
+        key = (self.use_persistent_decode, cache.slab.data_ptr(), cache.t_cap, cache.logical_cap, cache.sparse_cap, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0), repr(self.config.sparse_config))
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)
@@ -1093,7 +1177,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             cache.lens[1] += T
         cache.full_len_host = [n + T for n in cache.full_len_host]
         cache.seen_tokens += T
-        cache.sparse_cap = min(cache.t_cap, max(sparse_host) + T + (cache.t_cap - max(cache.full_len_host)))
+        cache.sparse_cap = min(cache.logical_cap, max(sparse_host) + T + (cache.logical_cap - max(cache.full_len_host)))
         logits = F.linear(x, self.lm_head.weight).float().view(B, T, -1)
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
 
@@ -1275,6 +1359,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 _score(produced - 1)
             if self._eos >= 0 and produced < max_new and bool(st.finished.min().item()):
                 break
+        if B == 1:
+            self.check_persistent()
         # host mirrors of what the device loop advanced: every row's un-evicted length grows by one per decode step
         cache.full_len_host = [n + produced - 1 for n in cache.full_len_host]
         cache.seen_tokens += produced - 1

@@ -199,6 +199,54 @@ int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_
             const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, int grid_cap,
             void* stream);
 
+/* ---- one whole batch-1 decode step as ONE persistent launch (replaces the per-layer chain dl_gemv x4 + dl_attn_decode_rope of
+ * DML:1011-1013 / 1127 / 328 / 2709 + DML:134-139 / 1289 / 1295 + DML:260-285 + CU:109-268 + DML:1114-1122, bit-identical to it).
+ * The caller describes the step as a phase table in DEVICE memory (built once per model / cache):
+ *   EMBED : h = W[cur_ids[0], :]                                    (W = embedding table [V, H])
+ *   GEMV  : y = W @ x.  flags: ADDNORM      x = norm_w * rmsnorm(h [+= delta]) (delta = the vector in in_region when HAS_DELTA)
+ *                              else         x = the vector in in_region (K elements)
+ *                              OUT_SILU_PAIR W = gate|up fused [2I, K]: y[n] = silu(W[n] x) * (W[I+n] x)
+ *                              OUT_GLOBAL   y written to `out` (model dtype, [N]) instead of out_region
+ *                       dump (optional, with ADDNORM): the updated residual stream h is also written there ([H], model dtype)
+ *                       in_expect: number of workgroups that publish in_region (grid size, or n_heads after an ATTN phase with
+ *                       n_splits > 1, or n_heads * ceil(n_splits / 2) ... see dl_decode_persistent_attn_publishers)
+ *   ATTN  : RoPE + KV append at slot kv_len + split-KV attention of one layer on the q|k|v vector of the preceding GEMV phase;
+ *           n_splits as dl_attn_decode_rope, len_group selects kv_len0 / kv_len1; output -> DL_REGION_ATTN.
+ * Regions are offsets (in 8-byte granules) into `sync_buf`, obtained from dl_decode_persistent_region.  sync_buf
+ * (dl_decode_persistent_sync_bytes) is zeroed by this call (memset node).  n_workgroups: 0 = one per CU.  Every in-kernel wait
+ * is bounded by spin_limit (0 = default); on give-up word 0 of sync_buf becomes non-zero (read it after a synchronisation). */
+#define DL_PHASE_EMBED 0
+#define DL_PHASE_GEMV 1
+#define DL_PHASE_ATTN 2
+#define DL_PHASE_ADDNORM 1
+#define DL_PHASE_OUT_SILU_PAIR 2
+#define DL_PHASE_OUT_GLOBAL 4
+#define DL_PHASE_HAS_DELTA 8
+#define DL_REGION_QKV 0
+#define DL_REGION_ATTN 1
+#define DL_REGION_O 2
+#define DL_REGION_ACT 3
+#define DL_REGION_DN 4
+typedef struct DlDecodePhase {
+  int32_t kind, flags;
+  int32_t N, K;
+  int64_t in_region, out_region;
+  int32_t in_expect, n_splits, len_group, reserved;
+  const void* W;
+  const void* norm_w;
+  void* out;
+  void* dump;
+  void* k_slab;
+  void* v_slab;
+} DlDecodePhase;
+int64_t dl_decode_persistent_sync_bytes(int n_phases, int H, int I, int n_heads, int n_kv_heads, int head_dim, int max_splits);
+int dl_decode_persistent_region(int which, int n_phases, int H, int I, int n_heads, int n_kv_heads, int max_splits,
+                                int64_t* offset_granules);
+int dl_decode_persistent(const DlDecodePhase* phases_dev, int n_phases, void* sync_buf, int64_t sync_bytes, int H, int I, int n_heads,
+                         int n_kv_heads, int head_dim, int max_splits, float eps, const void* cos_tab, const void* sin_tab, int n_pos,
+                         const int32_t* pos_base, const int32_t* kv_len0, const int32_t* kv_len1, const int64_t* cur_ids,
+                         int64_t slab_stride_h, int T_cap, int n_workgroups, int spin_limit, int dtype, void* stream);
+
 /* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
  * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;
  * out_ids[b, step[b]] = next[b]; ++step[b]; kv_len_full[b] += 1; kv_len_sparse[b] += decision ? decision[b] : 1.

@@ -425,6 +425,8 @@ class Oracle:
                 score = F.log_softmax(logit, dim=-1)[:, :, 0]  # DML:1867,1898
                 k = int(init_image_n * sc["vision_keep_rate"])  # DML:1899-1901
                 keep = topk_keep_index(score, k, self.tie_break)
+                if getattr(self, "force_keep_index", None) is not None:  # test hook: continue a comparison past a near-tied top-k boundary
+                    keep = self.force_keep_index.to(keep.device)
                 rec.update(vision_logit=logit, vision_score=score, keep_index=keep, predictor_input=img)
                 img_h = h[:, s0:s1, :]
                 kept = img_h.gather(dim=1, index=keep[..., None].expand(B, k, h.shape[2]))

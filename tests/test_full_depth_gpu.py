@@ -56,11 +56,17 @@ def test_configs1_32_layers_prefill_and_decode_vs_oracle():
         pos_ref, keep_ref = o.records["position_ids"], o.records["keep_index"]
         # kept-token index set: bit-exact unless the reference's own k-th score is inside the bf16 rounding band (then only
         # tokens inside that band may differ)
+        forced_keep = None
         if not torch.equal(keep_hip, keep_ref):
-            kth = torch.sort(score_hip[0], descending=True).values[114]
+            score_ref = o.records["vision_score"].float()
+            kth = torch.sort(score_ref[0], descending=True).values[114]
             diff = set(keep_hip[0].tolist()) ^ set(keep_ref[0].tolist())
-            assert all(abs(float(score_hip[0, t]) - float(kth)) <= 4 * 2.0**-7 * max(1.0, abs(float(kth))) for t in diff), diff
-            pytest.skip("near-tied kept sets differ inside the rounding band: downstream tensors legitimately differ")
+            assert all(abs(float(score_ref[0, t]) - float(kth)) <= 4 * 2.0**-7 * max(1.0, abs(float(kth))) for t in diff), (diff, float(kth))
+            # both sets are valid top-k sets of scores that agree to the last bf16 bit: continue with the HIP path's set on both sides
+            forced_keep = keep_hip
+            o.force_keep_index = forced_keep
+            l_ref, p_ref = o.forward(ids, image_features=feats.cpu())
+            pos_ref = o.records["position_ids"]
         assert torch.equal(pos_hip.long().view(-1), pos_ref.long().view(-1)), "position ids after compaction"
         ref_logits = [l_ref[0, -1].float()]
         dec_ref = []
@@ -70,6 +76,7 @@ def test_configs1_32_layers_prefill_and_decode_vs_oracle():
             dec_ref.append(int(o.records["text_decision"][0, 0]))
         del o, p_ref
         o32 = Oracle(cfg, sd, torch.float32)  # casts the bf16 tensors up: identical parameter values
+        o32.force_keep_index = keep_hip  # the fp32 run must follow the same kept set to be a ground truth for these logits
         l_32, p_32 = o32.forward(ids, image_features=feats.cpu().float())
         truth = [l_32[0, -1]]
         for j in range(n_steps):
