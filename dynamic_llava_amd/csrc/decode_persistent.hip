@@ -106,6 +106,8 @@ struct PParams {
   int64_t slab_stride_h;
   int T_cap;
   int spin_limit;
+  long long* stamps;         // debug: [n_phases][8] wall-clock stamps of workgroup `stamp_wg` (NULL in production)
+  int stamp_wg;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -126,36 +128,17 @@ __device__ __forceinline__ void poll_give_up(Poll& pl, uint32_t code) {
   __hip_atomic_store((gu32_t*)(pl.sync), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// wait until the 8 XCD-sharded arrival counters of phase `ph` sum to `expect` (hint only: the sweep validates tags)
-__device__ __forceinline__ void wait_hint(Poll& pl, const PParams& p, int ph, int expect) {
-  if (pl.dead) return;
-  const uint32_t* c = reinterpret_cast<const uint32_t*>(p.sync + p.r_cnt) + (int64_t)ph * 8;
-  const int lane = threadIdx.x & 63;
-  for (int spins = 0;; ++spins) {
-    uint32_t v = lane < 8 ? ctr_load(c + lane) : 0u;
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v = __builtin_amdgcn_readfirstlane(v);
-    if ((int)v >= expect) return;
-    if ((spins & 63) == 63 && poll_aborted(pl)) return;
-    if (spins > pl.spin_limit) {
-      poll_give_up(pl, 0x10000u | (uint32_t)ph);
-      return;
-    }
-    __builtin_amdgcn_s_sleep(8);
-  }
-}
-
-__device__ __forceinline__ void arrive(const PParams& p, int ph) {
-  uint32_t* c = reinterpret_cast<uint32_t*>(p.sync + p.r_cnt) + (int64_t)ph * 8 + (blockIdx.x & 7);
-  __hip_atomic_fetch_add((gu32_t*)(c), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Sweep `n_gr` granules of `region` (tag `tag`) into LDS words dst[i] = payload(granule i); the `n_thr` calling threads (wave
 // multiples; `t` = index of this thread among them) share the range.  Re-polls only what is still missing.
+// There is no separate "ready" flag to poll (a counter polled by 512 waves delayed its own increments by ~20 us): the sweep itself is
+// the poll, so it must not start long before the producers finish -- `t_first` (100 MHz wall clock; 0 = now) is the caller's estimate
+// of that moment (layers repeat: the previous layer's measured wait), `gap` the s_sleep between failed passes.
 template <int GU>
-__device__ __forceinline__ void sweep(Poll& pl, const u64_t* region, int n_gr, uint32_t tag, uint32_t* dst, int t, int n_thr, uint32_t code) {
+__device__ __forceinline__ void sweep(Poll& pl, const u64_t* region, int n_gr, uint32_t tag, uint32_t* dst, int t, int n_thr, uint32_t code,
+                                      long long t_first, int gap) {
+  if (t_first != 0) {
+    for (int spins = 0; wall_clock64() < t_first && spins < (1 << 16); ++spins) __builtin_amdgcn_s_sleep(8);
+  }
   for (int base = 0; base < n_gr; base += n_thr * GU) {
     u64_t v[GU];
     bool have[GU];
@@ -182,7 +165,9 @@ __device__ __forceinline__ void sweep(Poll& pl, const u64_t* region, int n_gr, u
         poll_give_up(pl, code);
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      if (gap > 32) __builtin_amdgcn_s_sleep(64);
+      else if (gap > 8) __builtin_amdgcn_s_sleep(24);
+      else __builtin_amdgcn_s_sleep(4);
     }
 #pragma unroll
     for (int k = 0; k < GU; ++k) {
@@ -290,6 +275,11 @@ __device__ __forceinline__ void consume(const Batch& b, int nvec, int lane, cons
 // the kernel.  Roles are split at the TOP level (two phase loops, same number of workgroup barriers per phase) so that each role gets
 // its own register allocation: the streamers' 128 VGPRs of in-flight weight batches never coexist with the pollers' sweep / norm state.
 // ---------------------------------------------------------------------------------------------------------------------------
+#define DL_PSTAMP(ph, slot)                                                                                  \
+  do {                                                                                                     \
+    if (p.stamps && (int)blockIdx.x == p.stamp_wg && lane == 0) p.stamps[(int64_t)(ph) * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+
 struct Lds {
   uint16_t* h;        // residual stream [Hpad]   (owned by poller wave 0)
   uint16_t* dbuf;     // gathered delta [Hpad]
@@ -297,18 +287,18 @@ struct Lds {
   float* sm_att;      // 2 x (m[16], l[16], o[16][128])
   uint32_t* qkvraw;   // q | k | v of this head, 3 x 64 words
   float* comb;        // [max_splits][D + kAttnPartPad]
-  int* cnt;           // [0] streamer arrivals (monotonic), [1] poller handshake (monotonic)
+  int* cnt;           // [1] poller handshake (monotonic); [8..23] per-poller wait estimates (10 ns ticks) by phase slot
+  const PhaseDev* tab; // the phase table, copied to LDS at kernel start (a descriptor read from global memory is a dependent ~2 us round trip)
 };
 
 // RoPE + KV append + split-KV attention of one layer; items (head, split pair) -> workgroups [0, n_heads * nv).  Run by ALL 8 waves of
 // the workgroups involved (three __syncthreads() for attention workgroups, two more for combiners: uniform per workgroup).
 template <typename T>
 __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, int ph, Poll& pl, const Lds& L, int tid, int lane, int wid,
-                                           int T_old, int pos) {
+                                           int T_old, int pos, long long t_first, int gap) {
   constexpr int D = kPD;
   constexpr int ANG = 16;  // lane groups of one 4-wave attention split
   const uint32_t tag = (uint32_t)ph + 1u;
-  const int G = gridDim.x;
   const int ns = d.n_splits;
   const int nv = (ns + 1) / 2;
   const int item = blockIdx.x;
@@ -325,13 +315,12 @@ __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, 
                                        p.T_cap, 0);
     // q | k | v of this head from the q|k|v phase's granules (pair u = elements 2u, 2u+1)
     if (wid == 6) {
-      wait_hint(pl, p, ph - 1, G);
-      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)hh * (D / 2), D / 2, tag - 1, L.qkvraw, lane, 64, 0x20000u | (uint32_t)ph);
+      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)hh * (D / 2), D / 2, tag - 1, L.qkvraw, lane, 64, 0x20000u | (uint32_t)ph, t_first, gap);
     } else if (wid == 7) {
-      wait_hint(pl, p, ph - 1, G);
-      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)(p.n_heads + kvh) * (D / 2), D / 2, tag - 1, L.qkvraw + D / 2, lane, 64, 0x20001u | (uint32_t)ph);
+      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)(p.n_heads + kvh) * (D / 2), D / 2, tag - 1, L.qkvraw + D / 2, lane, 64, 0x20001u | (uint32_t)ph,
+               t_first, gap);
       sweep<4>(pl, p.sync + p.r_qkv + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * (D / 2), D / 2, tag - 1, L.qkvraw + D, lane, 64,
-               0x20002u | (uint32_t)ph);
+               0x20002u | (uint32_t)ph, 0, gap);
     }
     __syncthreads();
     float M, Lsum, O;
@@ -383,9 +372,6 @@ __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, 
     }
     __syncthreads();
   }
-  // arrival hint of this phase: the workgroups that published attention outputs
-  const bool publishes = ns == 1 ? is_attn : item < p.n_heads;
-  if (publishes && tid == 0) arrive(p, ph);
 }
 
 // ---- streaming waves: weights only ----
@@ -395,7 +381,6 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
   const int G = gridDim.x;
   const int TW = G * kPS;
   int xsel = 0;
-  int n_gemv = 0;  // GEMV phases finished so far (the workgroup's streamer-arrival counter is monotonic)
   for (int ph = 0; ph < p.n_phases; ++ph) {
     // the thread index is re-materialised in every phase: otherwise the compiler hoists per-lane addresses / masks of every phase kind
     // out of this loop and keeps them alive across it
@@ -404,18 +389,17 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: batch descriptors / row pointers stay in SGPRs
     const int wgid = blockIdx.x * kPS + wid;
-    // every descriptor field is read NOW (a by-value copy): a descriptor load issued after the weight prefetch would be a vector load
-    // (the table is not provably unclobbered) whose wait drains the whole prefetch
-    const PhaseDev d = p.phases[ph];
+    const PhaseDev d = L.tab[ph];  // LDS copy of the table
     const uint32_t tag = (uint32_t)ph + 1u;
     if (d.kind == DL_PHASE_EMBED) continue;  // the poller that owns h loads it
     if (d.kind == DL_PHASE_ATTN) {
-      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos);
+      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos, 0, 0);
       continue;
     }
     const GemvGeom g = gemv_geom(d);
     const S* xs = L.x[xsel];
     xsel ^= 1;
+    if (wid == 0) DL_PSTAMP(ph, 0);
     // ---- the first two batches of this phase are requested BEFORE the input vector is waited for: the weight stream keeps running
     // through the exchange of the previous phase's results ----
     uint4 A[2][kPU], B[2][kPU];
@@ -450,7 +434,9 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
     bool v1 = v0 && next_batch(b0, b1);
     issue(b0, v0, g.W, g.nvec, lane, A);
     issue(b1, v1, g.W, g.nvec, lane, B);
+    if (wid == 0) DL_PSTAMP(ph, 1);
     __syncthreads();  // x of this phase is in LDS (gathered / normed by the pollers)
+    if (wid == 0) DL_PSTAMP(ph, 2);
 
     float acc0 = 0.f, acc1 = 0.f;
     uint32_t act_lo = 0;
@@ -495,13 +481,7 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
       v1 = v0 && next_batch(b0, b1);
       issue(b1, v1, g.W, g.nvec, lane, B);
     }
-    // arrival hint: the last streaming wave of this workgroup to finish the phase (all arrivals of phase k precede those of phase
-    // k + 1: the barrier in between needs every wave)
-    ++n_gemv;
-    if (lane == 0) {
-      const int old = atomicAdd(&L.cnt[0], 1);
-      if (old + 1 == kPS * n_gemv) arrive(p, ph);
-    }
+    if (wid == 0) DL_PSTAMP(ph, 3);
   }
 }
 
@@ -518,7 +498,15 @@ __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pw = wid - kPS;  // poller index 0..kPP-1
-    const PhaseDev d = p.phases[ph];
+    const PhaseDev d = L.tab[ph];
+    // when to start looking for this phase's input: the same phase slot of the previous layer told how long the producers take
+    // (layers are identical); before that is known, poll slowly
+    const long long t_enter = wall_clock64();
+    const int slot = ph % 5;
+    int* est = L.cnt + 8 + pw * 8 + slot;
+    const int e_prev = *est;
+    const long long t_first = e_prev > 0 ? t_enter + (long long)(e_prev - e_prev / 8) - 100 : 0;  // ~7/8 of the last wait, minus 1 us
+    const int gap = e_prev > 0 ? 4 : 48;
     if (d.kind == DL_PHASE_EMBED) {
       if (pw == 0) {  // h = embed[cur_id]
         const int64_t id = p.cur_ids[0];
@@ -528,20 +516,33 @@ __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll
       continue;
     }
     if (d.kind == DL_PHASE_ATTN) {
-      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos);
+      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos, t_first, gap);
+      if (lane == 0) *est = (int)(wall_clock64() - t_enter);
       continue;
     }
     const bool addnorm = (d.flags & DL_PHASE_ADDNORM) != 0;
     const bool has_delta = (d.flags & DL_PHASE_HAS_DELTA) != 0;
     S* xs = L.x[xsel];
     xsel ^= 1;
+    if (pw == 0) DL_PSTAMP(ph, 4);
+    // norm weights of this phase: requested before the wait (a load issued after it would add a dependent ~2.5 us round trip)
+    constexpr int MAXN = 16;  // 16-byte chunks per lane: H <= 8192
+    const int nvh = p.H / V;
+    uint4 nwv[MAXN];
+    if (addnorm && pw == 0) {
+#pragma unroll
+      for (int i = 0; i < MAXN; ++i)
+        if (lane + 64 * i < nvh) nwv[i] = ld_g16(d.norm_w + (lane + 64 * i) * V);
+    }
     if (has_delta || !addnorm) {
       const int in_gr = addnorm ? p.H / 2 : d.K / 2;
       const int prod = ph - 1;  // producer phase of the input region
-      wait_hint(pl, p, prod, d.in_expect);
+      if (pw == 0) DL_PSTAMP(ph, 5);
       sweep<kGU>(pl, p.sync + d.in_region, in_gr, (uint32_t)prod + 1u, reinterpret_cast<uint32_t*>(addnorm ? L.dbuf : xs), pw * 64 + lane, kPP * 64,
-                 0x40000u | (uint32_t)ph);
+                 0x40000u | (uint32_t)ph, t_first, gap);
+      if (lane == 0) *est = (int)(wall_clock64() - t_enter);
     }
+    if (pw == 0) DL_PSTAMP(ph, 6);
     if (addnorm) {
       // poller 0 waits for the other pollers' part of the delta (LDS handshake, no workgroup barrier: the streamers must not be held)
       if (has_delta) {
@@ -562,8 +563,6 @@ __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll
         // threads l, l + 64, l + 128, l + 192 of that 256-thread workgroup (chunks tid + 256 c), each with its own partial sum, reduced
         // per emulated wave and added in wave order -- bit-identical to the launch path.
         constexpr int MAXC = 4;
-        const int nvh = p.H / V;
-        gc16_t nw = d.norm_w;
         float ssw[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -593,18 +592,29 @@ __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll
 #pragma unroll
         for (int w = 0; w < 4; ++w) tsum += ssw[w];
         const float rstd = rsqrtf(tsum / (float)p.H + p.eps);
-        for (int v = lane; v < nvh; v += 64) {
-          float a[V], w[V];
-          unpack16<T>(*reinterpret_cast<const uint4*>(L.h + v * V), a);
-          unpack16<T>(ld_g16(nw + v * V), w);
 #pragma unroll
-          for (int e = 0; e < V; ++e) a[e] = w[e] * Elem<T>::round(a[e] * rstd);
-          store16<T>(xs + v * V, a);
+        for (int i = 0; i < MAXN; ++i) {
+          const int v = lane + 64 * i;
+          if (v < nvh) {
+            float a[V], w[V];
+            unpack16<T>(*reinterpret_cast<const uint4*>(L.h + v * V), a);
+            unpack16<T>(nwv[i], w);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] = w[e] * Elem<T>::round(a[e] * rstd);
+            store16<T>(xs + v * V, a);
+          }
         }
       }
     }
+    if (pw == 0) DL_PSTAMP(ph, 7);
     __syncthreads();  // x of this phase is ready for the streamers
   }
+}
+
+// tags / arrival counters / abort word start from zero on every call.  A kernel, not hipMemsetAsync: under stream capture the memset
+// node replayed a garbage fill pattern on ROCm 7.2 (observed: the buffer came back filled with a repeating 16-byte pointer pair).
+__global__ __launch_bounds__(256) void zero_sync_kernel(uint4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 template <typename T>
@@ -621,7 +631,14 @@ __global__ __launch_bounds__(kPT, 2) void decode_persistent_kernel(const PParams
   L.qkvraw = reinterpret_cast<uint32_t*>(L.sm_att + 2 * (2 * ANG + ANG * D));
   L.comb = reinterpret_cast<float*>(L.qkvraw + 3 * (D / 2));
   L.cnt = reinterpret_cast<int*>(L.comb + (int64_t)p.max_splits * (D + kAttnPartPad));
-  if (threadIdx.x < 8) L.cnt[threadIdx.x] = 0;
+  uint4* tab = reinterpret_cast<uint4*>(L.cnt + 32);
+  L.tab = reinterpret_cast<const PhaseDev*>(tab);
+  if (threadIdx.x < 32) L.cnt[threadIdx.x] = 0;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p.phases);
+    const int n16 = p.n_phases * (int)(sizeof(PhaseDev) / 16);
+    for (int i = threadIdx.x; i < n16; i += kPT) tab[i] = src[i];
+  }
   __syncthreads();
   Poll pl{p.sync, p.spin_limit, false};
   const int T0 = p.kv_len0[0], T1 = p.kv_len1[0], pos = p.pos_base[0];
@@ -656,13 +673,14 @@ PLayout p_layout(int n_phases, int H, int I, int n_heads, int n_kv_heads, int ma
   L.total = o;
   return L;
 }
-size_t p_lds_bytes(int H, int Kmax, int max_splits) {
+size_t p_lds_bytes(int H, int Kmax, int max_splits, int n_phases) {
   const int Hpad = (H + 7) / 8 * 8, Kpad = (Kmax + 7) / 8 * 8;
   size_t b = (size_t)(2 * Hpad + 2 * Kpad) * 2;
   b += (size_t)2 * (2 * 16 + 16 * kPD) * 4;
   b += (size_t)3 * (kPD / 2) * 4;
   b += (size_t)max_splits * (kPD + kAttnPartPad) * 4;
-  b += 8 * 4;
+  b += 32 * 4;
+  b += (size_t)n_phases * sizeof(DlDecodePhase);
   return (b + 15) / 16 * 16;
 }
 }  // namespace
@@ -689,7 +707,8 @@ extern "C" int dl_decode_persistent_region(int which, int n_phases, int H, int I
 extern "C" int dl_decode_persistent(const DlDecodePhase* phases_dev, int n_phases, void* sync_buf, int64_t sync_bytes, int H, int I, int n_heads,
                                     int n_kv_heads, int head_dim, int max_splits, float eps, const void* cos_tab, const void* sin_tab, int n_pos,
                                     const int32_t* pos_base, const int32_t* kv_len0, const int32_t* kv_len1, const int64_t* cur_ids,
-                                    int64_t slab_stride_h, int T_cap, int n_workgroups, int spin_limit, int dtype, void* stream) {
+                                    int64_t slab_stride_h, int T_cap, int n_workgroups, int spin_limit, void* debug_stamps, int debug_wg, int dtype,
+                                    void* stream) {
   DL_REQUIRE(phases_dev && sync_buf && cos_tab && sin_tab && pos_base && kv_len0 && kv_len1 && cur_ids, "dl_decode_persistent: NULL pointer");
   DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, "dl_decode_persistent: 16-bit dtypes only");
   DL_REQUIRE(head_dim == kPD, "dl_decode_persistent: head_dim must be %d", kPD);
@@ -710,7 +729,7 @@ extern "C" int dl_decode_persistent(const DlDecodePhase* phases_dev, int n_phase
   const PLayout L = p_layout(n_phases, H, I, n_heads, n_kv_heads, max_splits);
   DL_REQUIRE(sync_bytes >= L.total * 8, "dl_decode_persistent: sync buffer too small (%lld < %lld)", (long long)sync_bytes, (long long)(L.total * 8));
   const int Kmax = H > I ? H : I;
-  const size_t lds = p_lds_bytes(H, Kmax, max_splits);
+  const size_t lds = p_lds_bytes(H, Kmax, max_splits, n_phases);
   DL_REQUIRE(lds <= 160 * 1024, "dl_decode_persistent: %zu bytes of LDS needed", lds);
   hipStream_t st = as_stream(stream);
   PParams pp;
@@ -725,11 +744,12 @@ extern "C" int dl_decode_persistent(const DlDecodePhase* phases_dev, int n_phase
   pp.pos_base = pos_base; pp.kv_len0 = kv_len0; pp.kv_len1 = kv_len1; pp.cur_ids = cur_ids;
   pp.slab_stride_h = slab_stride_h; pp.T_cap = T_cap;
   pp.spin_limit = spin_limit > 0 ? spin_limit : (1 << 18);
-  // tags / arrival counters / abort word start from zero on every call (a memset node under graph capture)
-  if (hipMemsetAsync(sync_buf, 0, (size_t)L.total * 8, st) != hipSuccess) {
-    (void)hipGetLastError();
-    dl::set_error("dl_decode_persistent: memset of the sync buffer failed");
-    return DL_ERR_LAUNCH;
+  pp.stamps = reinterpret_cast<long long*>(debug_stamps);
+  pp.stamp_wg = debug_wg;
+  {
+    const int64_t n16 = L.total / 2;  // regions are 128-byte aligned: the total is a multiple of 16 granules
+    const int blocks = (int)((n16 + 255) / 256 < 512 ? (n16 + 255) / 256 : 512);
+    hipLaunchKernelGGL(zero_sync_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(sync_buf), n16);
   }
   auto go = [&](auto kfn) -> int {
     static std::once_flag attr_once;

@@ -102,7 +102,7 @@ SIGNATURES = {
     "dl_decode_persistent": (
         c_int,
         [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_int64, c_int, c_int, c_int, c_int, c_void_p],
+         c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     ),
     "dl_gemm_smallm_max_m": (c_int, []),
     "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
@@ -526,14 +526,14 @@ def decode_phase_table(phases, device):
 
 
 def decode_persistent(table, n_phases, sync_buf, H, I, n_heads, n_kv_heads, head_dim, max_splits, eps, cos, sin, pos_base, kv_len0, kv_len1, cur_ids,
-                      slab_stride_h, T_cap, n_workgroups, dtype, spin_limit=0):
+                      slab_stride_h, T_cap, n_workgroups, dtype, spin_limit=0, stamps=None, stamp_wg=0):
     _dev(table, sync_buf, cos, sin, pos_base, kv_len0, kv_len1, cur_ids)
     assert pos_base.dtype == torch.int32 and kv_len0.dtype == torch.int32 and kv_len1.dtype == torch.int32 and cur_ids.dtype == torch.int64
     _check(
         lib().dl_decode_persistent(
             _p(table), int(n_phases), _p(sync_buf), sync_buf.numel() * sync_buf.element_size(), int(H), int(I), int(n_heads), int(n_kv_heads), int(head_dim),
             int(max_splits), float(eps), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len0), _p(kv_len1), _p(cur_ids), int(slab_stride_h), int(T_cap),
-            int(n_workgroups), int(spin_limit), dtype_code(dtype), _stream(),
+            int(n_workgroups), int(spin_limit), _p(stamps), int(stamp_wg), dtype_code(dtype), _stream(),
         ),
         "dl_decode_persistent",
     )

@@ -872,7 +872,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cos, sin = self._rope
         ops.decode_persistent(tab, st.p_n_phases, st.psync, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                               st.p_max_splits, cfg.rms_norm_eps, cos, sin, cache.len_full, cache.lens[0], cache.lens[1], st.cur_ids, cache.k[0].stride(1), cache.t_cap,
-                              st.n_cu, self.dtype)
+                              st.n_cu, self.dtype, stamps=getattr(self, "_pstamps", None), stamp_wg=getattr(self, "_pstamp_wg", 0))
         use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and sc["sparse_layer"] < cfg.num_hidden_layers
         if use_tp:  # F6 on the hidden state entering layer SL (dumped by the kernel); only the end-of-step length advance consumes it
             self.model.output_text_score_predictor.decide(st.tp_x, st.tp_ws, st.tp_logits, st.decision)

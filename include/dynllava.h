@@ -213,8 +213,9 @@ int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_
  *   ATTN  : RoPE + KV append at slot kv_len + split-KV attention of one layer on the q|k|v vector of the preceding GEMV phase;
  *           n_splits as dl_attn_decode_rope, len_group selects kv_len0 / kv_len1; output -> DL_REGION_ATTN.
  * Regions are offsets (in 8-byte granules) into `sync_buf`, obtained from dl_decode_persistent_region.  sync_buf
- * (dl_decode_persistent_sync_bytes) is zeroed by this call (memset node).  n_workgroups: 0 = one per CU.  Every in-kernel wait
- * is bounded by spin_limit (0 = default); on give-up word 0 of sync_buf becomes non-zero (read it after a synchronisation). */
+ * (dl_decode_persistent_sync_bytes) is zeroed by this call (a small kernel ahead of the step).  n_workgroups: 0 = one per CU.  Every in-kernel wait
+ * is bounded by spin_limit (0 = default); on give-up word 0 of sync_buf becomes non-zero (read it after a synchronisation).
+ * debug_stamps (NULL in production): int64 [n_phases][8] wall-clock stamps (100 MHz) of workgroup debug_wg, tools/persistent_timeline.py. */
 #define DL_PHASE_EMBED 0
 #define DL_PHASE_GEMV 1
 #define DL_PHASE_ATTN 2
@@ -245,7 +246,8 @@ int dl_decode_persistent_region(int which, int n_phases, int H, int I, int n_hea
 int dl_decode_persistent(const DlDecodePhase* phases_dev, int n_phases, void* sync_buf, int64_t sync_bytes, int H, int I, int n_heads,
                          int n_kv_heads, int head_dim, int max_splits, float eps, const void* cos_tab, const void* sin_tab, int n_pos,
                          const int32_t* pos_base, const int32_t* kv_len0, const int32_t* kv_len1, const int64_t* cur_ids,
-                         int64_t slab_stride_h, int T_cap, int n_workgroups, int spin_limit, int dtype, void* stream);
+                         int64_t slab_stride_h, int T_cap, int n_workgroups, int spin_limit, void* debug_stamps, int debug_wg, int dtype,
+                         void* stream);
 
 /* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
  * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;
