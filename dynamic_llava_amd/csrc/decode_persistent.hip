@@ -130,15 +130,11 @@ __device__ __forceinline__ void poll_give_up(Poll& pl, uint32_t code) {
 
 // Sweep `n_gr` granules of `region` (tag `tag`) into LDS words dst[i] = payload(granule i); the `n_thr` calling threads (wave
 // multiples; `t` = index of this thread among them) share the range.  Re-polls only what is still missing.
-// There is no separate "ready" flag to poll (a counter polled by 512 waves delayed its own increments by ~20 us): the sweep itself is
-// the poll, so it must not start long before the producers finish -- `t_first` (100 MHz wall clock; 0 = now) is the caller's estimate
-// of that moment (layers repeat: the previous layer's measured wait), `gap` the s_sleep between failed passes.
+// There is no separate "ready" flag (a counter polled by 512 waves delayed its own increments by ~20 us): readiness is judged on a
+// sample of the granules themselves (wait_sample), then this sweep runs; `gap` selects the s_sleep between failed passes.
 template <int GU>
 __device__ __forceinline__ void sweep(Poll& pl, const u64_t* region, int n_gr, uint32_t tag, uint32_t* dst, int t, int n_thr, uint32_t code,
-                                      long long t_first, int gap) {
-  if (t_first != 0) {
-    for (int spins = 0; wall_clock64() < t_first && spins < (1 << 16); ++spins) __builtin_amdgcn_s_sleep(8);
-  }
+                                      int gap) {
   for (int base = 0; base < n_gr; base += n_thr * GU) {
     u64_t v[GU];
     bool have[GU];
@@ -174,6 +170,26 @@ __device__ __forceinline__ void sweep(Poll& pl, const u64_t* region, int n_gr, u
       const int idx = base + k * n_thr + t;
       if (idx < n_gr) dst[idx] = (uint32_t)v[k];
     }
+  }
+}
+
+// Cheap readiness poll: ONE 8-byte load per lane on a SAMPLE of the region -- `count` granules, `stride` apart, ending at the last
+// granule (for a GEMV phase: spread over the units of the last round, which finish last; for attention: one per head).  512 bytes
+// per pass instead of the 16-44 KB of a full sweep, so it can run for the whole producer phase without loading the fabric; the full
+// sweep that follows still validates every granule.
+__device__ __forceinline__ void wait_sample(Poll& pl, const u64_t* region, int n_gr, int count, int stride, uint32_t tag, int lane, uint32_t code) {
+  if (pl.dead || n_gr <= 0) return;
+  int idx = n_gr - 1 - (lane % count) * stride;
+  idx = idx < 0 ? 0 : idx;
+  for (int spins = 0;; ++spins) {
+    const u64_t v = gr_load(region + idx);
+    if (__all((uint32_t)(v >> 32) == tag)) return;
+    if ((spins & 63) == 63 && poll_aborted(pl)) return;
+    if (spins > pl.spin_limit) {
+      poll_give_up(pl, code);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(6);
   }
 }
 
@@ -275,9 +291,21 @@ __device__ __forceinline__ void consume(const Batch& b, int nvec, int lane, cons
 // the kernel.  Roles are split at the TOP level (two phase loops, same number of workgroup barriers per phase) so that each role gets
 // its own register allocation: the streamers' 128 VGPRs of in-flight weight batches never coexist with the pollers' sweep / norm state.
 // ---------------------------------------------------------------------------------------------------------------------------
+// one descriptor from the LDS copy of the table, every word made provably wave-uniform (SGPRs: scalar branches, scalar row pointers)
+__device__ __forceinline__ PhaseDev load_phase(const PhaseDev* tab, int ph) {
+  constexpr int NW = (int)(sizeof(PhaseDev) / 4);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(tab + ph);
+  uint32_t r[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);
+  PhaseDev d;
+  __builtin_memcpy(&d, r, sizeof(PhaseDev));
+  return d;
+}
+
 #define DL_PSTAMP(ph, slot)                                                                                  \
   do {                                                                                                     \
-    if (p.stamps && (int)blockIdx.x == p.stamp_wg && lane == 0) p.stamps[(int64_t)(ph) * 8 + (slot)] = wall_clock64(); \
+    if (p.stamps && lane == 0) p.stamps[((int64_t)blockIdx.x * p.n_phases + (ph)) * 8 + (slot)] = wall_clock64();       \
   } while (0)
 
 struct Lds {
@@ -287,7 +315,8 @@ struct Lds {
   float* sm_att;      // 2 x (m[16], l[16], o[16][128])
   uint32_t* qkvraw;   // q | k | v of this head, 3 x 64 words
   float* comb;        // [max_splits][D + kAttnPartPad]
-  int* cnt;           // [1] poller handshake (monotonic); [8..23] per-poller wait estimates (10 ns ticks) by phase slot
+  int* cnt;           // spare words
+  float* red;         // [4] partial sums of squares of the norm
   const PhaseDev* tab; // the phase table, copied to LDS at kernel start (a descriptor read from global memory is a dependent ~2 us round trip)
 };
 
@@ -295,7 +324,7 @@ struct Lds {
 // the workgroups involved (three __syncthreads() for attention workgroups, two more for combiners: uniform per workgroup).
 template <typename T>
 __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, int ph, Poll& pl, const Lds& L, int tid, int lane, int wid,
-                                           int T_old, int pos, long long t_first, int gap) {
+                                           int T_old, int pos) {
   constexpr int D = kPD;
   constexpr int ANG = 16;  // lane groups of one 4-wave attention split
   const uint32_t tag = (uint32_t)ph + 1u;
@@ -314,19 +343,21 @@ __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, 
     attn_split_issue<T, D, 4, true, 4>(st, vtid, (const void*)d.k_slab, (const void*)d.v_slab, 0, p.slab_stride_h, T_old, 1, 0, kvh, split, ns,
                                        p.T_cap, 0);
     // q | k | v of this head from the q|k|v phase's granules (pair u = elements 2u, 2u+1)
-    if (wid == 6) {
-      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)hh * (D / 2), D / 2, tag - 1, L.qkvraw, lane, 64, 0x20000u | (uint32_t)ph, t_first, gap);
+    if (wid == 6) DL_PSTAMP(ph, 0);
+    if (wid == 6) {  // small (192 granules per workgroup): the sweep itself is the poll
+      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)hh * (D / 2), D / 2, tag - 1, L.qkvraw, lane, 64, 0x20000u | (uint32_t)ph, 16);
     } else if (wid == 7) {
-      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)(p.n_heads + kvh) * (D / 2), D / 2, tag - 1, L.qkvraw + D / 2, lane, 64, 0x20001u | (uint32_t)ph,
-               t_first, gap);
+      sweep<4>(pl, p.sync + p.r_qkv + (int64_t)(p.n_heads + kvh) * (D / 2), D / 2, tag - 1, L.qkvraw + D / 2, lane, 64, 0x20001u | (uint32_t)ph, 16);
       sweep<4>(pl, p.sync + p.r_qkv + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * (D / 2), D / 2, tag - 1, L.qkvraw + D, lane, 64,
-               0x20002u | (uint32_t)ph, 0, gap);
+               0x20002u | (uint32_t)ph, 16);
     }
+    if (wid == 6) DL_PSTAMP(ph, 1);
     __syncthreads();
     float M, Lsum, O;
     float* sa = L.sm_att + vw * (2 * ANG + ANG * D);
     attn_split_finish<T, D, 4, true, 4>(st, vtid, L.qkvraw, L.qkvraw + D / 2, L.qkvraw + D, p.cos_tab, p.sin_tab, p.n_pos, pos, p.scale,
                                         hh % n_rep == 0, p.T_cap, sa, sa + ANG, sa + 2 * ANG, M, Lsum, O);
+    if (wid == 6) DL_PSTAMP(ph, 2);
     if (ns == 1) {
       // no merge needed: normalise, round, publish element pairs straight into the attention-output region
       if (vw == 0 && vtid < D) {
@@ -342,6 +373,7 @@ __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, 
         gr_store(pr + 1, tag, __float_as_uint(Lsum));
       }
     }
+    if (wid == 6) DL_PSTAMP(ph, 3);
     __syncthreads();  // qkvraw / sm_att are free again (a combiner role of this workgroup, or the next layer, reuses LDS)
   }
   if (ns > 1 && item < p.n_heads) {
@@ -362,6 +394,7 @@ __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, 
       const int s_ = i / kPartGr, e = i % kPartGr;
       L.comb[s_ * (D + kAttnPartPad) + (e < 2 ? e : e + 2)] = __uint_as_float((uint32_t)v);
     }
+    if (wid == 6) DL_PSTAMP(ph, 4);
     __syncthreads();
     if (tid < D) {
       float o1[1];
@@ -370,6 +403,7 @@ __device__ __forceinline__ void attn_phase(const PParams& p, const PhaseDev& d, 
       const uint32_t up = __shfl_down(mine, 1, 64);
       if ((tid & 1) == 0) gr_store(p.sync + p.r_attn + (int64_t)item * (D / 2) + tid / 2, tag, mine | (up << 16));
     }
+    if (wid == 6) DL_PSTAMP(ph, 5);
     __syncthreads();
   }
 }
@@ -389,16 +423,32 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: batch descriptors / row pointers stay in SGPRs
     const int wgid = blockIdx.x * kPS + wid;
-    const PhaseDev d = L.tab[ph];  // LDS copy of the table
+    const PhaseDev d = load_phase(L.tab, ph);
     const uint32_t tag = (uint32_t)ph + 1u;
-    if (d.kind == DL_PHASE_EMBED) continue;  // the poller that owns h loads it
+    constexpr int V = 8;
+    constexpr int MAXC = 4;  // residual-stream chunks per thread of waves 0..3 (thread t owns chunks t + 256 c: dl_gemv's ADDNORM map)
+    const int nvh = p.H / V;
+    if (d.kind == DL_PHASE_EMBED) {  // h = embed[cur_id]: every thread of waves 0..3 loads the chunks it owns
+      if (wid < 4) {
+        const int64_t id = p.cur_ids[0];
+        gc16_t row = d.W + id * (int64_t)p.H;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * 256;
+          if (v < nvh) *reinterpret_cast<uint4*>(L.h + v * V) = ld_g16(row + (int64_t)v * V);
+        }
+      }
+      continue;
+    }
     if (d.kind == DL_PHASE_ATTN) {
-      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos, 0, 0);
+      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos);
       continue;
     }
     const GemvGeom g = gemv_geom(d);
-    const S* xs = L.x[xsel];
+    S* xs = L.x[xsel];
     xsel ^= 1;
+    const bool addnorm = (d.flags & DL_PHASE_ADDNORM) != 0;
+    const bool has_delta = (d.flags & DL_PHASE_HAS_DELTA) != 0;
     if (wid == 0) DL_PSTAMP(ph, 0);
     // ---- the first two batches of this phase are requested BEFORE the input vector is waited for: the weight stream keeps running
     // through the exchange of the previous phase's results ----
@@ -435,7 +485,62 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
     issue(b0, v0, g.W, g.nvec, lane, A);
     issue(b1, v1, g.W, g.nvec, lane, B);
     if (wid == 0) DL_PSTAMP(ph, 1);
-    __syncthreads();  // x of this phase is in LDS (gathered / normed by the pollers)
+    if (addnorm) {
+      // h += delta (rounded), x = w * round(h * rstd): waves 0..3 replay dl_gemv's ADDNORM prologue (same chunk -> thread map, same
+      // summation order: bit-identical), while their weight batches are in flight.  The pollers gathered delta into dbuf.
+      uint4 wr[MAXC];
+      float a[MAXC][V];
+      if (wid < 4) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * 256;
+          if (v < nvh) wr[c] = ld_g16(d.norm_w + v * V);
+        }
+      }
+      __syncthreads();  // delta complete
+      if (wid == 0) DL_PSTAMP(ph, 5);
+      float ss = 0.f;
+      if (wid < 4) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * 256;
+          if (v < nvh) {
+            unpack16<T>(*reinterpret_cast<const uint4*>(L.h + v * V), a[c]);
+            if (has_delta) {
+              float dd[V];
+              unpack16<T>(*reinterpret_cast<const uint4*>(L.dbuf + v * V), dd);
+#pragma unroll
+              for (int e = 0; e < V; ++e) a[c][e] = Elem<T>::round(a[c][e] + dd[e]);
+              store16<T>(L.h + v * V, a[c]);
+            }
+            if (d.dump && blockIdx.x == 0) st_g16(d.dump + v * V, pack16<T>(a[c]));
+#pragma unroll
+            for (int e = 0; e < V; ++e) ss += a[c][e] * a[c][e];
+          }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) L.red[wid] = ss;
+      }
+      __syncthreads();
+      if (wid < 4) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tsum += L.red[i];
+        const float rstd = rsqrtf(tsum / (float)p.H + p.eps);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const int v = tid + c * 256;
+          if (v < nvh) {
+            float w[V];
+            unpack16<T>(wr[c], w);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[c][e] = w[e] * Elem<T>::round(a[c][e] * rstd);
+            store16<T>(xs + v * V, a[c]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // x of this phase is in LDS
     if (wid == 0) DL_PSTAMP(ph, 2);
 
     float acc0 = 0.f, acc1 = 0.f;
@@ -485,39 +590,22 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
   }
 }
 
-// ---- poller waves: gather the next input vector, residual add + RMSNorm (poller 0 owns h) ----
+// ---- poller waves: gather the next phase's input vector into LDS ----
 template <typename T>
 __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll& pl, int T0, int T1, int pos) {
   using S = uint16_t;
-  constexpr int V = 8;
+  const int TW = gridDim.x * kPS;
   int xsel = 0;
-  int n_delta = 0;  // HAS_DELTA phases so far (the poller handshake counter is monotonic)
   for (int ph = 0; ph < p.n_phases; ++ph) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pw = wid - kPS;  // poller index 0..kPP-1
-    const PhaseDev d = L.tab[ph];
-    // when to start looking for this phase's input: the same phase slot of the previous layer told how long the producers take
-    // (layers are identical); before that is known, poll slowly
-    const long long t_enter = wall_clock64();
-    const int slot = ph % 5;
-    int* est = L.cnt + 8 + pw * 8 + slot;
-    const int e_prev = *est;
-    const long long t_first = e_prev > 0 ? t_enter + (long long)(e_prev - e_prev / 8) - 100 : 0;  // ~7/8 of the last wait, minus 1 us
-    const int gap = e_prev > 0 ? 4 : 48;
-    if (d.kind == DL_PHASE_EMBED) {
-      if (pw == 0) {  // h = embed[cur_id]
-        const int64_t id = p.cur_ids[0];
-        gc16_t row = d.W + id * (int64_t)p.H;
-        for (int v = lane; v < p.H / V; v += 64) *reinterpret_cast<uint4*>(L.h + v * V) = ld_g16(row + (int64_t)v * V);
-      }
-      continue;
-    }
+    const PhaseDev d = load_phase(L.tab, ph);
+    if (d.kind == DL_PHASE_EMBED) continue;
     if (d.kind == DL_PHASE_ATTN) {
-      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos, t_first, gap);
-      if (lane == 0) *est = (int)(wall_clock64() - t_enter);
+      attn_phase<T>(p, d, ph, pl, L, tid, lane, wid, d.len_group == 0 ? T0 : T1, pos);
       continue;
     }
     const bool addnorm = (d.flags & DL_PHASE_ADDNORM) != 0;
@@ -525,89 +613,32 @@ __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll
     S* xs = L.x[xsel];
     xsel ^= 1;
     if (pw == 0) DL_PSTAMP(ph, 4);
-    // norm weights of this phase: requested before the wait (a load issued after it would add a dependent ~2.5 us round trip)
-    constexpr int MAXN = 16;  // 16-byte chunks per lane: H <= 8192
-    const int nvh = p.H / V;
-    uint4 nwv[MAXN];
-    if (addnorm && pw == 0) {
-#pragma unroll
-      for (int i = 0; i < MAXN; ++i)
-        if (lane + 64 * i < nvh) nwv[i] = ld_g16(d.norm_w + (lane + 64 * i) * V);
-    }
     if (has_delta || !addnorm) {
       const int in_gr = addnorm ? p.H / 2 : d.K / 2;
       const int prod = ph - 1;  // producer phase of the input region
-      if (pw == 0) DL_PSTAMP(ph, 5);
-      sweep<kGU>(pl, p.sync + d.in_region, in_gr, (uint32_t)prod + 1u, reinterpret_cast<uint32_t*>(addnorm ? L.dbuf : xs), pw * 64 + lane, kPP * 64,
-                 0x40000u | (uint32_t)ph, t_first, gap);
-      if (lane == 0) *est = (int)(wall_clock64() - t_enter);
-    }
-    if (pw == 0) DL_PSTAMP(ph, 6);
-    if (addnorm) {
-      // poller 0 waits for the other pollers' part of the delta (LDS handshake, no workgroup barrier: the streamers must not be held)
-      if (has_delta) {
-        ++n_delta;
-        if (pw != 0) {
-          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
-          if (lane == 0) __hip_atomic_fetch_add(&L.cnt[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-          const int want = (kPP - 1) * n_delta;
-          for (int spins = 0; __hip_atomic_load(&L.cnt[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++spins) {
-            if (spins > (1 << 24)) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
+      const uint32_t ptag = (uint32_t)prod + 1u;
+      // readiness sample: after an attention phase one granule per head (in_expect = n_heads publishers of 64 granules each), after
+      // a GEMV phase 64 granules spread over the units of its last round
+      int count, stride;
+      if (d.in_expect > 0 && d.in_expect < 64) {
+        count = d.in_expect;
+        stride = in_gr / d.in_expect;
+      } else {
+        const int last_round = in_gr - (in_gr - 1) / TW * TW;
+        count = last_round < 64 ? last_round : 64;
+        stride = last_round / count;
       }
-      if (pw == 0) {
-        // h += delta (rounded), x = w * round(h * rstd).  ONE wave replays the four waves of dl_gemv's ADDNORM prologue: lane l stands for
-        // threads l, l + 64, l + 128, l + 192 of that 256-thread workgroup (chunks tid + 256 c), each with its own partial sum, reduced
-        // per emulated wave and added in wave order -- bit-identical to the launch path.
-        constexpr int MAXC = 4;
-        float ssw[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          float ss = 0.f;
-          const int et = w * 64 + lane;  // emulated thread
-#pragma unroll
-          for (int c = 0; c < MAXC; ++c) {
-            const int v = et + c * 256;
-            if (v < nvh) {
-              float a[V];
-              unpack16<T>(*reinterpret_cast<const uint4*>(L.h + v * V), a);
-              if (has_delta) {
-                float dd[V];
-                unpack16<T>(*reinterpret_cast<const uint4*>(L.dbuf + v * V), dd);
-#pragma unroll
-                for (int e = 0; e < V; ++e) a[e] = Elem<T>::round(a[e] + dd[e]);
-                store16<T>(L.h + v * V, a);
-              }
-              if (d.dump && blockIdx.x == 0) st_g16(d.dump + v * V, pack16<T>(a));
-#pragma unroll
-              for (int e = 0; e < V; ++e) ss += a[e] * a[e];
-            }
-          }
-          ssw[w] = wave_sum(ss);
-        }
-        float tsum = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) tsum += ssw[w];
-        const float rstd = rsqrtf(tsum / (float)p.H + p.eps);
-#pragma unroll
-        for (int i = 0; i < MAXN; ++i) {
-          const int v = lane + 64 * i;
-          if (v < nvh) {
-            float a[V], w[V];
-            unpack16<T>(*reinterpret_cast<const uint4*>(L.h + v * V), a);
-            unpack16<T>(nwv[i], w);
-#pragma unroll
-            for (int e = 0; e < V; ++e) a[e] = w[e] * Elem<T>::round(a[e] * rstd);
-            store16<T>(xs + v * V, a);
-          }
-        }
-      }
+      wait_sample(pl, p.sync + d.in_region, in_gr, count, stride, ptag, lane, 0x50000u | (uint32_t)ph);
+      if (pw == 0) DL_PSTAMP(ph, 6);
+      sweep<kGU>(pl, p.sync + d.in_region, in_gr, ptag, reinterpret_cast<uint32_t*>(addnorm ? L.dbuf : xs), pw * 64 + lane, kPP * 64,
+                 0x40000u | (uint32_t)ph, 4);
     }
     if (pw == 0) DL_PSTAMP(ph, 7);
-    __syncthreads();  // x of this phase is ready for the streamers
+    if (addnorm) {
+      __syncthreads();  // delta complete (waves 0..3 do the residual add + norm)
+      __syncthreads();
+    }
+    __syncthreads();  // x of this phase is ready
   }
 }
 
@@ -631,6 +662,7 @@ __global__ __launch_bounds__(kPT, 2) void decode_persistent_kernel(const PParams
   L.qkvraw = reinterpret_cast<uint32_t*>(L.sm_att + 2 * (2 * ANG + ANG * D));
   L.comb = reinterpret_cast<float*>(L.qkvraw + 3 * (D / 2));
   L.cnt = reinterpret_cast<int*>(L.comb + (int64_t)p.max_splits * (D + kAttnPartPad));
+  L.red = reinterpret_cast<float*>(L.cnt + 24);
   uint4* tab = reinterpret_cast<uint4*>(L.cnt + 32);
   L.tab = reinterpret_cast<const PhaseDev*>(tab);
   if (threadIdx.x < 32) L.cnt[threadIdx.x] = 0;

@@ -215,7 +215,7 @@ int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_
  * Regions are offsets (in 8-byte granules) into `sync_buf`, obtained from dl_decode_persistent_region.  sync_buf
  * (dl_decode_persistent_sync_bytes) is zeroed by this call (a small kernel ahead of the step).  n_workgroups: 0 = one per CU.  Every in-kernel wait
  * is bounded by spin_limit (0 = default); on give-up word 0 of sync_buf becomes non-zero (read it after a synchronisation).
- * debug_stamps (NULL in production): int64 [n_phases][8] wall-clock stamps (100 MHz) of workgroup debug_wg, tools/persistent_timeline.py. */
+ * debug_stamps (NULL in production): int64 [n_workgroups][n_phases][8] wall-clock stamps (100 MHz), tools/persistent_timeline.py. */
 #define DL_PHASE_EMBED 0
 #define DL_PHASE_GEMV 1
 #define DL_PHASE_ATTN 2
