@@ -33,7 +33,7 @@ constexpr int kPU = 8;           // 16-byte chunks per row per batch
 constexpr int kPD = 128;         // head_dim
 constexpr int kPartGr = kPD + 2; // granules of one split partial: M, L, O[D]
 constexpr int kCtrlGr = 16;      // control granules at the start of the sync buffer (word 0: abort)
-constexpr int kGU = 16;          // granules per lane per sweep group
+constexpr int kGU = 44;          // granules per lane per sweep group (pollers: <= 6144 granules in one round trip)
 
 typedef unsigned long long u64_t;
 typedef __attribute__((address_space(1))) u64_t gu64_t;
@@ -135,24 +135,24 @@ __device__ __forceinline__ void poll_give_up(Poll& pl, uint32_t code) {
 template <int GU>
 __device__ __forceinline__ void sweep(Poll& pl, const u64_t* region, int n_gr, uint32_t tag, uint32_t* dst, int t, int n_thr, uint32_t code,
                                       int gap) {
+  static_assert(GU <= 64, "one bit per granule slot");
   for (int base = 0; base < n_gr; base += n_thr * GU) {
     u64_t v[GU];
-    bool have[GU];
-#pragma unroll
-    for (int k = 0; k < GU; ++k) have[k] = false;
+    u64_t have = 0;  // bit k: slot k holds a granule with the right tag (per lane)
     for (int spins = 0;; ++spins) {
+#pragma unroll
+      for (int k = 0; k < GU; ++k) {
+        const int idx = base + k * n_thr + t;
+        if (idx < n_gr && !((have >> k) & 1)) v[k] = gr_load(region + idx);
+      }
       bool ok = true;
 #pragma unroll
       for (int k = 0; k < GU; ++k) {
         const int idx = base + k * n_thr + t;
-        if (idx < n_gr && !have[k]) v[k] = gr_load(region + idx);
-      }
-#pragma unroll
-      for (int k = 0; k < GU; ++k) {
-        const int idx = base + k * n_thr + t;
-        if (idx < n_gr && !have[k]) {
-          have[k] = (uint32_t)(v[k] >> 32) == tag;
-          ok &= have[k];
+        if (idx < n_gr && !((have >> k) & 1)) {
+          const bool h = (uint32_t)(v[k] >> 32) == tag;
+          have |= (u64_t)h << k;
+          ok &= h;
         }
       }
       if (__all(ok) || pl.dead) break;
@@ -413,7 +413,6 @@ template <typename T>
 __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Poll& pl, int T0, int T1, int pos) {
   using S = uint16_t;
   const int G = gridDim.x;
-  const int TW = G * kPS;
   int xsel = 0;
   for (int ph = 0; ph < p.n_phases; ++ph) {
     // the thread index is re-materialised in every phase: otherwise the compiler hoists per-lane addresses / masks of every phase kind
@@ -422,7 +421,6 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: batch descriptors / row pointers stay in SGPRs
-    const int wgid = blockIdx.x * kPS + wid;
     const PhaseDev d = load_phase(L.tab, ph);
     const uint32_t tag = (uint32_t)ph + 1u;
     constexpr int V = 8;
@@ -471,15 +469,15 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
         return true;
       }
       n.sp = 0;
-      if (b.u + TW < g.n_units) {
-        n.u = b.u + TW;
+      if (b.u + kPS * G < g.n_units) {  // units are dealt to WORKGROUPS round-robin (u = k G + workgroup), wave = k mod kPS: the bytes
+        n.u = b.u + kPS * G;            // per CU are what bounds a phase (a CU streams ~25 GB/s), so CUs must get equal shares
         batch_rows(g, n);
         return true;
       }
       return false;
     };
-    b0.u = wgid;
-    bool v0 = wgid < g.n_units;
+    b0.u = wid * G + (int)blockIdx.x;
+    bool v0 = b0.u < g.n_units;
     if (v0) batch_rows(g, b0);
     bool v1 = v0 && next_batch(b0, b1);
     issue(b0, v0, g.W, g.nvec, lane, A);
@@ -594,7 +592,6 @@ __device__ __forceinline__ void streamer_loop(const PParams& p, const Lds& L, Po
 template <typename T>
 __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll& pl, int T0, int T1, int pos) {
   using S = uint16_t;
-  const int TW = gridDim.x * kPS;
   int xsel = 0;
   for (int ph = 0; ph < p.n_phases; ++ph) {
     int tid = threadIdx.x;
@@ -624,7 +621,9 @@ __device__ __forceinline__ void poller_loop(const PParams& p, const Lds& L, Poll
         count = d.in_expect;
         stride = in_gr / d.in_expect;
       } else {
-        const int last_round = in_gr - (in_gr - 1) / TW * TW;
+        const int G = gridDim.x;
+        int last_round = in_gr - (in_gr - 1) / G * G;  // units of the last dealing round (k = kmax) ...
+        if (in_gr > G) last_round += G;                // ... and the one before it (other waves of the same workgroups)
         count = last_round < 64 ? last_round : 64;
         stride = last_round / count;
       }

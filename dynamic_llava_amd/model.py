@@ -432,7 +432,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._prefill_graphs = {}
         self.use_hip_graph = True
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
-        self.use_persistent_decode = True  # batch-1 decode step as one persistent launch (falls back to the launch path where it does not apply)
+        # batch-1 decode step as ONE persistent launch (csrc/decode_persistent.hip): bit-identical to the launch path, but measured SLOWER on
+        # MI355X (3.56 vs 2.65 ms/token at 7B: DESIGN.md section 4b), so it is opt-in
+        self.use_persistent_decode = False
         self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         self.smallm_max_decode_batch = 16  # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
