@@ -14,6 +14,7 @@ ids = torch.randint(3, cfg.vocab_size, (55,), generator=g)
 prompt = torch.cat([torch.tensor([1]), ids[:34], torch.tensor([-200]), ids[35:]]).long()[None].cuda()
 images = torch.randn((1, 3, 336, 336), generator=g).to(torch.bfloat16).cuda()
 model.use_hip_graph = False
+model.use_persistent_decode = True
 n_ph = 2 + 5 * L
 G = torch.cuda.get_device_properties(0).multi_processor_count
 model._pstamps = torch.zeros((G, n_ph, 8), dtype=torch.int64, device="cuda")
