@@ -12,7 +12,13 @@ LLaVA-1.5-7B, bf16, B=1, one synthetic 336x336 image, prompt = 35 system tokens 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N > 1: weak scaling, one identical request per rank (weights replicated), one RCCL all-gather of the last-token
-logits + generated ids per step, no collective in the decode loop.  Rank 0 prints ONE JSON line.
+logits + generated ids per step, no collective in the decode loop.  The ranks' results must be identical (FATAL otherwise).
+After the timed region an N > 1 run also executes BASELINE configs[3] once (32 ragged requests per rank, one all-gather) and checks
+the gathered rows against a re-run of another rank's chunk.  Rank 0 prints ONE JSON line.
+
+The output-text predictor is random-init here: its keep/evict bit would saturate one way, so its final bias is calibrated on the
+workload itself (median of the keep-logit gap over a teacher-forced pass) until about half of the generated tokens are evicted from
+layers >= 2 -- the regime `output_text_keep_rate=0.5` names; `phases.evicted/generated` reports what the timed run did.
 """
 from __future__ import annotations
 
@@ -43,6 +49,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="decode steps as ONE persistent launch (opt-in: measured slower than the launch path, DESIGN.md 4b)")
     ap.add_argument("--predictor-gain", type=float, default=50.0, help="'trained-like' predictor scaling (no score ties); 1.0 = plain random init")
+    ap.add_argument("--no-calibrate", action="store_true", help="leave the random-init output-text predictor as is (it then keeps or evicts everything)")
     return ap.parse_args()
 
 
@@ -221,59 +228,49 @@ def other_kernel_rooflines(model, n_tokens):
     return res
 
 
-def cpu_baseline(new_tokens):
-    """The oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
-    LLaVA-1.5-7B layer width, bf16, the bench prompt, with 8 and 16 decoder layers (+ full-size predictors),
-    linearly extrapolated to 32 layers; CLIP ViT-L/14-336 + projector timed once and added."""
-    import torch.nn.functional as F  # noqa: F401
+def _pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
-    from oracle import fixtures as fx
+
+def cpu_baseline(model, prompt, images, new_tokens):
+    """The oracle (CPU restatement of the reference path, oracle/ref_cpu.py, bf16) on this box's host cores at FULL depth: the bench
+    model's own 32 distinct layers (state dict copied to the host), the bench prompt.  Bounded sample, SURVEY 8d protocol scaled to
+    ~25 s of CPU work: CLIP+projector+prefill 1 warm-up + 3 timed repetitions, decode 1 warm-up + 10 timed tokens; medians (p10 / p90
+    reported), value = (N + T_new) / (median prefill + (T_new - 1) x median decode step)."""
     from oracle.ref_cpu import Oracle
 
-    torch.manual_seed(0)
     threads = torch.get_num_threads()
-    dt = torch.bfloat16
-    times = {}
-    base_cfg = fx.llava7b_config(num_hidden_layers=1)
-    layer_sd = fx.make_state_dict(base_cfg, seed=0, dtype=dt, init="hf")
-    clip = fx.build_clip(base_cfg, seed=1, dtype=dt)
-    images = torch.randn(1, 3, 336, 336).to(dt)
-    prompt = fx.make_prompt(base_cfg, N_SYS, N_Q)[None]
-    for L in (8, 16):
-        cfg = fx.llava7b_config(num_hidden_layers=L)
-        sd = {k: v for k, v in layer_sd.items() if ".layers." not in k}
-        for i in range(L):  # all layers alias layer 0's tensors: timing does not depend on the values
-            for k, v in layer_sd.items():
-                if ".layers.0." in k:
-                    sd[k.replace(".layers.0.", f".layers.{i}.")] = v
-        o = Oracle(cfg, sd, dt, clip=clip)
-        best = None
-        with torch.no_grad():
-            for rep in range(3):  # first repetition = warm-up (thread pool, allocator, oneDNN primitive caches)
-                t0 = time.perf_counter()
-                feats = o.encode_images(images)
-                t1 = time.perf_counter()
-                logits, pkv = o.forward(prompt, image_features=feats)
-                t2 = time.perf_counter()
-                n_dec = 3
-                for _ in range(n_dec):
-                    logits, pkv = o.forward(logits[:, -1:].argmax(-1), past_key_values=pkv)
-                t3 = time.perf_counter()
-                cur = (t1 - t0, t2 - t1, (t3 - t2) / n_dec)
-                if rep > 0:
-                    best = cur if best is None else tuple(min(a, b) for a, b in zip(best, cur))
-        times[L] = best
-    clip_s = min(times[8][0], times[16][0])
-    prefill = times[8][1] + 3 * max(times[16][1] - times[8][1], 0.0)  # 32 layers = 8 + 3 x (16 - 8)
-    decode = times[8][2] + 3 * max(times[16][2] - times[8][2], 0.0)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if "vision_tower" not in k}
+    import copy as _copy
+
+    clip = _copy.deepcopy(model.model.vision_tower.vision_tower).cpu()
+    o = Oracle(model.config, sd, torch.bfloat16, clip=clip)
+    ids, img = prompt.cpu(), images.cpu()
+    pre, dec = [], []
+    pkv = logits = None
+    with torch.no_grad():
+        for rep in range(4):
+            t0 = time.perf_counter()
+            feats = o.encode_images(img)
+            logits, pkv = o.forward(ids, image_features=feats)
+            if rep > 0:
+                pre.append(time.perf_counter() - t0)
+        for j in range(11):
+            t0 = time.perf_counter()
+            logits, pkv = o.forward(logits[:, -1:].argmax(-1), past_key_values=pkv)
+            if j > 0:
+                dec.append(time.perf_counter() - t0)
     n_prompt = N_SYS + N_IMG + N_Q
-    total = clip_s + prefill + (new_tokens - 1) * decode
+    p50, d50 = _pct(pre, 0.5), _pct(dec, 0.5)
+    total = p50 + (new_tokens - 1) * d50
     return {
         "value": round((n_prompt + new_tokens) / total, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
-        "sample": f"oracle/ref_cpu.py bf16, 7B width, bench prompt N={n_prompt}: measured with 8 and 16 layers (prefill {times[8][1]:.2f}s/{times[16][1]:.2f}s, "
-                  f"decode {times[8][2]*1e3:.0f}/{times[16][2]*1e3:.0f} ms/token over 3 tokens, best of 2 after a warm-up), extrapolated linearly to 32 layers "
-                  f"(prefill {prefill:.2f}s, decode {decode*1e3:.0f} ms/token x {new_tokens - 1}) + CLIP+projector {clip_s:.2f}s measured once",
-        "prefill_tokens_per_s": round(n_prompt / (clip_s + prefill), 2), "decode_tokens_per_s": round(1.0 / decode, 3),
+        "sample": f"oracle/ref_cpu.py bf16, the bench model's 32 distinct layers + CLIP on the host, bench prompt N={n_prompt}: CLIP+projector+prefill "
+                  f"1 warm-up + {len(pre)} reps, decode 1 warm-up + {len(dec)} tokens; medians; step = prefill + {new_tokens - 1} decode steps",
+        "prefill_s": {"median": round(p50, 3), "p10": round(_pct(pre, 0.1), 3), "p90": round(_pct(pre, 0.9), 3)},
+        "decode_s_per_token": {"median": round(d50, 4), "p10": round(_pct(dec, 0.1), 4), "p90": round(_pct(dec, 0.9), 4)},
+        "prefill_tokens_per_s": round(n_prompt / p50, 2), "decode_tokens_per_s": round(1.0 / d50, 3),
     }
 
 
@@ -302,6 +299,108 @@ def ref_gpu_path(model, prompt, images, new_tokens):
             "prefill_tokens_per_s": round(n_prompt / t_pre, 1), "decode_tokens_per_s": round((new_tokens - 1) / max(t_full - t_pre, 1e-9), 2), "ms_per_step": round(t_full * 1e3, 2)}
 
 
+@torch.no_grad()
+def calibrate_text_predictor(model, prompt, images, n_tokens):
+    """Shift the final bias of the (random-init) output-text predictor so that about half of the tokens of THIS workload are evicted:
+    gap_j = keep logit - evict logit of decode step j along the model's own greedy continuation; bias[0] -= median(gap).  A few
+    rounds, because evicting tokens changes the later hidden states.  Deterministic (same weights / inputs on every rank)."""
+    tp = getattr(model.model, "output_text_score_predictor", None)
+    if tp is None:
+        return None
+    last = tp.output_mlp[7]
+    frac = None
+    for _ in range(4):
+        model.debug_records = {}
+        out = model(prompt, images=images)
+        pkv = out.past_key_values
+        tok = out.logits[:, -1].argmax(-1)
+        gaps = []
+        for _j in range(n_tokens - 1):
+            out = model(tok[:, None], past_key_values=pkv)
+            pkv = out.past_key_values
+            tl = model.debug_records["text_logit"]
+            gaps.append(float(tl[0, 0] - tl[0, 1]))
+            tok = out.logits[:, -1].argmax(-1)
+        model.debug_records = None
+        frac = sum(g > 0 for g in gaps) / max(len(gaps), 1)
+        if 0.4 <= frac <= 0.6:
+            break
+        med = sorted(gaps)[len(gaps) // 2]
+        last.bias.data[0] -= torch.tensor(med, dtype=last.bias.dtype, device=last.bias.device)
+    model._dstate = None  # predictor weights are read through cached pointers: nothing to rebuild, but captured graphs are re-made
+    model._prefill_graphs = {}
+    return frac
+
+
+def bimg_prompt_phase(model, images, reps=20):
+    """The reference's prefill harness (llava/dynamic_eval/bench_test/dynamic_llava_image_time_and_mem.py:124-151): input_ids
+    [[1, -200, 1]] (N = 578 -> 117 after layer 2), generate(max_new_tokens=1, min_new_tokens=1), event pairs around each call."""
+    ids = torch.tensor([[1, -200, 1]], device=images.device)
+    ts = []
+    for i in range(reps + 3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        model.generate(ids, images=images, do_sample=False, num_beams=1, use_cache=True, min_new_tokens=1, max_new_tokens=1)
+        b.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            ts.append(a.elapsed_time(b))
+    return {"prompt": "[[1,-200,1]] (BIMG:124), N=578 -> 117", "reps": reps, "prefill_ms_median": round(_pct(ts, 0.5), 3), "p10": round(_pct(ts, 0.1), 3),
+            "p90": round(_pct(ts, 0.9), 3), "prefill_tokens_per_s": round(578 / _pct(ts, 0.5) * 1e3, 1)}
+
+
+def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
+    """BASELINE configs[3]: 32 ragged requests per rank (256 over 8 GPUs), contiguous chunks (model_vqa_loader.py:30-38), one all-gather of
+    last-token logits + ids.  Rank 0 then re-runs the LAST rank's chunk and compares it with the gathered rows (fatal on mismatch)."""
+    per = 32
+    g = torch.Generator().manual_seed(1)
+    n_req = per * world
+    n_q = torch.randint(8, 65, (n_req,), generator=g).tolist()
+
+    def chunk(r):
+        idx = list(dd.get_chunk(list(range(n_req)), world, r))
+        gi = torch.Generator().manual_seed(100 + r)
+        W = max(35 + 1 + n_q[i] for i in idx)
+        ids = torch.zeros(len(idx), W, dtype=torch.long)
+        am = torch.zeros(len(idx), W, dtype=torch.long)
+        for row, i in enumerate(idx):
+            gq = torch.Generator().manual_seed(1000 + i)
+            body = torch.randint(3, cfg.vocab_size, (35 + n_q[i],), generator=gq)
+            p = torch.cat([torch.tensor([1]), body[:34], torch.tensor([-200]), body[35:]])
+            ids[row, : p.numel()] = p
+            am[row, : p.numel()] = 1
+        imgs = torch.randn((len(idx), 3, 336, 336), generator=gi).to(dtype)
+        return ids.to(device), am.to(device), imgs.to(device), sum(35 + 576 + n_q[i] for i in idx)
+
+    ids, am, imgs, n_prompt_tok = chunk(rank)
+
+    def run(i_, a_, im_):
+        out = model.generate(i_, attention_mask=a_, images=im_, max_new_tokens=new_tokens, eos_token_id=None)
+        return out, model.last_prefill_logits.float().clone()
+
+    run(ids, am, imgs)  # warm-up (graph capture, allocator)
+    dd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, lg = run(ids, am, imgs)
+    all_ids = dd.all_gather_rows(out)
+    all_lg = dd.all_gather_rows(lg)
+    torch.cuda.synchronize()
+    dd.barrier()
+    el = dd.max_over_ranks(time.perf_counter() - t0, device)
+    tot = dd.max_over_ranks(float(n_prompt_tok), device)  # not summed: report per-rank max and the global count below
+    ok = True
+    if rank == 0 and world > 1:
+        r = world - 1
+        i2, a2, im2, _ = chunk(r)
+        o2, l2 = run(i2, a2, im2)
+        ok = bool(torch.equal(all_ids[r * per:(r + 1) * per], o2) and torch.equal(all_lg[r * per:(r + 1) * per], l2))
+    n_tok_all = sum(35 + 576 + q for q in n_q) + n_req * new_tokens
+    return {"workload": f"BASELINE configs[3]: {n_req} ragged requests ({per} per rank, question lengths ~U[8,64]), {new_tokens} new tokens each, one all-gather",
+            "tokens_per_s": round(n_tok_all / el, 1), "seconds": round(el, 4), "gathered_rows": int(all_ids.shape[0]), "dp_equals_rerun_of_last_rank": ok,
+            "max_prompt_tokens_per_rank": int(tot)}
+
+
 def main():
     args = parse()
     from dynamic_llava_amd import dist as dd
@@ -322,6 +421,7 @@ def main():
     prompt, images = make_inputs(cfg, device, dtype)
     n_prompt = N_SYS + N_IMG + N_Q
     T_new = args.new_tokens
+    calib = None if args.no_calibrate else calibrate_text_predictor(model, prompt, images, T_new)
     gathered = {}
 
     def step():
@@ -343,14 +443,23 @@ def main():
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
     end_lens = model.last_cache.lens.cpu().tolist()  # KV lengths at the end of a full step (before the pooled slab is reset)
     dp_consistent = None
-    if world > 1:  # identical requests on every rank: the gathered rows must be identical (reported, never fatal)
-        dp_consistent = bool(gathered["ids"].shape[0] == world and all(torch.equal(gathered["ids"][0], gathered["ids"][r]) for r in range(world)))
+    c3 = None
+    if world > 1:  # identical requests on every rank: the gathered rows must be identical -- FATAL otherwise (a DP run whose ranks disagree measured nothing)
+        dp_consistent = bool(gathered["ids"].shape[0] == world and all(torch.equal(gathered["ids"][0], gathered["ids"][r]) for r in range(world))
+                             and all(torch.equal(gathered["logits"][0], gathered["logits"][r]) for r in range(world)))
+        if not dp_consistent:
+            raise SystemExit(f"rank {rank}: data-parallel ranks produced different results for identical requests")
+        c3 = configs3_leg(model, cfg, dd, rank, world, device, dtype)
+        if rank == 0 and not c3["dp_equals_rerun_of_last_rank"]:
+            raise SystemExit("configs[3] leg: gathered rows differ from a re-run of the last rank's chunk")
 
     if rank != 0:
         return
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * (n_prompt + T_new) * args.steps / elapsed
     # ---- phase split (outside the timed region) ----
+    out = model.generate(prompt, images=images, max_new_tokens=T_new, do_sample=False, num_beams=1, use_cache=True, eos_token_id=None)  # fresh run: end_lens of a step
+    end_lens = model.last_cache.lens.cpu().tolist()
     pre_ms = min(event_time_ms(lambda: model.generate(prompt, images=images, max_new_tokens=1, eos_token_id=None), 3, 1) for _ in range(2))
     dec_ms = (ms_per_step - pre_ms) / max(T_new - 1, 1)
     clip_ms = event_time_ms(lambda: model.encode_images(images), 5, 2)
@@ -385,10 +494,12 @@ def main():
         "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
                                f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
                    "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dp_rows_identical": dp_consistent, "hip_graph_decode": model.use_hip_graph,
-                   "predictor_gain": args.predictor_gain},
+                   "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib, "persistent_decode": bool(args.persistent)},
         "phases": {"prefill_ms": round(pre_ms, 3), "clip_projector_ms": round(clip_ms, 3), "decode_ms_per_token": round(dec_ms, 4),
                    "prefill_tokens_per_s": round(n_prompt / pre_ms * 1e3, 1), "decode_tokens_per_s": round(1e3 / dec_ms, 1),
                    "kv_len_full": t_full, "kv_len_sparse": t_sparse,
+                   "evicted/generated": f"{(N_SYS + 115 + N_Q + T_new - 1) - t_sparse}/{T_new - 1}",
+                   "bimg_prompt": bimg_prompt_phase(model, images) if world == 1 else None,
                    "decode_weight_stream_GBps": round(sum(p.numel() * p.element_size() for n, p in model.named_parameters() if ".layers." in n or n.startswith("lm_head")) / dec_ms / 1e6, 1)},
         # dominant kernel of the step by time (~84 % of a decode step, rocprof: profiles/): the hand-written weight-streaming GEMV
         "roofline": {"bound": "hbm", "achieved": roof_main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_main["frac"], "traffic": traffic, "traffic_source": traffic_src,
@@ -397,6 +508,8 @@ def main():
                      "note": "averaged over the 129 dl_gemv launches of one decode step replayed as one hipGraph between HIP events on the launch stream (includes inter-kernel gaps); the north_star's sparse-attention kernel is the first entry of roofline_kernels"},
         "roofline_kernels": extra,
     }
+    if c3 is not None:
+        res["configs3"] = c3
     if args.layers != 32:
         res["INVALID"] = f"debug run with {args.layers} layers"
     if world == 1 and not args.no_ref_gpu:
@@ -408,7 +521,7 @@ def main():
             res["ref_gpu_path"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(T_new)
+            res["cpu_baseline"] = cpu_baseline(model, prompt, images, T_new)
         except Exception as e:
             res["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(res))

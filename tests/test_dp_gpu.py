@@ -57,7 +57,14 @@ def _worker(rank, world, port, q):
     prompts, feats = _requests(cfg, dtype)
     mine = dd.get_chunk(list(range(N_REQ)), w, r)
     assert len(mine) == PER_RANK
-    ids, logits, lens = _run_chunk(model, prompts, feats, mine)
+    # the two ranks share ONE GPU here: they take turns, so that each generate() has the device to itself as it does on the 8-GPU
+    # node (with both running at once the library GEMMs of the B=32 decode step were seen to differ in the last bit from run to
+    # run -- work-partitioning that depends on which CUs are free -- which flips eviction decisions that sit on the boundary)
+    for turn in range(w):
+        if turn == r:
+            ids, logits, lens = _run_chunk(model, prompts, feats, mine)
+            torch.cuda.synchronize()
+        dd.barrier()
     all_ids = dd.all_gather_rows(ids)
     all_logits = dd.all_gather_rows(logits)
     all_lens = dd.all_gather_rows(lens)
@@ -75,7 +82,7 @@ def _worker(rank, world, port, q):
         ref_lens = torch.cat([x[2] for x in ref])
         kept = (ref_lens - torch.tensor([35 + 115 + p.shape[0] - 36 for p in prompts])).tolist()
         q.put(dict(ids=bool(torch.equal(all_ids, ref_ids)), logits=bool(torch.equal(all_logits, ref_logits)), lens=bool(torch.equal(all_lens, ref_lens)),
-                   shape=tuple(all_ids.shape), weights=ok_w, evicted_some=bool(0 < sum(kept) < N_REQ * (STEPS - 1))))
+                   shape=tuple(all_ids.shape), weights=ok_w, lens_diff=(all_lens - ref_lens).tolist(), evicted_some=bool(0 < sum(kept) < N_REQ * (STEPS - 1))))
     dd.barrier()
     torch.distributed.destroy_process_group()
 

@@ -555,3 +555,28 @@ def test_generate_then_forward_on_returned_cache_vs_oracle():
             model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=2, **bad)
     with pytest.raises(NotImplementedError):
         model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=2, do_sample=True, num_beams=3)
+
+
+def test_harness_long_text_kv_length_curve_matches_reference_golden(golden_dir):
+    """SURVEY A9 / BLTM:326-351: tools/harness_long_text_mem.py drives the reference's own loop and record format; the KV-length curve
+    (`past_key_values[0][-1][0].shape[-2]` after every call) must equal the one the REFERENCE produced (golden), and the dense layers'
+    length must grow by one per token."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("harness_long_text_mem", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "harness_long_text_mem.py"))
+    h = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(h)
+    name = "tiny_fp32_b1_gain50"
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    forced = torch.from_numpy(g["forced"]).cuda()  # [steps + 1, B]: the label ids the reference was teacher-forced with
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    rec = h.run(model, cfg, ids, forced.t().contiguous(), images, verbose=False)
+    n = forced.shape[0]
+    assert rec["kv_cache_length"] == [int(x) for x in g["kv_len_last"][:n]]
+    n_prompt = ids.shape[1] - 1 + fx.n_image_tokens(cfg)
+    # total_token_length follows the script's own accounting (images.shape[-2] * images.shape[-1] // 14 // 14 patches + text)
+    assert rec["total_token_length"][0] == n_prompt and rec["total_token_length"][-1] == n_prompt + n - 1
+    assert len(rec["max_memory"]) == n and all(m > 0 for m in rec["max_memory"])
