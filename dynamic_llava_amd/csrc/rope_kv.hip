@@ -105,3 +105,60 @@ extern "C" int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_
   DL_CHECK_LAUNCH("dl_rope_kv_write");
   return DL_OK;
 }
+
+// ---- in-place packing of the kept rows of a just-appended chunk (multi-round "new instruct" call: DML:2506-2521 decides per chunk
+// token whether its K/V stays in layers >= sparse_layer; the reference then slices / concatenates / zero-pads row by row on the host,
+// CU:165-241).  Every (K|V tensor, layer, row, kv head) is one workgroup: the chunk sits at slots [kv_len[b], kv_len[b] + T); the rows
+// with keep[b,t] != 0 move, in order, to [kv_len[b], kv_len[b] + n_keep).  dst <= src always, rows are moved in ascending rounds of
+// `kPackRows` (all sources of a round are in registers before any destination is written), so the move is safe in place.
+namespace dl {
+constexpr int kPackRows = 16;  // rows per round: 16 lanes x 16 bytes per row (head_dim 128 x 2 bytes), 256 threads
+
+__global__ __launch_bounds__(256) void kv_pack_rows_kernel(unsigned char* __restrict__ k0, unsigned char* __restrict__ v0, int64_t layer_stride_b,
+                                                            int64_t stride_b_b, int64_t stride_h_b, int row_bytes, int T_cap,
+                                                            const int32_t* __restrict__ keep, const int32_t* __restrict__ kv_len, int T) {
+  extern __shared__ int dst_of[];  // [T]: destination slot offset of chunk token t, or -1
+  const int h = blockIdx.x, b = blockIdx.y, lz = blockIdx.z;
+  const int layer = lz >> 1;
+  unsigned char* base = ((lz & 1) ? v0 : k0) + (int64_t)layer * layer_stride_b + (int64_t)b * stride_b_b + (int64_t)h * stride_h_b;
+  const int len = kv_len[b];
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int t = 0; t < T; ++t) dst_of[t] = keep[(int64_t)b * T + t] != 0 ? n++ : -1;
+  }
+  __syncthreads();
+  const int cpr = row_bytes / 16;            // 16-byte chunks per row
+  const int rows_par = 256 / cpr;            // rows moved per round
+  const int r = threadIdx.x / cpr, c = threadIdx.x % cpr;
+  for (int t0 = 0; t0 < T; t0 += rows_par) {
+    const int t = t0 + r;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    int d = -1;
+    if (r < rows_par && t < T) {
+      d = dst_of[t];
+      if (d >= 0 && d != t && len + t < T_cap) val = *reinterpret_cast<const uint4*>(base + (int64_t)(len + t) * row_bytes + c * 16);
+    }
+    __syncthreads();
+    if (d >= 0 && d != t && len + t < T_cap) *reinterpret_cast<uint4*>(base + (int64_t)(len + d) * row_bytes + c * 16) = val;
+    __syncthreads();
+  }
+}
+}  // namespace dl
+
+extern "C" int dl_kv_pack_rows(void* k_slab0, void* v_slab0, int64_t layer_stride, int n_layers, int64_t slab_stride_b, int64_t slab_stride_h,
+                               int T_cap, const int32_t* keep, const int32_t* kv_len, int B, int n_kv_heads, int T, int head_dim, int dtype,
+                               void* stream) {
+  DL_REQUIRE(k_slab0 && v_slab0 && keep && kv_len, "dl_kv_pack_rows: NULL pointer");
+  DL_REQUIRE(B > 0 && n_kv_heads > 0 && T >= 0 && n_layers >= 0 && T_cap > 0, "dl_kv_pack_rows: bad shape");
+  if (T == 0 || n_layers == 0) return DL_OK;
+  const int es = dtype == DL_F32 ? 4 : 2;
+  DL_REQUIRE(dtype == DL_F32 || dtype == DL_F16 || dtype == DL_BF16, "dl_kv_pack_rows: unsupported dtype %d", dtype);
+  const int row_bytes = head_dim * es;
+  DL_REQUIRE(row_bytes % 16 == 0 && row_bytes / 16 <= 256 && 256 % (row_bytes / 16) == 0, "dl_kv_pack_rows: head_dim=%d unsupported", head_dim);
+  DL_REQUIRE((size_t)T * sizeof(int) <= 48 * 1024, "dl_kv_pack_rows: chunk of %d tokens too long", T);
+  hipLaunchKernelGGL(dl::kv_pack_rows_kernel, dim3((unsigned)n_kv_heads, (unsigned)B, (unsigned)(2 * n_layers)), dim3(256), (size_t)T * sizeof(int),
+                     dl::as_stream(stream), reinterpret_cast<unsigned char*>(k_slab0), reinterpret_cast<unsigned char*>(v_slab0), layer_stride * es,
+                     slab_stride_b * es, slab_stride_h * es, row_bytes, T_cap, keep, kv_len, T);
+  DL_CHECK_LAUNCH("dl_kv_pack_rows");
+  return DL_OK;
+}

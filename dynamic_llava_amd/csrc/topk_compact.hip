@@ -120,3 +120,60 @@ extern "C" int dl_compact_tokens(const void* h_in, void* h_out, const int64_t* k
   DL_CHECK_LAUNCH("dl_compact_tokens");
   return DL_OK;
 }
+
+// ---- device-side prompt layout: one workgroup per row ----
+namespace dl {
+__global__ __launch_bounds__(256) void prompt_layout_kernel(const int64_t* __restrict__ ids, int W, int n_feat, int image_token, int u0, int u1,
+                                                             int32_t* __restrict__ seg, int64_t* __restrict__ text_src,
+                                                             int64_t* __restrict__ text_dst, int64_t* __restrict__ img_dst,
+                                                             int32_t* __restrict__ img_start, int32_t* __restrict__ err) {
+  __shared__ int s_pos, s_cnt, s_user;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t* row = ids + (int64_t)b * W;
+  if (tid == 0) {
+    s_pos = W;
+    s_cnt = 0;
+    s_user = -1;
+  }
+  __syncthreads();
+  for (int c = tid; c < W; c += 256)
+    if (row[c] == (int64_t)image_token) {
+      atomicMin(&s_pos, c);
+      atomicAdd(&s_cnt, 1);
+    }
+  __syncthreads();
+  const int p = s_pos < W ? s_pos : 0;
+  // last "USER:" pair inside the instruct span (columns p+1 .. W-1), as an offset from its start (ARCH:418-454 with no labels: the
+  // span runs to the end of the row)
+  for (int c = p + 1 + tid; c + 1 < W; c += 256)
+    if (row[c] == (int64_t)u0 && row[c + 1] == (int64_t)u1) atomicMax(&s_user, c - (p + 1));
+  __syncthreads();
+  const int n_row = W - 1 + n_feat;  // packed rows of this sequence
+  const int64_t base = (int64_t)b * n_row;
+  for (int c = tid; c < W; c += 256) {
+    if (c == p) continue;
+    const int j = c < p ? c : c - 1;  // index among the text tokens
+    text_src[(int64_t)b * (W - 1) + j] = (int64_t)b * W + c;
+    text_dst[(int64_t)b * (W - 1) + j] = base + (c < p ? c : c - 1 + n_feat);
+  }
+  for (int i = tid; i < n_feat; i += 256) img_dst[(int64_t)b * n_feat + i] = base + p + i;
+  if (tid == 0) {
+    seg[b * 8 + 0] = p;
+    seg[b * 8 + 1] = s_user < 0 ? 0 : s_user;
+    seg[b * 8 + 2] = s_cnt;
+    seg[b * 8 + 3] = W;
+    img_start[b] = p;
+    if (s_cnt != 1) atomicMax(err, 1 + b);
+  }
+}
+}  // namespace dl
+
+extern "C" int dl_prompt_layout(const int64_t* input_ids, int B, int W, int n_feat, int image_token, int user_id0, int user_id1, int32_t* seg,
+                                int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, void* stream) {
+  DL_REQUIRE(input_ids && seg && text_src && text_dst && img_dst && img_start && err, "dl_prompt_layout: NULL pointer");
+  DL_REQUIRE(B > 0 && W > 0 && n_feat >= 0, "dl_prompt_layout: bad shape");
+  hipLaunchKernelGGL(dl::prompt_layout_kernel, dim3((unsigned)B), dim3(256), 0, dl::as_stream(stream), input_ids, W, n_feat, image_token, user_id0,
+                     user_id1, seg, text_src, text_dst, img_dst, img_start, err);
+  DL_CHECK_LAUNCH("dl_prompt_layout");
+  return DL_OK;
+}

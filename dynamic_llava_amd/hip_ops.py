@@ -97,6 +97,8 @@ SIGNATURES = {
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
+    "dl_kv_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dl_decode_persistent_sync_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "dl_decode_persistent_region": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int64)]),
     "dl_decode_persistent": (
@@ -536,4 +538,41 @@ def decode_persistent(table, n_phases, sync_buf, H, I, n_heads, n_kv_heads, head
             int(n_workgroups), int(spin_limit), _p(stamps), int(stamp_wg), dtype_code(dtype), _stream(),
         ),
         "dl_decode_persistent",
+    )
+
+
+def kv_pack_rows(k_slab0, v_slab0, layer_stride, n_layers, keep, kv_len, T_cap):
+    """Pack the kept rows of a just-appended T-token chunk in place, for n_layers consecutive layer slabs (see include/dynllava.h).
+    k_slab0 / v_slab0: [B, nKV, T_cap, d] views of the first layer; keep int32 [B, T]; kv_len int32 [B] (not modified)."""
+    _dev(k_slab0, v_slab0, keep, kv_len)
+    assert keep.dtype == torch.int32 and keep.is_contiguous() and kv_len.dtype == torch.int32 and k_slab0.stride() == v_slab0.stride() and k_slab0.stride(3) == 1
+    B, nKV, _, d = k_slab0.shape
+    _check(
+        lib().dl_kv_pack_rows(_p(k_slab0), _p(v_slab0), int(layer_stride), int(n_layers), k_slab0.stride(0), k_slab0.stride(1), int(T_cap), _p(keep), _p(kv_len), B, nKV,
+                              keep.shape[1], d, dtype_code(k_slab0.dtype), _stream()),
+        "dl_kv_pack_rows",
+    )
+
+
+def prompt_layout(input_ids, n_feat, image_token, user_ids):
+    """Device-side layout of un-padded one-image-per-row prompts (include/dynllava.h).  Returns dict of device tensors."""
+    _dev(input_ids)
+    assert input_ids.dtype == torch.int64 and input_ids.is_contiguous() and input_ids.dim() == 2
+    B, W = input_ids.shape
+    dev = input_ids.device
+    out = dict(
+        seg=torch.zeros((B, 8), dtype=torch.int32, device=dev), text_src=torch.empty(B * (W - 1), dtype=torch.int64, device=dev),
+        text_dst=torch.empty(B * (W - 1), dtype=torch.int64, device=dev), img_dst=torch.empty(B * n_feat, dtype=torch.int64, device=dev),
+        img_start=torch.empty(B, dtype=torch.int32, device=dev), err=torch.zeros(1, dtype=torch.int32, device=dev),
+    )
+    prompt_layout_into(input_ids, n_feat, image_token, user_ids, out)
+    return out
+
+
+def prompt_layout_into(input_ids, n_feat, image_token, user_ids, out):
+    B, W = input_ids.shape
+    _check(
+        lib().dl_prompt_layout(_p(input_ids), B, W, int(n_feat), int(image_token), int(user_ids[0]), int(user_ids[1]), _p(out["seg"]), _p(out["text_src"]), _p(out["text_dst"]),
+                               _p(out["img_dst"]), _p(out["img_start"]), _p(out["err"]), _stream()),
+        "dl_prompt_layout",
     )

@@ -431,6 +431,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._dstate = None
         self._prefill_graphs = {}
         self.use_hip_graph = True
+        self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
         # batch-1 decode step as ONE persistent launch (csrc/decode_persistent.hip): bit-identical to the launch path, but measured SLOWER on
         # MI355X (3.56 vs 2.65 ms/token at 7B: DESIGN.md section 4b), so it is opt-in
@@ -513,41 +514,56 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         B, W = ids_host.shape
         am = None if attention_mask is None else attention_mask.detach().to("cpu").bool()
         lab = None if labels is None else labels.detach().to("cpu")
-        lens, indices, text_src, text_dst, img_dst, img_rows = [], [], [], [], [], []
+        lens, indices, text_src, text_dst, img_dst, img_rows, img_src = [], [], [], [], [], [], []
         base, img_i = 0, 0
+        maxlen = getattr(self.config, "tokenizer_model_max_length", None)  # ARCH:493-506: every row is cut to this many embeddings
+        truncated = False
         for b in range(B):
             cols = list(range(W)) if am is None else torch.nonzero(am[b]).flatten().tolist()
             r = [int(ids_host[b, c]) for c in cols]
             lr = None if lab is None else [int(lab[b, c]) for c in cols]
             n_images = r.count(IMAGE_TOKEN_INDEX)
             if n_feat == 0 or n_images == 0:  # ARCH:315-324: a text-only row consumes (and ignores) one image feature
-                text_src += [b * W + c for c in cols]
-                text_dst += list(range(base, base + len(r)))
-                lens.append(len(r))
+                n = len(r) if maxlen is None else min(len(r), maxlen)
+                truncated |= n < len(r)
+                text_src += [b * W + c for c in cols[:n]]
+                text_dst += list(range(base, base + n))
+                lens.append(n)
                 indices.append(None)
-                base += len(r)
+                base += n
                 img_i += 1
                 continue
             if n_images != 1:
                 raise NotImplementedError("exactly one <image> per row (ARCH:330-332 calls .item() on the position)")
             seg = self._segments(r, lr, n_feat)
             p = seg["system"][1]
-            text_src += [b * W + c for j, c in enumerate(cols) if j != p]
-            text_dst += list(range(base, base + p)) + list(range(base + p + n_feat, base + len(r) - 1 + n_feat))
-            img_dst += list(range(base + p, base + p + n_feat))
+            # row-local destinations, then the cut at tokenizer_model_max_length, then the packed offsets
+            t_src = [b * W + c for j, c in enumerate(cols) if j != p]
+            t_dst = list(range(0, p)) + list(range(p + n_feat, len(r) - 1 + n_feat))
+            i_dst = list(range(p, p + n_feat))
+            n = len(r) - 1 + n_feat
+            if maxlen is not None and n > maxlen:
+                truncated = True
+                n = maxlen
+                keep_t = [k for k, dd_ in enumerate(t_dst) if dd_ < n]
+                t_src, t_dst = [t_src[k] for k in keep_t], [t_dst[k] for k in keep_t]
+                i_dst = [dd_ for dd_ in i_dst if dd_ < n]
+                for key in seg:  # ARCH:502-506
+                    seg[key] = [min(seg[key][0], n), min(seg[key][1], n)]
+            text_src += t_src
+            text_dst += [base + dd_ for dd_ in t_dst]
+            img_dst += [base + dd_ for dd_ in i_dst]
+            img_src += [img_i * n_feat + (dd_ - p) for dd_ in i_dst]
             img_rows.append(img_i)
             img_i += 1
-            n = len(r) - 1 + n_feat
             lens.append(n)
             indices.append(seg)
             base += n
-        maxlen = getattr(self.config, "tokenizer_model_max_length", None)
-        if maxlen is not None and max(lens) > maxlen:
-            raise NotImplementedError("truncation to tokenizer_model_max_length (ARCH:493-506) is not built")
         if all(i is None for i in indices):
             indices = None
         sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, hash(tuple(text_src)), len(text_src))
-        return dict(sig=sig, B=B, lens=lens, indices=indices, text_src=text_src, text_dst=text_dst, img_dst=img_dst, img_rows=img_rows, total=base, n_feat=n_feat)
+        return dict(sig=sig, B=B, lens=lens, indices=indices, text_src=text_src, text_dst=text_dst, img_dst=img_dst, img_rows=img_rows, total=base, n_feat=n_feat,
+                    img_src=img_src if truncated else None)
 
     def _assemble(self, lay, dev_idx, input_ids, image_features):
         """Device-only: packed embeds [total,H] from token ids + projector output (index_copy, no host sync)."""
@@ -555,7 +571,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         embeds = torch.empty((lay["total"], H), dtype=self.dtype, device=self.device)
         ids = input_ids.reshape(-1).index_select(0, dev_idx["text_src"])
         embeds.index_copy_(0, dev_idx["text_dst"], self.model.embed_tokens(ids))
-        if lay["img_dst"]:
+        if lay["img_dst"] and lay.get("img_src") is not None:  # rows cut inside their image span: only some features are placed
+            f = image_features.to(self.dtype).reshape(-1, H).index_select(0, dev_idx["img_src"])
+            embeds.index_copy_(0, dev_idx["img_dst"], f)
+        elif lay["img_dst"]:
             f = image_features.to(self.dtype)
             if len(lay["img_rows"]) != f.shape[0] or lay["img_rows"] != list(range(f.shape[0])):
                 f = f.index_select(0, dev_idx["img_rows"])
@@ -565,7 +584,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     def _dev_idx(self, lay):
         dev = self.device
         t = lambda x: torch.tensor(x, dtype=torch.long, device=dev)
-        return {"text_src": t(lay["text_src"]), "text_dst": t(lay["text_dst"]), "img_dst": t(lay["img_dst"]), "img_rows": t(lay["img_rows"])}
+        d = {"text_src": t(lay["text_src"]), "text_dst": t(lay["text_dst"]), "img_dst": t(lay["img_dst"]), "img_rows": t(lay["img_rows"])}
+        if lay.get("img_src") is not None:
+            d["img_src"] = t(lay["img_src"])
+        return d
 
     def _n_feat(self, images, image_features):
         if image_features is not None:
@@ -592,21 +614,35 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
         embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, labels, images)
         B, N = len(lens), max(lens)
+        left = getattr(self.config, "tokenizer_padding_side", "right") == "left"  # ARCH:529-555: rows right-aligned, indices shifted by the pad
         out = embeds.new_zeros((B, N, embeds.shape[-1]))
         o = 0
         for b, n in enumerate(lens):
-            out[b, :n] = embeds[o : o + n]
+            if left:
+                out[b, N - n :] = embeds[o : o + n]
+                if indices is not None and indices[b] is not None:
+                    for key in indices[b]:
+                        indices[b][key] = [indices[b][key][0] + N - n, indices[b][key][1] + N - n]
+            else:
+                out[b, :n] = embeds[o : o + n]
             o += n
         new_mask = None
         if attention_mask is not None:
             new_mask = torch.zeros((B, N), dtype=attention_mask.dtype, device=attention_mask.device)
             for b, n in enumerate(lens):
-                new_mask[b, :n] = 1
+                if left:
+                    new_mask[b, N - n :] = 1
+                else:
+                    new_mask[b, :n] = 1
         new_pos = None
         if position_ids is not None:
             new_pos = torch.zeros((B, N), dtype=position_ids.dtype, device=position_ids.device)
             for b, n in enumerate(lens):
-                new_pos[b, :n] = torch.arange(n, dtype=position_ids.dtype, device=position_ids.device)
+                ar = torch.arange(n, dtype=position_ids.dtype, device=position_ids.device)
+                if left:
+                    new_pos[b, N - n :] = ar
+                else:
+                    new_pos[b, :n] = ar
         return (None, new_pos, new_mask, past_key_values, out, None), (indices,)
 
     # ---- decoder engine -----------------------------------------------------------------------
@@ -1078,10 +1114,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
         # ---- prefill ----
         if inputs_embeds is not None:
-            B, N = inputs_embeds.shape[:2]
-            lens = [N] * B if attention_mask is None else attention_mask.sum(dim=1).tolist()
-            embeds = torch.cat([inputs_embeds[b, : lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
-            indices = input_embeds_indices
+            embeds, lens, indices = self._unpad_embeds(inputs_embeds, attention_mask, input_embeds_indices)
         else:
             embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
         x, cache, lens2, cu_list = self._prefill(embeds, lens, indices, cache, reserve=256, last_only=False)
@@ -1095,6 +1128,21 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 logits[b, : lens2[b]] = logits_packed[cu_list[b] : cu_list[b + 1]]
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
 
+    def _unpad_embeds(self, inputs_embeds, attention_mask, input_embeds_indices):
+        """Padded [B, N, H] embeddings (what prepare_inputs_labels_for_multimodal returns: right- OR left-padded, ARCH:529-579) ->
+        packed rows + per-row lengths + row-relative segment dicts."""
+        B, N = inputs_embeds.shape[:2]
+        if attention_mask is None:
+            return inputs_embeds.reshape(B * N, -1).to(self.dtype).contiguous(), [N] * B, input_embeds_indices
+        am = attention_mask.bool()
+        lens = am.sum(dim=1).tolist()
+        first = am.int().argmax(dim=1).tolist()  # first valid column of every row (0 when right-padded)
+        embeds = torch.cat([inputs_embeds[b, first[b] : first[b] + lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
+        indices = input_embeds_indices
+        if indices is not None and any(first):
+            indices = [None if ix is None else {k: [v[0] - first[b], v[1] - first[b]] for k, v in ix.items()} for b, ix in enumerate(indices)]
+        return embeds, lens, indices
+
     def _forward_nocache(self, input_ids, attention_mask, past_key_values, inputs_embeds, images, image_features, input_embeds_indices):
         """`model(total_input_ids, images=..., use_cache=False)` -- the whole sequence is re-run every step
         (llava/dynamic_eval/bench_test/dynamic_llava_long_text_time_with_no_cache.py:336-343); no cache is returned."""
@@ -1102,10 +1150,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             raise NotImplementedError("use_cache=False with past_key_values")
         cfg, sc = self.config, self.config.sparse_config
         if inputs_embeds is not None:
-            B, N = inputs_embeds.shape[:2]
-            lens = [N] * B if attention_mask is None else attention_mask.sum(dim=1).tolist()
-            embeds = torch.cat([inputs_embeds[b, : lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
-            indices = input_embeds_indices
+            embeds, lens, indices = self._unpad_embeds(inputs_embeds, attention_mask, input_embeds_indices)
         else:
             embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
         p = self._plan_prefill(lens, indices)
@@ -1137,7 +1182,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         instruct = bool(sc["use_text_predictor"] and sc["use_instruct_predictor"]) and SL < L
         cache.ensure_capacity(T + 1)
         cos, sin = self._rope_tables(max(cache.full_len_host) + T + 1)
-        sparse_host = cache.lens[1].tolist()  # one device->host copy per chunk (the reference syncs per row per layer, CU:197-199)
+        # no device->host copy (the reference syncs per row per layer, CU:197-199): the un-evicted length bounds both length groups
+        bound = max(cache.full_len_host) + T
         total = B * T
         cu = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=dev)
         h = self.model.embed_tokens(input_ids.reshape(-1).to(dev)).clone()
@@ -1151,21 +1197,15 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 tp.decide(h, ops.text_predictor_workspace(total, tp.d_model, dev), lg, dec)
                 dec = dec.view(B, T)
                 dec[:, -1] = 1  # DML:2521
-                keep_idx = [torch.nonzero(dec[b]).flatten() for b in range(B)]
+                keep_idx = dec.contiguous()  # int32 [B, T] on the device: which chunk rows stay in layers >= SL
                 if self.debug_records is not None:
                     self.debug_records.update(text_decision=dec.clone(), text_logit=lg.view(B, T, 2).clone())
             g = cache.group(i)
             lens = cache.lens[g]
-            bound = (max(cache.full_len_host) if g == 0 else max(sparse_host)) + T
             qkv = F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
             attn = torch.empty((total, nH * d), dtype=dt, device=dev)
             ops.attn_prefill_cached(qkv[:, : nH * d], cache.k[i], cache.v[i], lens, attn, cu, T, bound, nH, nKV, d)
-            if keep_idx is not None and g == 1:  # keep only the chosen rows of this chunk, packed right after the old ones
-                for b in range(B):
-                    n, src = int(keep_idx[b].numel()), keep_idx[b] + sparse_host[b]
-                    cache.k[i][b, :, sparse_host[b] : sparse_host[b] + n] = cache.k[i][b][:, src]
-                    cache.v[i][b, :, sparse_host[b] : sparse_host[b] + n] = cache.v[i][b][:, src]
             o = F.linear(attn, layer.self_attn.o_proj.weight)
             x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
             act = ops.silu_mul(F.linear(x, layer.w_gu))
@@ -1174,12 +1214,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             x = ops.add_rmsnorm(h, dn, nw, eps)
         cache.lens[0] += T
         if keep_idx is not None:
-            cache.lens[1] += torch.tensor([int(k.numel()) for k in keep_idx], dtype=torch.int32, device=dev)
+            # keep only the chosen rows of this chunk, packed in place right after the old ones: ONE launch for all layers >= SL
+            # (every layer's attention has already read its un-packed chunk rows), then the kept counts are added on the device
+            ops.kv_pack_rows(cache.k[SL], cache.v[SL], cache.slab.stride(0), L - SL, keep_idx, cache.lens[1], cache.t_cap)
+            cache.lens[1] += keep_idx.sum(dim=1).to(torch.int32)
         else:
             cache.lens[1] += T
         cache.full_len_host = [n + T for n in cache.full_len_host]
-        cache.seen_tokens += T
-        cache.sparse_cap = min(cache.logical_cap, max(sparse_host) + T + (cache.logical_cap - max(cache.full_len_host)))
+        cache.seen_tokens += T  # cache.sparse_cap stays a valid (host-known) upper bound of the evicted group's lengths
         logits = F.linear(x, self.lm_head.weight).float().view(B, T, -1)
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
 
@@ -1290,7 +1332,24 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         want_dict = bool(kwargs.get("return_dict_in_generate"))
         want_scores = want_dict and bool(kwargs.get("output_scores"))
         inputs = inputs.to(self.device)
-        lay = self._layout(inputs, attention_mask, None, self._n_feat(images, image_features))
+        n_feat = self._n_feat(images, image_features)
+        sc_ = self.config.sparse_config
+        vp_ = getattr(self.model, "image_score_predictor", None)
+        dev_layout = (self.device_prompt_layout and not kwargs.get("_host_layout") and attention_mask is None and n_feat > 0 and inputs.shape[1] >= 1
+                      and self.use_hip_graph and self.debug_records is None and not (sc_["use_text_predictor"] and sc_["use_instruct_predictor"])
+                      and not (vp_ is not None and (len(vp_._forward_hooks) or len(vp_._forward_pre_hooks)))
+                      and getattr(self.config, "tokenizer_model_max_length", None) is None)
+        if dev_layout:
+            # ARCH:309-490 on the device.  Every row is assumed to hold exactly one image token (checked by the kernel; a
+            # violation is seen at the final synchronisation and the call is repeated with the host layout): all shapes then follow
+            # from (B, W), and where the image sits is the kernel's business, inside the captured graph.
+            Bq, Wq = inputs.shape
+            n_row = Wq - 1 + n_feat
+            fake = [{"system": [0, 0], "image": [0, n_feat], "instruct": [n_feat, n_row], "answer": [n_row, n_row], "last_instruct": [n_feat, n_row]} for _ in range(Bq)]
+            lay = dict(sig=("dev", Bq, Wq, n_feat), B=Bq, lens=[n_row] * Bq, indices=fake, text_src=[0], text_dst=[0], img_dst=[0], img_rows=list(range(Bq)),
+                       total=Bq * n_row, n_feat=n_feat)
+        else:
+            lay = self._layout(inputs, attention_mask, None, n_feat)
         lens, indices, B = lay["lens"], lay["indices"], lay["B"]
         max_new, min_new, eos, pad = self._gen_kwargs(kwargs, lens)
         if isinstance(eos, list):
@@ -1314,11 +1373,18 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if ent is None:
                 if len(self._prefill_graphs) >= 8:
                     self._prefill_graphs.pop(next(iter(self._prefill_graphs)))
-                ent = dict(ids=inputs.clone(), images=None if images is None else images.to(self.device).clone(),
+                ent = dict(ids=inputs.contiguous().clone(), images=None if images is None else images.to(self.device).clone(),
                            feats=None if image_features is None else image_features.to(self.device).clone(),
-                           plan=self._plan_prefill(lens, indices), didx=self._dev_idx(lay), indices=copy.deepcopy(indices))
+                           plan=self._plan_prefill(lens, indices), indices=copy.deepcopy(indices))
+                if dev_layout:
+                    ent["didx"] = ops.prompt_layout(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
+                    ent["plan"]["img_start"] = ent["didx"]["img_start"]  # written by the layout kernel inside the graph
+                else:
+                    ent["didx"] = self._dev_idx(lay)
 
                 def run():
+                    if dev_layout:
+                        ops.prompt_layout_into(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS, ent["didx"])
                     f = ent["feats"] if ent["feats"] is not None else (self.encode_images(ent["images"]) if ent["images"] is not None else None)
                     emb = self._assemble(lay, ent["didx"], ent["ids"], f)
                     x = self._prefill_run(ent["plan"], emb, cache, copy.deepcopy(ent["indices"]), True)
@@ -1363,6 +1429,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 break
         if B == 1:
             self.check_persistent()
+        if dev_layout and int(ent["didx"]["err"].item()) != 0:
+            # a row without exactly one image token (text-only row, several images): what was computed is meaningless -- repeat the
+            # call with the host-side layout, which handles (or rejects) those rows like the reference does
+            ent["didx"]["err"].zero_()
+            return self.generate(inputs, images=images, image_sizes=image_sizes, _host_layout=True, **kwargs)
         # host mirrors of what the device loop advanced: every row's un-evicted length grows by one per decode step
         cache.full_len_host = [n + produced - 1 for n in cache.full_len_host]
         cache.seen_tokens += produced - 1

@@ -199,6 +199,28 @@ int dl_gemv(int mode, const void* W, int N, int K, const void* x, int64_t x_row_
             const void* delta, const void* norm_w, float eps, void* y, int64_t y_row_stride, int B, int dtype, int grid_cap,
             void* stream);
 
+/* ---- in-place packing of the kept rows of a just-appended chunk: replaces the per-row slice / cat / zero-pad of CU:165-241 for the
+ * multi-round "new instruct" call (DML:2506-2521).  For n_layers consecutive layer slabs starting at k_slab0 / v_slab0 (layer_stride
+ * elements apart; each [B, nKV, T_cap, d] with the given strides), the chunk of T tokens sits at slots [kv_len[b], kv_len[b] + T); rows
+ * with keep[b,t] != 0 (int32 [B,T]) are moved in order to [kv_len[b], ...).  kv_len itself is NOT modified (the caller adds the kept
+ * counts once, on the device). */
+int dl_kv_pack_rows(void* k_slab0, void* v_slab0, int64_t layer_stride, int n_layers, int64_t slab_stride_b, int64_t slab_stride_h,
+                    int T_cap, const int32_t* keep, const int32_t* kv_len, int B, int n_kv_heads, int T, int head_dim, int dtype,
+                    void* stream);
+
+/* ---- device-side prompt layout (replaces the host logic of ARCH:309-490 -- per row `.item()` on the image position ARCH:330-334, the
+ * O(n) `torch.equal` scan for "USER:" ARCH:422-428 -- for the common eval case: every row holds exactly ONE image token (-200) and is not
+ * padded).  input_ids int64 [B, W].  Outputs (all on the device, nothing is read back):
+ *   seg      int32 [B, 8]   : img_pos, last_user (offset inside the instruct span of the last "USER:" id pair, 0 if none), n_images,
+ *                             n_valid, reserved...
+ *   text_src int64 [B*(W-1)]: flat positions (b*W + col) of the text tokens, row-major
+ *   text_dst int64 [B*(W-1)]: their rows in the packed [B*(W-1+n_feat), H] embedding matrix
+ *   img_dst  int64 [B*n_feat]: packed rows of the image features
+ *   img_start int32 [B]     : = img_pos
+ *   err      int32 [1]      : set to 1 + row when a row does not hold exactly one image token (checked by the caller at its next sync) */
+int dl_prompt_layout(const int64_t* input_ids, int B, int W, int n_feat, int image_token, int user_id0, int user_id1, int32_t* seg,
+                     int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, void* stream);
+
 /* ---- one whole batch-1 decode step as ONE persistent launch (replaces the per-layer chain dl_gemv x4 + dl_attn_decode_rope of
  * DML:1011-1013 / 1127 / 328 / 2709 + DML:134-139 / 1289 / 1295 + DML:260-285 + CU:109-268 + DML:1114-1122, bit-identical to it).
  * The caller describes the step as a phase table in DEVICE memory (built once per model / cache):

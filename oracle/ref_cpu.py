@@ -318,6 +318,15 @@ class Oracle:
             indices.append(
                 {"system": [0, s], "image": [s, i0], "instruct": [i0, a0], "answer": [a0, e.shape[0]], "last_instruct": [i0 + last_ins, a0]}
             )
+        tmax = getattr(self.cfg, "tokenizer_model_max_length", None)  # ARCH:493-506
+        if tmax is not None:
+            new_embeds = [x[:tmax] for x in new_embeds]
+            new_labels = [x[:tmax] for x in new_labels]
+            for x in indices:
+                for key, value in x.items():
+                    value[0] = min(value[0], tmax)
+                    value[1] = min(value[1], tmax)
+        left = getattr(self.cfg, "tokenizer_padding_side", "right") == "left"  # ARCH:529-555
         max_len = max(x.shape[0] for x in new_embeds)
         B = len(new_embeds)
         padded = []
@@ -325,9 +334,21 @@ class Oracle:
         lab_p = torch.full((B, max_len), IGNORE_INDEX, dtype=new_labels[0].dtype, device=dev)
         am = torch.zeros((B, max_len), dtype=attention_mask.dtype, device=dev)
         pid = torch.zeros((B, max_len), dtype=position_ids.dtype, device=dev)
-        for i, (e, l) in enumerate(zip(new_embeds, new_labels)):  # right padding (ARCH:558-577)
+        for i, (e, l) in enumerate(zip(new_embeds, new_labels)):  # right padding (ARCH:558-577) / left padding (ARCH:529-555)
             n = e.shape[0]
-            padded.append(torch.cat((e, torch.zeros((max_len - n, e.shape[1]), dtype=e.dtype, device=e.device)), dim=0))
+            z = torch.zeros((max_len - n, e.shape[1]), dtype=e.dtype, device=e.device)
+            if left:
+                padded.append(torch.cat((z, e), dim=0))
+                if i < len(indices):  # as the reference: input_embeds_indices[i] (one entry per row that held an image)
+                    for key, value in indices[i].items():
+                        value[0] += max_len - n
+                        value[1] += max_len - n
+                if n > 0:
+                    lab_p[i, -n:] = l
+                    am[i, -n:] = True
+                    pid[i, -n:] = torch.arange(0, n, dtype=pid.dtype, device=dev)
+                continue
+            padded.append(torch.cat((e, z), dim=0))
             if n > 0:
                 lab_p[i, :n] = l
                 am[i, :n] = True

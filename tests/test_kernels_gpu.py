@@ -582,3 +582,36 @@ def test_smallm_partials_consumers_bit_equal_reduce_then_op(ops, dtype, M, H, I)
     assert torch.equal(h_a, h_b) and torch.equal(x_a, x_b)
     h_c = h0.clone()
     assert ops.add_rmsnorm_parts(h_c, parts) is None and torch.equal(h_c, h_a)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,nKV,d,T,n_layers", [(1, 2, 128, 9, 3), (3, 4, 128, 40, 2), (2, 2, 64, 17, 1)])
+def test_kv_pack_rows(ops, dtype, B, nKV, d, T, n_layers):
+    """In-place packing of the kept rows of an appended chunk for several layer slabs at once == slicing / concatenating per row (CU:165-241
+    without the zero padding); rows outside [kv_len, kv_len + T) and other layers untouched."""
+    g = torch.Generator().manual_seed(50)
+    L_all, T_cap = n_layers + 2, 96
+    slab = torch.randn((L_all, 2, B, nKV, T_cap, d), generator=g).to(dtype)
+    kv_len = torch.randint(3, 40, (B,), generator=g).to(torch.int32)
+    keep = (torch.rand((B, T), generator=g) > 0.4).to(torch.int32)
+    keep[:, -1] = 1
+    keep[0, :] = 1 if B > 1 else keep[0, :]
+    ref = slab.clone()
+    for l in range(1, 1 + n_layers):
+        for kv in range(2):
+            for b in range(B):
+                n0 = int(kv_len[b])
+                rows = ref[l, kv, b, :, n0 : n0 + T][:, keep[b].bool()]
+                ref[l, kv, b, :, n0 : n0 + rows.shape[1]] = rows
+    sd = slab.cuda()
+    ops.kv_pack_rows(sd[1, 0], sd[1, 1], sd.stride(0), n_layers, keep.cuda().contiguous(), kv_len.cuda(), T_cap)
+    got = sd.cpu()
+    for l in range(L_all):
+        for kv in range(2):
+            for b in range(B):
+                n0, nk = int(kv_len[b]), int(keep[b].sum())
+                if 1 <= l <= n_layers:
+                    assert torch.equal(got[l, kv, b, :, : n0 + nk], ref[l, kv, b, :, : n0 + nk]), (l, kv, b)
+                    assert torch.equal(got[l, kv, b, :, n0 + T :], slab[l, kv, b, :, n0 + T :])
+                else:
+                    assert torch.equal(got[l, kv, b], slab[l, kv, b])

@@ -580,3 +580,109 @@ def test_harness_long_text_kv_length_curve_matches_reference_golden(golden_dir):
     # total_token_length follows the script's own accounting (images.shape[-2] * images.shape[-1] // 14 // 14 patches + text)
     assert rec["total_token_length"][0] == n_prompt and rec["total_token_length"][-1] == n_prompt + n - 1
     assert len(rec["max_memory"]) == n and all(m > 0 for m in rec["max_memory"])
+
+
+@pytest.mark.parametrize("side,tmax", [("right", None), ("left", None), ("right", 30), ("left", 30)])
+def test_prepare_inputs_padding_side_and_truncation_vs_oracle(side, tmax):
+    """ARCH:493-579 (the oracle is pinned to the live reference for exactly these cases in tests/test_oracle_vs_reference.py): ragged
+    batch -> padded embeddings / mask / position ids / shifted-clamped segment dicts, then forward(inputs_embeds=...) on them."""
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=5, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=6)
+    model = _build(cfg, sd, clip, torch.float32)
+    prompts = [fx.make_prompt(cfg, 4, 9, seed=1), fx.make_prompt(cfg, 2, 5, seed=2)]
+    W = max(p.shape[0] for p in prompts)
+    ids = torch.zeros(2, W, dtype=torch.long)
+    am = torch.zeros(2, W, dtype=torch.bool)
+    for b, p in enumerate(prompts):
+        ids[b, : p.shape[0]] = p
+        am[b, : p.shape[0]] = True
+    images = fx.make_images(cfg, 2, seed=3)
+    pos = torch.arange(W)[None].repeat(2, 1)
+    cfg.tokenizer_padding_side = side
+    cfg.tokenizer_model_max_length = tmax
+    model.config.tokenizer_padding_side = side
+    model.config.tokenizer_model_max_length = tmax
+    o = Oracle(cfg, sd, torch.float32, clip=clip)
+    with torch.no_grad():
+        (_, o_pos, o_am, _, o_emb, _), (o_idx,) = o.prepare_inputs_labels_for_multimodal(ids, pos, am, None, None, images)
+    (_, h_pos, h_am, _, h_emb, _), (h_idx,) = model.prepare_inputs_labels_for_multimodal(ids.cuda(), pos.cuda(), am.cuda(), None, None, images.cuda())
+    assert torch.equal(h_am.cpu().bool(), o_am.bool()) and torch.equal(h_pos.cpu(), o_pos)
+    assert [{k: [int(v[0]), int(v[1])] for k, v in d.items()} for d in h_idx] == [{k: [int(v[0]), int(v[1])] for k, v in d.items()} for d in o_idx]
+    assert h_emb.shape == o_emb.shape and float((h_emb.cpu() - o_emb).abs().max()) < 1e-3
+    # the padded tensors drive forward() exactly as DLL:68-115 passes them on
+    import copy as _copy
+
+    out = model(inputs_embeds=h_emb, attention_mask=h_am, input_embeds_indices=_copy.deepcopy(h_idx))
+    with torch.no_grad():
+        l_ref, pkv = o.forward(ids, attention_mask=am, images=images)
+    lens = out.past_key_values[1][-1].tolist()
+    assert lens == pkv[1][-1].tolist()
+    first = (o_am.int().argmax(dim=1)).tolist() if side == "left" else [0, 0]
+    for b in range(2):
+        n_sparse = lens[b]
+        ref_row = l_ref[b, first[b] * 0 : , :]  # the oracle's logits are laid out like its (compacted, padded) hidden states
+        got = out.logits[b, :n_sparse].cpu()
+        # compare the last valid position of every row (layout-independent)
+        ref_last = l_ref[b, -1] if side == "left" else l_ref[b, n_sparse - 1]
+        assert float((got[-1] - ref_last).abs().max()) < 1e-3, (b, side, tmax)
+
+
+def test_device_prompt_layout_kernel_and_generate_fast_path():
+    """dl_prompt_layout == the host restatement of ARCH:330-340 / 418-489 (image position, last "USER:" match, packed
+    index lists); generate() with the device layout == generate() with the host layout; rows without an image fall back."""
+    from dynamic_llava_amd import hip_ops as ops
+    from dynamic_llava_amd.config import IMAGE_TOKEN_INDEX
+    from dynamic_llava_amd.model import USER_IDS
+
+    cfg = fx.tiny_config()
+    cfg.vocab_size = 30000
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1)
+    model = _build(cfg, sd, clip, torch.float32)
+    n_feat = fx.n_image_tokens(cfg)
+    g = torch.Generator().manual_seed(3)
+    B, W = 5, 40
+    ids = torch.randint(3, cfg.vocab_size, (B, W), generator=g)
+    img_pos = [0, 7, 39, 20, 11]
+    for b in range(B):
+        ids[b, img_pos[b]] = IMAGE_TOKEN_INDEX
+    for b, offs in enumerate([[], [3, 20], [], [1], [5, 6, 25]]):  # "USER:" pairs inside the instruct span
+        for o_ in offs:
+            c = img_pos[b] + 1 + o_
+            if c + 1 < W:
+                ids[b, c], ids[b, c + 1] = USER_IDS[0], USER_IDS[1]
+    out = ops.prompt_layout(ids.cuda().contiguous(), n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
+    lay = model._layout(ids.cuda(), None, None, n_feat)
+    seg = out["seg"].cpu()
+    assert int(out["err"].item()) == 0
+    for b in range(B):
+        ix = lay["indices"][b]
+        assert int(seg[b, 0]) == ix["image"][0] and int(seg[b, 2]) == 1
+        assert int(seg[b, 1]) == ix["last_instruct"][0] - ix["instruct"][0], b
+    assert out["text_src"].cpu().tolist() == lay["text_src"] and out["text_dst"].cpu().tolist() == lay["text_dst"]
+    assert out["img_dst"].cpu().tolist() == lay["img_dst"] and out["img_start"].cpu().tolist() == [ix["image"][0] for ix in lay["indices"]]
+    bad = ids.clone()
+    bad[2, img_pos[2]] = 5  # no image token in row 2
+    assert int(ops.prompt_layout(bad.cuda().contiguous(), n_feat, IMAGE_TOKEN_INDEX, USER_IDS)["err"].item()) == 3
+    # generate(): device layout (graph replay on changing image positions) == host layout
+    images = fx.make_images(cfg, 2, seed=0)
+    p2 = ids[:2, :12].clone()
+    p2[0, 4], p2[1, 9] = IMAGE_TOKEN_INDEX, IMAGE_TOKEN_INDEX
+    p2[p2 == IMAGE_TOKEN_INDEX] = 7
+    for trial, (c0, c1) in enumerate([(4, 9), (0, 11), (6, 2)]):
+        q = p2.clone()
+        q[0, c0], q[1, c1] = IMAGE_TOKEN_INDEX, IMAGE_TOKEN_INDEX
+        model.device_prompt_layout = True
+        a = model.generate(q.cuda(), images=images.cuda(), max_new_tokens=5, eos_token_id=None)
+        model.device_prompt_layout = False
+        b_ = model.generate(q.cuda(), images=images.cuda(), max_new_tokens=5, eos_token_id=None)
+        assert torch.equal(a, b_), trial
+    # a row without an image: the device layout flags it and the call transparently re-runs on the host layout
+    q = p2.clone()
+    q[0, 3] = IMAGE_TOKEN_INDEX
+    model.device_prompt_layout = True
+    a = model.generate(q.cuda(), images=images.cuda(), max_new_tokens=4, eos_token_id=None)
+    model.device_prompt_layout = False
+    b_ = model.generate(q.cuda(), images=images.cuda(), max_new_tokens=4, eos_token_id=None)
+    assert torch.equal(a, b_)
