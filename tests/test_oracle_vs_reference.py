@@ -50,7 +50,7 @@ def test_oracle_equals_live_reference(dll, dtype, sparse, n_sys, n_q, steps, see
             cur = forced[j][:, None]
 
 
-@pytest.mark.parametrize("side,tmax", [("right", None), ("left", None), ("right", 30), ("left", 30)])
+@pytest.mark.parametrize("side,tmax", [("right", None), ("left", None), ("right", 42), ("left", 42)])
 def test_oracle_prepare_inputs_padding_and_truncation_equal_live_reference(dll, side, tmax):
     """ARCH:493-579 -- tokenizer_model_max_length truncation and left / right padding of a ragged batch: embeddings, attention mask,
     position ids and the (shifted / clamped) segment dicts, bit for bit against the reference."""
