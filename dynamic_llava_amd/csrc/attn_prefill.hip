@@ -552,13 +552,13 @@ static int attn_prefill_impl(const char* who, const void* q, const void* k, cons
                        dim3(256), smem, st, q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, n_rep,
                        1.0f / sqrtf((float)head_dim), head_dim, causal, max_kv_len, kv_len, kv_sb, kv_sh);
   } else if (dtype == DL_F16 || dtype == DL_BF16) {
-    DL_REQUIRE(head_dim == 64 || head_dim == 128, "%s: head_dim=%d unsupported (64 or 128)", who, head_dim);
+    DL_REQUIRE(head_dim == 32 || head_dim == 64 || head_dim == 128, "%s: head_dim=%d unsupported (32, 64 or 128)", who, head_dim);
     DL_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0, "%s: row strides must be multiples of 8 elements", who);
 #define DL_PF_ARGS q, k, v, q_row_stride, kv_row_stride, out, out_row_stride, cu_seqlens, B, max_seqlen, n_heads, n_rep, causal, st, kv_len, kv_sb, kv_sh
     if (dtype == DL_BF16) {
-      if (head_dim == 128) launch_mfma<bf16_t, 128>(DL_PF_ARGS); else launch_mfma<bf16_t, 64>(DL_PF_ARGS);
+      if (head_dim == 128) launch_mfma<bf16_t, 128>(DL_PF_ARGS); else if (head_dim == 64) launch_mfma<bf16_t, 64>(DL_PF_ARGS); else launch_mfma<bf16_t, 32>(DL_PF_ARGS);
     } else {
-      if (head_dim == 128) launch_mfma<f16_t, 128>(DL_PF_ARGS); else launch_mfma<f16_t, 64>(DL_PF_ARGS);
+      if (head_dim == 128) launch_mfma<f16_t, 128>(DL_PF_ARGS); else if (head_dim == 64) launch_mfma<f16_t, 64>(DL_PF_ARGS); else launch_mfma<f16_t, 32>(DL_PF_ARGS);
     }
 #undef DL_PF_ARGS
   } else {

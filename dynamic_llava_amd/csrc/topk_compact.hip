@@ -26,7 +26,8 @@ __global__ void topk_select_kernel(const void* __restrict__ score_, int64_t* __r
   int* wave_cnt = reinterpret_cast<int*>(keys + ((n + 3) & ~3));  // [n_waves]
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-  for (int i = tid; i < n; i += blockDim.x) keys[i] = order_key(load1<T>(score_, (int64_t)b * n + i));
+  const int n4 = (n + 3) & ~3;
+  for (int i = tid; i < n4; i += blockDim.x) keys[i] = i < n ? order_key(load1<T>(score_, (int64_t)b * n + i)) : 0u;  // pad: smallest key, index >= n
   __syncthreads();
   int base = 0;  // survivors emitted by earlier passes
   const int passes = (n + blockDim.x - 1) / blockDim.x;
@@ -34,11 +35,19 @@ __global__ void topk_select_kernel(const void* __restrict__ score_, int64_t* __r
     const int i = p * blockDim.x + tid;
     bool kept = false;
     if (i < n) {
+      // rank = #{keys that precede mine in the pinned order}: the keys are read four at a time (16-byte LDS broadcast reads) and eight
+      // reads are in flight per trip -- one dependent 4-byte read per key was 576 x ~64 cycles = 22 us at n = 576
       const uint32_t me = keys[i];
       int rank = 0;
-      for (int j = 0; j < n; ++j) {
-        const uint32_t o = keys[j];
-        rank += (o > me) || (o == me && j < i);
+      const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+#pragma unroll 8
+      for (int j4 = 0; j4 < n4 / 4; ++j4) {
+        const uint4 o = k4[j4];
+        const int j = 4 * j4;
+        rank += (o.x > me) || (o.x == me && j < i);
+        rank += (o.y > me) || (o.y == me && j + 1 < i);
+        rank += (o.z > me) || (o.z == me && j + 2 < i);
+        rank += (o.w > me) || (o.w == me && j + 3 < i);
       }
       kept = rank < k;
     }
@@ -57,15 +66,34 @@ __global__ void topk_select_kernel(const void* __restrict__ score_, int64_t* __r
   }
 }
 
+template <typename T>
+__device__ __forceinline__ void unpack_u4(const uint4& r, float (&f)[Elem<T>::kVec]) {
+  if constexpr (Elem<T>::kVec == 4) {
+    f[0] = __uint_as_float(r.x);
+    f[1] = __uint_as_float(r.y);
+    f[2] = __uint_as_float(r.z);
+    f[3] = __uint_as_float(r.w);
+  } else {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = Elem<T>::to_f((uint16_t)(w[i] & 0xffffu));
+      f[2 * i + 1] = Elem<T>::to_f((uint16_t)(w[i] >> 16));
+    }
+  }
+}
+
 // one workgroup per OUTPUT token: binary-search its row, map to the source token, copy H elements.
 template <typename T>
 __global__ __launch_bounds__(256) void compact_tokens_kernel(const void* __restrict__ in_, void* __restrict__ out_,
                                                               const int64_t* __restrict__ keep, const int32_t* __restrict__ cu_in,
                                                               const int32_t* __restrict__ cu_out, const int32_t* __restrict__ img_start,
-                                                              int32_t* __restrict__ pos_out, int B, int n_img, int k, int H) {
+                                                              int32_t* __restrict__ pos_out, int B, int n_img, int k, int H,
+                                                              const void* __restrict__ norm_w, float eps, void* __restrict__ x_out) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   __shared__ int64_t sh_src;
+  __shared__ float red[4];
   const int t = blockIdx.x;
   if (threadIdx.x == 0) {
     int lo = 0, hi = B;
@@ -85,7 +113,44 @@ __global__ __launch_bounds__(256) void compact_tokens_kernel(const void* __restr
   __syncthreads();
   const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const S*>(in_) + sh_src * H);
   uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<S*>(out_) + (int64_t)t * H);
-  for (int v = threadIdx.x; v < H / V; v += 256) dst[v] = src[v];
+  if (norm_w == nullptr) {
+    for (int v = threadIdx.x; v < H / V; v += 256) dst[v] = src[v];
+    return;
+  }
+  // fused RMSNorm of the compacted row (the input_layernorm of layer `sparse_layer`, DML:134-139): the row is in registers anyway.
+  // Same thread -> chunk map, same reduction and rounding order as dl_rmsnorm (elementwise.hip), so the bits are the same.
+  constexpr int kMaxVec = 8;  // H <= 256 * 8 * kVec
+  const int nvec = H / V;
+  uint4 raw[kMaxVec];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      raw[i] = src[v];
+      dst[v] = raw[i];
+      float x[V];
+      unpack_u4<T>(raw[i], x);
+#pragma unroll
+      for (int j = 0; j < V; ++j) ss += x[j] * x[j];
+    }
+  }
+  const float tot = block_sum<4>(ss, red);
+  const float rstd = rsqrtf(tot / (float)H + eps);
+  const S* w = reinterpret_cast<const S*>(norm_w);
+  S* xo = reinterpret_cast<S*>(x_out) + (int64_t)t * H;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      float x[V], wv[V], o[V];
+      unpack_u4<T>(raw[i], x);
+      load16<T>(w + v * V, wv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = wv[j] * Elem<T>::round(x[j] * rstd);  // cast, THEN weight
+      store16<T>(xo + v * V, o);
+    }
+  }
 }
 
 }  // namespace dl
@@ -106,16 +171,18 @@ extern "C" int dl_topk_select(const void* score, int64_t* keep_idx, int B, int n
 }
 
 extern "C" int dl_compact_tokens(const void* h_in, void* h_out, const int64_t* keep_idx, const int32_t* cu_in, const int32_t* cu_out,
-                                 const int32_t* img_start, int32_t* pos_out, int B, int n_img, int k, int total_out, int H, int dtype,
-                                 void* stream) {
+                                 const int32_t* img_start, int32_t* pos_out, int B, int n_img, int k, int total_out, int H, const void* norm_w,
+                                 float eps, void* x_out, int dtype, void* stream) {
   DL_REQUIRE(h_in && h_out && cu_in && cu_out && img_start && pos_out, "dl_compact_tokens: NULL pointer");
+  DL_REQUIRE((norm_w == nullptr) == (x_out == nullptr), "dl_compact_tokens: norm_w and x_out go together");
   DL_REQUIRE(keep_idx || k == 0, "dl_compact_tokens: keep_idx is NULL");
   DL_REQUIRE(B > 0 && n_img >= 0 && k >= 0 && k <= n_img && total_out >= 0 && H > 0, "dl_compact_tokens: bad shape");
   if (total_out == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0, "dl_compact_tokens: H=%d must be a multiple of %d", H, Elem<T>::kVec);
+    DL_REQUIRE(norm_w == nullptr || H <= 256 * 8 * Elem<T>::kVec, "dl_compact_tokens: H=%d too wide for the fused norm", H);
     hipLaunchKernelGGL((compact_tokens_kernel<T>), dim3((unsigned)total_out), dim3(256), 0, as_stream(stream), h_in, h_out, keep_idx,
-                       cu_in, cu_out, img_start, pos_out, B, n_img, k, H);
+                       cu_in, cu_out, img_start, pos_out, B, n_img, k, H, norm_w, eps, x_out);
   });
   DL_CHECK_LAUNCH("dl_compact_tokens");
   return DL_OK;

@@ -84,7 +84,7 @@ SIGNATURES = {
         [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "dl_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "dl_vision_predictor_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -307,18 +307,21 @@ def topk_select(score, k):
     return keep
 
 
-def compact_tokens(h_in, keep_idx, cu_in, cu_out, img_start, n_img, k, total_out):
-    _dev(h_in, keep_idx, cu_in, cu_out, img_start)
+def compact_tokens(h_in, keep_idx, cu_in, cu_out, img_start, n_img, k, total_out, norm_w=None, eps=0.0):
+    """-> (h_out, pos) or, with norm_w, (h_out, pos, rmsnorm(h_out) * norm_w) from the same launch."""
+    _dev(h_in, keep_idx, cu_in, cu_out, img_start, norm_w)
     assert h_in.is_contiguous()
     H = h_in.shape[-1]
     B = cu_in.numel() - 1
     h_out = torch.empty((total_out, H), dtype=h_in.dtype, device=h_in.device)
     pos = torch.empty((total_out,), dtype=torch.int32, device=h_in.device)
+    x_out = torch.empty_like(h_out) if norm_w is not None else None
     _check(
-        lib().dl_compact_tokens(_p(h_in), _p(h_out), _p(keep_idx), _p(cu_in), _p(cu_out), _p(img_start), _p(pos), B, n_img, k, total_out, H, dtype_code(h_in.dtype), _stream()),
+        lib().dl_compact_tokens(_p(h_in), _p(h_out), _p(keep_idx), _p(cu_in), _p(cu_out), _p(img_start), _p(pos), B, n_img, k, total_out, H, _p(norm_w), float(eps), _p(x_out),
+                                dtype_code(h_in.dtype), _stream()),
         "dl_compact_tokens",
     )
-    return h_out, pos
+    return (h_out, pos) if norm_w is None else (h_out, pos, x_out)
 
 
 def linear(a, w, bias=None, flags=0, residual=None, out=None):

@@ -284,18 +284,15 @@ class CLIPVisionTower(nn.Module):
         cu = self._cu.get(B)
         if cu is None:
             cu = self._cu[B] = (torch.arange(B + 1, device=h.device, dtype=torch.int32) * T).contiguous()
-        hip_attn = h.dtype == torch.float32 or d in (64, 128)
+        if not (h.dtype == torch.float32 or d in (32, 64, 128)):
+            raise ops.HipOpsError(f"CLIP head_dim={d}: dl_attn_prefill tiles head dims 32 / 64 / 128 in 16-bit dtypes (no torch fallback exists)")
         layers = vm.encoder.layers[: self._n_layers_needed()]
         xn = ops.layernorm(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if len(layers) else None
         for i, l in enumerate(layers):
             wq, bq = self._qkv[i]
             qkv = F.linear(xn, wq, bq)
-            if hip_attn:
-                attn = torch.empty((B * T, C), dtype=h.dtype, device=h.device)
-                ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
-            else:  # head dims the MFMA kernel does not tile (tiny test towers): torch SDPA on the same packed projection
-                q, k, v = (t.reshape(B, T, nH, d).transpose(1, 2) for t in qkv.split(C, dim=1))
-                attn = F.scaled_dot_product_attention(q, k, v, scale=d**-0.5).transpose(1, 2).reshape(B * T, C)
+            attn = torch.empty((B * T, C), dtype=h.dtype, device=h.device)
+            ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
             y = F.linear(attn, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias)
             xn = ops.add_layernorm(h, y, l.layer_norm2.weight, l.layer_norm2.bias, eps)
             g = ops.quick_gelu(F.linear(xn, l.mlp.fc1.weight, l.mlp.fc1.bias))
@@ -726,7 +723,12 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 else:
                     logits, score = vp.score_packed(h, cu, p["img_start"], n_img)
                 keep = ops.topk_select(score, k)
-                h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, p["cu2_list"][-1])
+                # compaction + this layer's input RMSNorm in one launch (unless a text-predictor compaction still follows at this layer)
+                fuse_norm = not p["instruct_on"] and not p["nocache"]
+                if fuse_norm:
+                    h, pos, x_fused = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, p["cu2_list"][-1], layer.input_layernorm.weight, eps)
+                else:
+                    h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, p["cu2_list"][-1])
                 if rec is not None:
                     rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=p["cu2"])
                 cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], p["cu2_list"][-1]
@@ -790,7 +792,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 p["nocache_lens"] = [L_new] * B
                 if rec is not None:
                     rec.update(position_ids=pos, cu_after=cu)
-            if i == SL and (vision_on or p["instruct_on"] or p["nocache"]):
+            if i == SL and vision_on and not p["instruct_on"] and not p["nocache"]:
+                x = x_fused
+            elif i == SL and (vision_on or p["instruct_on"] or p["nocache"]):
                 x = ops.rmsnorm(h, layer.input_layernorm.weight, eps)
             qkv = F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)

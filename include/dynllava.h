@@ -117,10 +117,12 @@ int dl_topk_select(const void* score, int64_t* keep_idx, int B, int n, int k, in
 /* ---- F3 + F4: token compaction, DML:1917-1983.  Row b of the packed input has an image span
  * [img_start[b], img_start[b] + n_img); the output row keeps everything outside the span and the
  * k rows keep_idx[b,:] of it, in order.  pos_out[t] = original in-row index of output token t
- * (what the reference builds as position_ids).  h_in [total_in,H] -> h_out [total_out,H]. */
+ * (what the reference builds as position_ids).  h_in [total_in,H] -> h_out [total_out,H].
+ * norm_w / x_out (both or neither): the RMSNorm of the compacted rows (the next layer's input_layernorm, DML:134-139) is written to
+ * x_out [total_out,H] in the same pass -- the row is in registers anyway, and the result is bit-identical to dl_rmsnorm(h_out). */
 int dl_compact_tokens(const void* h_in, void* h_out, const int64_t* keep_idx, const int32_t* cu_in,
                       const int32_t* cu_out, const int32_t* img_start, int32_t* pos_out, int B, int n_img, int k,
-                      int total_out, int H, int dtype, void* stream);
+                      int total_out, int H, const void* norm_w, float eps, void* x_out, int dtype, void* stream);
 
 /* ---- generic small linear layer used by the predictors: C = epilogue(A @ W^T + bias)
  * A [M,K] (row stride lda), W [N,K] (nn.Linear layout), bias [N] or NULL, C [M,N] (row stride ldc).

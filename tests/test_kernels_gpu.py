@@ -211,6 +211,11 @@ def test_compact_tokens_bit_exact(ops, dtype):
         ref_pos = torch.cat([torch.arange(0, s), keep[b] + s, torch.arange(s + n_img, lens[b])])  # DML:1963-1983
         assert torch.equal(out.cpu()[int(cu2[b]) : int(cu2[b + 1])], ref)
         assert torch.equal(pos.cpu()[int(cu2[b]) : int(cu2[b + 1])].long(), ref_pos)
+    # fused RMSNorm of the compacted rows: bit-identical to compaction followed by dl_rmsnorm
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype).cuda()
+    out2, pos2, x2 = ops.compact_tokens(h.cuda(), keep.cuda(), cu.cuda(), cu2.cuda(), torch.tensor(starts, dtype=torch.int32).cuda(), n_img, k, sum(new_lens), w, 1e-5)
+    assert torch.equal(out2, out) and torch.equal(pos2, pos)
+    assert torch.equal(x2, ops.rmsnorm(out, w, 1e-5))
 
 
 def _sdpa_ref(q, k, v, causal):
@@ -225,7 +230,7 @@ def _sdpa_ref(q, k, v, causal):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (4, 2, 128, [129]), (4, 2, 128, [300, 631, 17, 257])])
+@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (4, 2, 128, [129]), (4, 2, 128, [300, 631, 17, 257]), (2, 2, 32, [37, 150, 5])])
 def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
     g = torch.Generator().manual_seed(8)
     total = sum(lens)
