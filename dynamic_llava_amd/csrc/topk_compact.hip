@@ -1,10 +1,10 @@
 // F2: order-preserving top-k select (DML:1898-1908) and F3/F4: token compaction + position ids
 // (DML:1917-1983).  Integer results -> bit-exact against the oracle.
 //
-// top-k: one workgroup per row.  Scores become order-preserving uint32 keys in LDS; each element's
-// rank under the pinned total order (score descending, then index ascending) is counted against all
-// keys (LDS broadcast reads); rank < k survives.  Survivors are emitted in index order with a
-// wavefront ballot + cross-wave prefix (no sort, no atomics => deterministic).
+// top-k: one workgroup per row.  Scores become order-preserving uint32 keys in LDS; a radix select finds
+// the k-th largest key, ties at the threshold are resolved by index (the pinned total order: score
+// descending, then index ascending).  Survivors are emitted in index order with a wavefront ballot +
+// cross-wave prefix (no sort => deterministic).
 #include "dl_common.h"
 
 namespace dl {
@@ -19,38 +19,76 @@ __device__ __forceinline__ uint32_t order_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Radix select: the k-th largest key is found digit by digit (4 passes of 8 bits: LDS histogram of the still-matching keys, suffix
+// scan of the 256 bins by one wave), O(n) work per pass instead of the O(n^2) rank counting that kept one CU busy for ~20 us at n = 576.
+// kept = key > threshold, or key == threshold and among the first `need` such keys in index order (the pinned tie rule: score
+// descending, then index ascending).  Survivors are emitted in index order with wavefront ballots + cross-wave prefixes: no sort,
+// no data-dependent atomics in the result => deterministic and bit-exact against the oracle.
 template <typename T>
 __global__ void topk_select_kernel(const void* __restrict__ score_, int64_t* __restrict__ keep, int n, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);             // [n_pad]
-  int* wave_cnt = reinterpret_cast<int*>(keys + ((n + 3) & ~3));  // [n_waves]
+  int* hist = reinterpret_cast<int*>(keys + ((n + 3) & ~3));      // [256]
+  int* wave_cnt = hist + 256;                                     // [2][16]
+  int* sel = wave_cnt + 32;                                       // [2]: chosen bin, keys above it
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-  const int n4 = (n + 3) & ~3;
-  for (int i = tid; i < n4; i += blockDim.x) keys[i] = i < n ? order_key(load1<T>(score_, (int64_t)b * n + i)) : 0u;  // pad: smallest key, index >= n
-  __syncthreads();
-  int base = 0;  // survivors emitted by earlier passes
+  for (int i = tid; i < n; i += blockDim.x) keys[i] = order_key(load1<T>(score_, (int64_t)b * n + i));
+  uint32_t prefix = 0, mask = 0;
+  int need = k;  // keys still to take among those that match `prefix` on the `mask` bits
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+      const uint32_t key = keys[i];
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (wid == 0) {
+      // lane l owns bins 4l .. 4l+3; `above` = number of matching keys in bins higher than this lane's (suffix sum over lanes l+1 .. 63)
+      const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const int mine = c0 + c1 + c2 + c3;
+      int suf = mine;  // inclusive suffix sum
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+      }
+      const int above = suf - mine;
+      if (above < need && need <= suf) {  // the k-th key falls into one of this lane's bins (exactly one lane)
+        int a = above, bin = 4 * lane + 3;
+        if (a + c3 >= need) bin = 4 * lane + 3;
+        else if ((a += c3) + c2 >= need) bin = 4 * lane + 2;
+        else if ((a += c2) + c1 >= need) bin = 4 * lane + 1;
+        else { a += c1; bin = 4 * lane; }
+        sel[0] = bin;
+        sel[1] = a;
+      }
+    }
+    __syncthreads();
+    prefix |= (uint32_t)sel[0] << shift;
+    mask |= 255u << shift;
+    need -= sel[1];
+    __syncthreads();
+  }
+  const uint32_t thr = prefix;  // the k-th largest key; `need` of the keys equal to it are taken, lowest index first
+  int base = 0, eq_base = 0;
   const int passes = (n + blockDim.x - 1) / blockDim.x;
   for (int p = 0; p < passes; ++p) {
     const int i = p * blockDim.x + tid;
-    bool kept = false;
-    if (i < n) {
-      // rank = #{keys that precede mine in the pinned order}: the keys are read four at a time (16-byte LDS broadcast reads) and eight
-      // reads are in flight per trip -- one dependent 4-byte read per key was 576 x ~64 cycles = 22 us at n = 576
-      const uint32_t me = keys[i];
-      int rank = 0;
-      const uint4* k4 = reinterpret_cast<const uint4*>(keys);
-#pragma unroll 8
-      for (int j4 = 0; j4 < n4 / 4; ++j4) {
-        const uint4 o = k4[j4];
-        const int j = 4 * j4;
-        rank += (o.x > me) || (o.x == me && j < i);
-        rank += (o.y > me) || (o.y == me && j + 1 < i);
-        rank += (o.z > me) || (o.z == me && j + 2 < i);
-        rank += (o.w > me) || (o.w == me && j + 3 < i);
-      }
-      kept = rank < k;
+    const uint32_t me = i < n ? keys[i] : 0u;
+    const bool eq = i < n && me == thr;
+    const unsigned long long me_q = __ballot(eq);
+    if (lane == 0) wave_cnt[16 + wid] = __popcll(me_q);
+    __syncthreads();
+    int eq_before = eq_base, eq_tot = 0;
+    for (int w = 0; w < nw; ++w) {
+      const int c = wave_cnt[16 + w];
+      if (w < wid) eq_before += c;
+      eq_tot += c;
     }
+    eq_before += __popcll(me_q & ((1ull << lane) - 1ull));
+    const bool kept = i < n && (me > thr || (eq && eq_before < need));
     const unsigned long long m = __ballot(kept);
     if (lane == 0) wave_cnt[wid] = __popcll(m);
     __syncthreads();
@@ -62,6 +100,7 @@ __global__ void topk_select_kernel(const void* __restrict__ score_, int64_t* __r
     }
     if (kept) keep[(int64_t)b * k + off + __popcll(m & ((1ull << lane) - 1ull))] = (int64_t)i;
     base += tot;
+    eq_base += eq_tot;
     __syncthreads();
   }
 }
@@ -162,7 +201,7 @@ extern "C" int dl_topk_select(const void* score, int64_t* keep_idx, int B, int n
   DL_REQUIRE(B > 0 && n > 0 && n <= kTopkMaxN && k >= 0 && k <= n, "dl_topk_select: bad shape B=%d n=%d k=%d", B, n, k);
   if (k == 0) return DL_OK;
   int threads = n <= 64 ? 64 : (n <= 256 ? 256 : 1024);
-  const size_t smem = (size_t)((n + 3) & ~3) * 4 + 16 * 4;
+  const size_t smem = (size_t)((n + 3) & ~3) * 4 + (256 + 32 + 2) * 4;
   DL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((topk_select_kernel<T>), dim3((unsigned)B), dim3(threads), smem, as_stream(stream), score, keep_idx, n, k);
   });
