@@ -123,14 +123,17 @@ def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim):
     vs = [v] + [torch.randn_like(v) for _ in range(n_buf - 1)]
     it = [0]
 
+    tagc = [0]
+
     def launch():
         i = it[0] = (it[0] + 1) % n_buf
-        ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, ws, n_splits, n_heads, n_heads, head_dim)
+        tagc[0] = (tagc[0] + 1) % 251  # as in the decode step: consecutive launches sharing the workspace carry different call tags
+        ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, ws, n_splits, n_heads, n_heads, head_dim, call_tag=tagc[0])
 
     ms = graph_time_ms(launch)
     nbytes = sum(2 * t * H * 2 + 2 * H * 2 for t in T_list)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    name = "dl_attn_decode_rope (attn_decode_split_kernel<bf16,128,4,fused,4>" + (" + attn_decode_combine_kernel)" if n_splits > 1 else ")")
+    name = "dl_attn_decode_rope (attn_decode_split_kernel<bf16,128,4,fused,4" + (",in-kernel combine>)" if 1 < n_splits and n_splits * n_heads * B <= 1024 else ">)")
     return {"kernel": name, "shape": label, "n_splits": n_splits, "bytes": nbytes, "us": round(ms * 1e3, 3), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 

@@ -9,6 +9,7 @@
 // Per-row lengths are read from the device (kv_len[b] + extra): no host sync, graph-capturable,
 // and a slot beyond the true length (an evicted token) is simply never read.
 #include "attn_decode_body.h"
+#include "granule.h"
 
 namespace dl {
 
@@ -31,12 +32,17 @@ __device__ long long g_attn_stamps[8];
 // kernel: q|k|v are read un-rotated from the projection output, the new token's rotated key / value are used from
 // registers by the one lane group that owns key index kv_len[b] and written to slab slot kv_len[b] for later steps.
 // The body lives in attn_decode_body.h (shared with the persistent decode step).
-template <typename T, int D, int NW, bool FUSED, int U>
+// INK ("in-kernel combine", FUSED only): the partials travel as 8-byte {tag, value} granules (granule.h) and the workgroup of split 0
+// merges them itself -- same merge code, same order, same bits as attn_decode_combine_kernel -- instead of a second launch (4.7 us +
+// a ~1.2 us boundary per layer at batch 1).  tag = f(position of the new token, call_tag): the writes that precede a launch in the same
+// slot come from the previous layer / step, so a stale granule never carries the expected tag.  Needs every workgroup of the grid
+// resident (the host only selects INK for grids of <= 1024 workgroups); the wait is bounded and poisons the output with NaN on give-up.
+template <typename T, int D, int NW, bool FUSED, int U, bool INK = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     const void* __restrict__ q_, int64_t q_row_stride, const void* k_slab_, const void* v_slab_, int64_t stride_b, int64_t stride_h,
     const int32_t* __restrict__ kv_len, int extra, float* __restrict__ ws, void* __restrict__ out_, int64_t out_row_stride, int n_rep,
     float scale, const void* __restrict__ cos_, const void* __restrict__ sin_, int n_pos, const int32_t* __restrict__ pos_base, int T_cap,
-    int n_kv_heads, int chunk_keys) {
+    int n_kv_heads, int chunk_keys, int call_tag = 0) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename Elem<T>::storage;
   constexpr int NG = St::NG;
@@ -56,6 +62,58 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
   attn_split_finish<T, D, NW, FUSED, U>(st, tid, row + (int64_t)h * D, row + (int64_t)(n_heads + kvh) * D,
                                         row + (int64_t)(n_heads + n_kv_heads + kvh) * D, cos_, sin_, n_pos, FUSED ? pos_base[b] : 0, scale,
                                         h % n_rep == 0, T_cap, sm_m, sm_l, sm_o, M, L, O);
+  if constexpr (INK) {
+    extern __shared__ __attribute__((aligned(16))) float comb[];  // [n_splits][D + kAttnPartPad]: the layout attn_split_merge reads
+    constexpr int PG = D + 2;                                      // granules of one partial: M, L, O[D]
+    const uint32_t tag = ((((uint32_t)pos_base[b] & 0x7fffffu) << 8) | ((uint32_t)call_tag & 0xffu)) + 1u;
+    u64_t* gws = reinterpret_cast<u64_t*>(ws) + ((int64_t)b * n_heads + h) * n_splits * PG;
+    if (n_splits == 1) {
+      if (tid < D) store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + tid, L > 0.f ? O / L : 0.f);
+      return;
+    }
+    if (split != 0) {
+      if (tid < D) {
+        u64_t* pr = gws + (int64_t)split * PG;
+        gr_store(pr + 2 + tid, tag, __float_as_uint(O));
+        if (tid == 0) {
+          gr_store(pr, tag, __float_as_uint(M));
+          gr_store(pr + 1, tag, __float_as_uint(L));
+        }
+      }
+      return;
+    }
+    // split 0: own partial straight into the staging area, the others as they arrive
+    if (tid < D) {
+      comb[kAttnPartPad + tid] = O;
+      if (tid == 0) {
+        comb[0] = M;
+        comb[1] = L;
+      }
+    }
+    bool bad = false;
+    for (int i = PG + tid; i < n_splits * PG; i += NW * 64) {
+      u64_t v = 0;
+      int spins = 0;
+      for (;; ++spins) {
+        v = gr_load(gws + i);
+        if ((uint32_t)(v >> 32) == tag) break;
+        if (spins > (1 << 22)) {
+          bad = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const int s_ = i / PG, e = i % PG;
+      comb[s_ * (D + kAttnPartPad) + (e < 2 ? e : e + 2)] = __uint_as_float((uint32_t)v);
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (tid < D) {
+      float o1[1];
+      attn_split_merge<1>(comb, n_splits, D, tid, o1);
+      store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o1[0]);
+    }
+    return;
+  } else {
   if (tid < D) {
     DL_STAMP(3, false);  // workgroup merge done
     if (n_splits == 1) {
@@ -70,6 +128,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     }
   }
   DL_STAMP(4, true);  // stores acknowledged
+  }
 }
 
 constexpr int kMaxSplits = 128;
@@ -89,8 +148,18 @@ template <typename T, int D, int NW, bool FUSED, int U>
 static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t stride_b, int64_t stride_h,
                          const int32_t* kv_len, int extra, void* out, int64_t out_row_stride, void* workspace, int n_splits, int B,
                          int n_heads, int n_kv_heads, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base,
-                         int T_cap, int chunk_keys, hipStream_t st) {
+                         int T_cap, int chunk_keys, hipStream_t st, int call_tag = -1) {
   const float scale = 1.0f / sqrtf((float)D);
+  if constexpr (FUSED) {
+    // in-kernel combine: only when every workgroup of the grid is certainly resident (<= 4 per CU) and the caller gave a call tag
+    if (call_tag >= 0 && n_splits > 1 && (int64_t)n_splits * n_heads * B <= 1024) {
+      const size_t smem = (size_t)n_splits * (D + kAttnPartPad) * sizeof(float);
+      hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, true, U, true>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64),
+                         smem, st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,
+                         out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads, chunk_keys, call_tag);
+      return;
+    }
+  }
   hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, FUSED, U>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64), 0,
                      st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,
                      out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads, chunk_keys);
@@ -105,7 +174,8 @@ using namespace dl;
 
 extern "C" int64_t dl_attn_decode_workspace_bytes(int B, int n_heads, int head_dim, int n_splits) {
   if (n_splits <= 1) return 0;
-  return (int64_t)B * n_heads * n_splits * (head_dim + kAttnPartPad) * (int64_t)sizeof(float);
+  // float partials [D + 4] (separate combine launch) or 8-byte granules [D + 2] (in-kernel combine): sized for the larger
+  return (int64_t)B * n_heads * n_splits * (head_dim + kAttnPartPad) * (int64_t)sizeof(u64_t);
 }
 
 extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t slab_stride_b,
@@ -133,7 +203,7 @@ extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k
 extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
                                    const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
                                    int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
-                                   int keys_in_flight, int chunk_keys, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
+                                   int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
                                    void* stream) {
   DL_REQUIRE(keys_in_flight == 64 || keys_in_flight == 256, "dl_attn_decode_rope: keys_in_flight must be 64 or 256");
   DL_REQUIRE(chunk_keys >= 0, "dl_attn_decode_rope: chunk_keys must be >= 0");
@@ -145,12 +215,14 @@ extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, cons
   hipStream_t st = as_stream(stream);
   // a 16-byte-per-lane row covers head_dim with D/kVec lanes, so one wave-wide load is 64/(D/kVec) keys: U is chosen so that
   // NW * keys-per-load * U = keys_in_flight for the 16-bit dtypes at head_dim 128 (the production shape)
+  // the in-kernel combine is built for the production shape only (U = 4); other variants keep the separate combine launch
+  const int tag4 = (keys_in_flight == 64 && chunk_keys == 0) ? call_tag : -1;
 #define DL_FUSED_ARGS qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride, workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, chunk_keys, st
   DL_DISPATCH_DTYPE(dtype, T, {
     if (head_dim == 128) {
-      if (keys_in_flight == 256) launch_split<T, 128, 4, true, 16>(DL_FUSED_ARGS); else launch_split<T, 128, 4, true, 4>(DL_FUSED_ARGS);
+      if (keys_in_flight == 256) launch_split<T, 128, 4, true, 16>(DL_FUSED_ARGS); else launch_split<T, 128, 4, true, 4>(DL_FUSED_ARGS, tag4);
     } else {
-      if (keys_in_flight == 256) launch_split<T, 64, 4, true, 16>(DL_FUSED_ARGS); else launch_split<T, 64, 4, true, 4>(DL_FUSED_ARGS);
+      if (keys_in_flight == 256) launch_split<T, 64, 4, true, 16>(DL_FUSED_ARGS); else launch_split<T, 64, 4, true, 4>(DL_FUSED_ARGS, tag4);
     }
   });
 #undef DL_FUSED_ARGS

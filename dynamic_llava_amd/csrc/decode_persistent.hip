@@ -22,6 +22,7 @@
 
 #include "attn_decode_body.h"
 #include "gemv_dot.h"
+#include "granule.h"
 
 namespace dl {
 
@@ -34,20 +35,6 @@ constexpr int kPD = 128;         // head_dim
 constexpr int kPartGr = kPD + 2; // granules of one split partial: M, L, O[D]
 constexpr int kCtrlGr = 16;      // control granules at the start of the sync buffer (word 0: abort)
 constexpr int kGU = 44;          // granules per lane per sweep group (pollers: <= 6144 granules in one round trip)
-
-typedef unsigned long long u64_t;
-typedef __attribute__((address_space(1))) u64_t gu64_t;
-typedef __attribute__((address_space(1))) uint32_t gu32_t;
-
-__device__ __forceinline__ void gr_store(u64_t* g, uint32_t tag, uint32_t val) {
-  __hip_atomic_store((gu64_t*)(g), ((u64_t)tag << 32) | (u64_t)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64_t gr_load(const u64_t* g) {
-  return __hip_atomic_load((const gu64_t*)(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t ctr_load(const uint32_t* g) {
-  return __hip_atomic_load((const gu32_t*)(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // Device-side view of DlDecodePhase (same layout): the pointer fields are typed as GLOBAL pointers.  Pointers loaded from memory
 // are generic to the compiler (flat_load: 64-bit VGPR addresses, both wait counters); typed this way it emits global_load with

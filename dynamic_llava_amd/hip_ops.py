@@ -81,7 +81,7 @@ SIGNATURES = {
     ),
     "dl_attn_decode_rope": (
         c_int,
-        [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
@@ -282,7 +282,7 @@ def attn_decode(q, k_slab, v_slab, kv_len, extra, out, workspace, n_splits, n_he
     return out
 
 
-def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, workspace, n_splits, n_heads, n_kv_heads, head_dim, keys_in_flight=64, chunk_keys=0):
+def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, workspace, n_splits, n_heads, n_kv_heads, head_dim, keys_in_flight=64, chunk_keys=0, call_tag=-1):
     """Fused RoPE + KV append + ragged decode attention.  qkv [B, (nH+2nKV)*d] un-rotated (not modified)."""
     _dev(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out)
     assert qkv.stride(1) == 1 and out.stride(1) == 1 and kv_len.dtype == torch.int32 and pos_base.dtype == torch.int32
@@ -291,7 +291,7 @@ def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, works
     _check(
         lib().dl_attn_decode_rope(
             _p(qkv), qkv.stride(0), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(0), k_slab.stride(1),
-            k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), int(keys_in_flight), int(chunk_keys), B, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
+            k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), int(keys_in_flight), int(chunk_keys), int(call_tag), B, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
         ),
         "dl_attn_decode_rope",
     )

@@ -428,6 +428,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._dstate = None
         self._prefill_graphs = {}
         self.use_hip_graph = True
+        self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
         # batch-1 decode step as ONE persistent launch (csrc/decode_persistent.hip): bit-identical to the launch path, but measured SLOWER on
@@ -970,7 +971,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             lens = cache.len_of_layer(i)
             # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
             # only when the row is long enough to need more than one workgroup per head)
-            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d)
+            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d,
+                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
             ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
             ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
             h_cur, h_alt = h_alt, h_cur
@@ -997,7 +999,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
             qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws) if sm else F.linear(st.x, layer.w_qkv)
-            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d)
+            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d,
+                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             if sm:
                 parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)

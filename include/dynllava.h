@@ -102,12 +102,16 @@ int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, cons
  * keys_in_flight = 64 or 256: K/V rows a workgroup requests per loop trip (256 = one HBM round trip for a 256-key split:
  * the batch-1 decode step is latency-bound).  chunk_keys > 0: split s owns keys [s*chunk_keys, (s+1)*chunk_keys) (the last
  * split also takes any remainder), so the K/V rows are requested before kv_len[b] has been read; 0: the kernel balances
- * ceil((kv_len[b]+1) / n_splits) keys per split itself.  Results are identical either way up to the merge order. */
+ * ceil((kv_len[b]+1) / n_splits) keys per split itself.  Results are identical either way up to the merge order.
+ * call_tag >= 0 (with keys_in_flight = 64, chunk_keys = 0, n_splits > 1 and a grid of <= 1024 workgroups): the splits are merged
+ * INSIDE this launch by the workgroup of split 0 (partials travel through `workspace` as self-validating 8-byte granules; same
+ * merge order and bits as the two-launch form).  call_tag must differ between consecutive calls that share `workspace` at the same
+ * pos_base (the layer index does); -1: always the separate merge launch. */
 int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
                         const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab,
                         int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride,
-                        void* workspace, int n_splits, int keys_in_flight, int chunk_keys, int B, int n_heads, int n_kv_heads,
-                        int head_dim, int dtype, void* stream);
+                        void* workspace, int n_splits, int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads,
+                        int n_kv_heads, int head_dim, int dtype, void* stream);
 
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins

@@ -316,6 +316,15 @@ def test_attn_decode_rope_fused_equals_unfused(ops, dtype, nH, nKV, d, n_splits,
         ref = _sdpa_ref(qa[b].cpu()[: nH * d].view(1, nH, d), ka[b, :, :T].cpu().transpose(0, 1), va[b, :, :T].cpu().transpose(0, 1), False)[0]
         err = float((out_b[b].cpu().float().view(nH, d) - ref).abs().max())
         assert err < (2e-5 if dtype == torch.float32 else 3 * ULP[dtype]), (b, err)
+    # in-kernel combine (call_tag >= 0; production shape only: keys_in_flight 64, kernel-balanced splits): split 0's workgroup merges the
+    # granule partials itself -- bit-identical to the two-launch form, also when the same workspace is reused call after call
+    if kif == 64 and chunk == 0 and n_splits > 1:
+        for rep, tag in enumerate([0, 1, 2, 0, 31]):
+            kc, vc = k0.cuda().clone(), v0.cuda().clone()
+            out_c = torch.full((B, nH * d), float("nan"), dtype=dtype, device="cuda")
+            ops.attn_decode_rope(qb, cos.cuda(), sin.cuda(), posd, lens, kc, vc, out_c, ws, n_splits, nH, nKV, d, call_tag=tag)
+            assert torch.equal(out_c, out_b), (rep, tag)
+            assert torch.equal(kc.nan_to_num(7.0), kb.nan_to_num(7.0)) and torch.equal(vc.nan_to_num(7.0), vb.nan_to_num(7.0))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
