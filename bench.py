@@ -479,12 +479,12 @@ def main():
     ] + gemv_shapes + other_kernel_rooflines(model, n_prompt)
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_probe.py under rocprofv3 --pmc, see profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pmc = {r["case"]: r for r in json.load(f)}
         rs = [pmc[k] for k in ("gemv qkv", "gemv o", "gemv gate_up", "gemv down")]
         ratio = sum(r["fetch_bytes_corrected"] + r["write_bytes"] for r in rs) / sum(r["algorithmic_bytes"] for r in rs)
         traffic = int(ratio * roof_main["bytes"])
-        traffic_src = (f"profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes over the four "
+        traffic_src = (f"profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes over the four "
                        f"per-layer dl_gemv shapes: measured traffic / algorithmic bytes = {ratio:.4f}, applied to this run's average launch")
         roof_attn["traffic_over_algorithmic_pmc"] = pmc["decode_attn B=1 T=226"]["traffic_over_algorithmic"]
     except Exception:
