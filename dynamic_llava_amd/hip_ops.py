@@ -83,6 +83,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
+    "dl_attn_decode_rope_oproj": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+         c_int, c_void_p],
+    ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "dl_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -296,6 +301,20 @@ def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, works
         "dl_attn_decode_rope",
     )
     return out
+
+
+def attn_decode_rope_oproj(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, attn_out, workspace, n_splits, call_tag, n_heads, n_kv_heads, head_dim, w_o, y):
+    """Batch 1: fused RoPE + KV append + split-KV attention + o_proj GEMV in one launch (include/dynllava.h)."""
+    _dev(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, attn_out, workspace, w_o, y)
+    assert qkv.shape[0] == 1 and qkv.is_contiguous() and w_o.is_contiguous() and y.is_contiguous() and attn_out.is_contiguous()
+    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
+    _check(
+        lib().dl_attn_decode_rope_oproj(_p(qkv), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(1), k_slab.shape[2],
+                                        _p(attn_out), _p(workspace), int(n_splits), int(call_tag), n_heads, n_kv_heads, head_dim, _p(w_o), w_o.shape[0], _p(y),
+                                        dtype_code(qkv.dtype), _stream()),
+        "dl_attn_decode_rope_oproj",
+    )
+    return y
 
 
 def topk_select(score, k):

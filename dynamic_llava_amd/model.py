@@ -428,6 +428,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._dstate = None
         self._prefill_graphs = {}
         self.use_hip_graph = True
+        self.attn_oproj_fused = True  # batch-1 decode: attention + o_proj GEMV in one launch (dl_attn_decode_rope_oproj)
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
@@ -954,6 +955,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
         h_cur, h_alt, delta = st.h, st.h2, None
         A = ops.GEMV_ADDNORM
+        fuse_o = (self.attn_oproj_fused and st.B == 1 and self.dtype in (torch.bfloat16, torch.float16) and d == 128 and L >= 2 and nH * d <= 8192
+                  and self.attn_inkernel_combine)
         for i, layer in enumerate(self.model.layers):
             ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
             if delta is not None:
@@ -971,9 +974,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             lens = cache.len_of_layer(i)
             # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
             # only when the row is long enough to need more than one workgroup per head)
-            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d,
-                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
-            ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
+            if fuse_o:  # attention + o_proj in one launch: W_o streams while the attention runs
+                ops.attn_decode_rope_oproj(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, nH), i & 0xff,
+                                           nH, nKV, d, layer.self_attn.o_proj.weight, st.o)
+            else:
+                ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d,
+                                     call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
+                ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
             ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
             h_cur, h_alt = h_alt, h_cur
             ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)

@@ -113,6 +113,16 @@ int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos
                         void* workspace, int n_splits, int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads,
                         int n_kv_heads, int head_dim, int dtype, void* stream);
 
+/* ---- batch 1: dl_attn_decode_rope (in-kernel combine) AND the o_proj GEMV y = W_o @ attn (DML:1127) in ONE launch: the GEMV
+ * workgroups request their weight rows at once -- W_o streams while the attention runs -- and pick the attention output up from
+ * granules in `workspace` (dl_attn_decode_workspace_bytes(1, ...)).  Bit-identical to dl_attn_decode_rope + dl_gemv(PLAIN).
+ * qkv: [(nH + 2 nKV) * 128] un-rotated; attn_out [nH * 128] is written too; w_o [N, nH * 128]; y [N].  16-bit dtypes, head_dim 128,
+ * nH * 128 <= 8192; call_tag as dl_attn_decode_rope (>= 0). */
+int dl_attn_decode_rope_oproj(const void* qkv, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base,
+                              const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_h, int T_cap, void* attn_out,
+                              void* workspace, int n_splits, int call_tag, int n_heads, int n_kv_heads, int head_dim, const void* w_o,
+                              int N, void* y, int dtype, void* stream);
+
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
  * (= stable descending sort; the reference's argsort is non-stable).  n <= 4096. */

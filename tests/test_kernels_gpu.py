@@ -629,3 +629,36 @@ def test_kv_pack_rows(ops, dtype, B, nKV, d, T, n_layers):
                     assert torch.equal(got[l, kv, b, :, n0 + T :], slab[l, kv, b, :, n0 + T :])
                 else:
                     assert torch.equal(got[l, kv, b], slab[l, kv, b])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nH,nKV,N,T,n_splits", [(32, 32, 4096, 234, 4), (32, 32, 4096, 695, 8), (40, 40, 5120, 2047, 6), (2, 2, 256, 60, 1), (8, 2, 1000, 130, 3)])
+def test_attn_decode_rope_oproj_fused_equals_two_launches(ops, dtype, nH, nKV, N, T, n_splits):
+    """dl_attn_decode_rope_oproj (attention + o_proj GEMV in one launch, W_o streaming while the attention runs) == dl_attn_decode_rope followed
+    by dl_gemv(PLAIN): attention output, appended K/V and y bit-identical; repeated on the same workspace with changing call tags."""
+    d = 128
+    g = torch.Generator().manual_seed(60)
+    T_cap = T + 8
+    k0 = torch.randn(1, nKV, T_cap, d, generator=g).to(dtype)
+    v0 = torch.randn(1, nKV, T_cap, d, generator=g).to(dtype)
+    k0[0, :, T:] = float("nan")
+    v0[0, :, T:] = float("nan")
+    qkv = torch.randn(1, (nH + 2 * nKV) * d, generator=g).to(dtype).cuda()
+    w_o = (torch.randn(N, nH * d, generator=g) / math.sqrt(nH * d)).to(dtype).cuda()
+    cos, sin = orc.rope_table(d, 4096, 10000.0, dtype)
+    lens = torch.tensor([T], dtype=torch.int32).cuda()
+    posd = torch.tensor([T + 461], dtype=torch.int32).cuda()
+    ws = ops.attn_decode_workspace(1, nH, d, 32, "cuda")
+    ka, va = k0.cuda().clone(), v0.cuda().clone()
+    attn_a = torch.empty(1, nH * d, dtype=dtype, device="cuda")
+    ops.attn_decode_rope(qkv, cos.cuda(), sin.cuda(), posd, lens, ka, va, attn_a, ws, n_splits, nH, nKV, d)
+    y_a = torch.empty(1, N, dtype=dtype, device="cuda")
+    ops.gemv(w_o, y_a, x=attn_a)
+    for rep, tag in enumerate([0, 1, 5, 0]):
+        kb, vb = k0.cuda().clone(), v0.cuda().clone()
+        attn_b = torch.full((1, nH * d), float("nan"), dtype=dtype, device="cuda")
+        y_b = torch.full((1, N), float("nan"), dtype=dtype, device="cuda")
+        ops.attn_decode_rope_oproj(qkv, cos.cuda(), sin.cuda(), posd, lens, kb, vb, attn_b, ws, n_splits, tag, nH, nKV, d, w_o, y_b)
+        assert torch.equal(attn_b, attn_a), (rep, "attention output")
+        assert torch.equal(y_b, y_a), (rep, "o_proj output", float((y_b.float() - y_a.float()).abs().max()))
+        assert torch.equal(ka.nan_to_num(7.0), kb.nan_to_num(7.0)) and torch.equal(va.nan_to_num(7.0), vb.nan_to_num(7.0))
