@@ -428,7 +428,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._dstate = None
         self._prefill_graphs = {}
         self.use_hip_graph = True
-        self.attn_oproj_fused = True  # batch-1 decode: attention + o_proj GEMV in one launch (dl_attn_decode_rope_oproj)
+        # batch-1 decode: attention + o_proj GEMV in ONE launch (dl_attn_decode_rope_oproj, bit-identical).  Measured 17.0 vs 16.3 us per layer for
+        # the two launches (tools/bench_attn_oproj.py): the attention slows down under W_o's stream and the GEMV side still pays two fabric
+        # round trips after it, so it is opt-in
+        self.attn_oproj_fused = False
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
