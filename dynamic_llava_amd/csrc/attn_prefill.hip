@@ -410,6 +410,265 @@ __global__ __launch_bounds__(NW * 64) void attn_prefill_mfma_pipe_kernel(const v
   }
 }
 
+// ---- key-split variant for rows with FEW K/V tiles (fresh prefill: the 170 / 117 tokens a decoder layer >= 2 sees at head_dim 128;
+// the 577 / 576 tokens of the CLIP tower / vision predictor at head_dim 64).  With 3-5 K/V tiles per row the plain kernel is one long
+// dependent chain per workgroup (tools/pf_timing.hip, T=170: per tile 3.5 us of exposed staging + 2.1 us of S -> softmax -> P -> PV,
+// three times, + 1.6 us of 2-byte stores).  Here a workgroup = RW row tiles x KW key tiles of waves: a ROUND stages KW*64 keys at
+// once (one round trip; the next round's rows are already in flight in registers), each wave does S / online softmax / PV for its
+// own 64 keys of the round, and at the end the KW partial (m, l, O) of a row tile are merged through LDS by the kw == 0 wave in key
+// order (deterministic).  V is read coalesced like K and transposed with 8-byte LDS writes into an XOR-swizzled V^T image
+// (conflict-free on both sides).  Output rows leave as 16-byte stores (transposed through LDS).
+template <typename T, int D, bool CAUSAL, int RW, int KW>
+__global__ __launch_bounds__(RW * KW * 64) void attn_prefill_keysplit_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
+                                                                             const void* __restrict__ v_, int64_t q_rs, int64_t kv_rs,
+                                                                             void* __restrict__ out_, int64_t out_rs,
+                                                                             const int32_t* __restrict__ cu, int n_rep, float scale) {
+  using S = uint16_t;
+  constexpr int KS = D / 32, DT = D / 16, NT = kBN / 16;
+  constexpr int NKEY = KW * kBN;                 // keys per round
+  constexpr int LDK = D + kPad, LDV = NKEY + kPad, LDP = kBN + kPad, LDO = D + kPad;
+  constexpr int kBM = 16 * RW, NT_ = RW * KW * 64;
+  constexpr int CPR = D / 8;
+  constexpr int KIT = (NKEY * CPR) / NT_;        // K chunks per thread per round
+  constexpr int VITEMS = (NKEY / 4) * CPR;       // V items (4 keys x one chunk) per round
+  constexpr int VIT = (VITEMS + NT_ - 1) / NT_;  // V items per thread per round
+  constexpr int SW = D == 64 ? 2 : 1;            // swizzle step: a half-wave spans 128 / D key pairs
+  static_assert((NKEY * CPR) % NT_ == 0, "K staging must divide evenly");
+  static_assert(D == 64 || D == 128, "swizzle derived for head_dim 64 / 128");
+  constexpr int kPartF = (DT * 4 + 8) * 64;      // floats per partial: O[DT][4][64 lanes], m[4][64], l[4][64]
+  constexpr int kSmemEl = NKEY * LDK + D * LDV + RW * KW * 16 * LDP;
+  static_assert(RW * (KW - 1) * kPartF * 4 + RW * 16 * LDO * 2 <= kSmemEl * 2, "partials + output staging alias the tile buffers");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S* Ks = reinterpret_cast<S*>(smem);   // [NKEY][LDK]
+  S* Vt = Ks + NKEY * LDK;              // [D][LDV], key pairs swizzled
+  S* Ps = Vt + D * LDV;                 // [RW*KW][16][LDP]
+  float* part = reinterpret_cast<float*>(smem);                               // after the last round: [RW][KW-1][kPartF]
+  S* Os = reinterpret_cast<S*>(smem + RW * (KW - 1) * kPartF * 4);            // and [RW][16][LDO]
+
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  const int q0 = qt * kBM;
+  if (q0 >= L) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int rw = w % RW, kw = w / RW;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kvh = h / n_rep;
+  const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
+  const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const int n_keys = CAUSAL ? min(L, q0 + kBM) : L;  // keys any row of this workgroup can see
+  const int n_rounds = (n_keys + NKEY - 1) / NKEY;
+  DL_PSTAMP(0);
+
+  uint4 kreg[KIT], vreg[VIT][4];
+  auto fetch = [&](int base) {  // round -> registers (zeros beyond n_keys)
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = it * NT_ + tid;
+      const int key = base + idx / CPR, ch = idx % CPR;
+      kreg[it] = make_uint4(0, 0, 0, 0);
+      if (key < n_keys) kreg[it] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * kv_rs + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int item = it * NT_ + tid;  // chunk fastest: 128 / D ... 16 lanes read one whole row (coalesced like K)
+      const int kg = item / CPR, ch = item % CPR;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = base + kg * 4 + j;
+        vreg[it][j] = make_uint4(0, 0, 0, 0);
+        if (item < VITEMS && key < n_keys) vreg[it][j] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * kv_rs + ch * 8);
+      }
+    }
+  };
+  auto stash = [&]() {  // registers -> K (row-major) | V^T (swizzled)
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = it * NT_ + tid;
+      *reinterpret_cast<uint4*>(Ks + (idx / CPR) * LDK + (idx % CPR) * 8) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int item = it * NT_ + tid;
+      if (item < VITEMS) {
+        const int kg = item / CPR, ch = item % CPR;
+        // V^T[dim][key]: the 16-byte key pairs of a row are XOR-swizzled by (dim / 16) within blocks of 8 pairs, so that the lanes
+        // of a half-wave (rows 8 * LDV apart: only two bank offsets) spread over all banks
+        const int pair = kg >> 1;
+        const int col = (((pair & ~7) | ((pair ^ (SW * (ch >> 1))) & 7)) << 3) + ((kg & 1) << 2);
+        const uint32_t w0[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
+        const uint32_t w1[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+        const uint32_t w2[4] = {vreg[it][2].x, vreg[it][2].y, vreg[it][2].z, vreg[it][2].w};
+        const uint32_t w3[4] = {vreg[it][3].x, vreg[it][3].y, vreg[it][3].z, vreg[it][3].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // dims 2e, 2e+1 of the chunk: 4 keys each -> one 8-byte write per dim
+          uint2 lo, hi;
+          lo.x = (w0[e] & 0xffffu) | (w1[e] << 16);
+          lo.y = (w2[e] & 0xffffu) | (w3[e] << 16);
+          hi.x = (w0[e] >> 16) | (w1[e] & 0xffff0000u);
+          hi.y = (w2[e] >> 16) | (w3[e] & 0xffff0000u);
+          *reinterpret_cast<uint2*>(Vt + (ch * 8 + 2 * e) * LDV + col) = lo;
+          *reinterpret_cast<uint2*>(Vt + (ch * 8 + 2 * e + 1) * LDV + col) = hi;
+        }
+      }
+    }
+  };
+
+  fetch(0);
+  uint4 qf[KS];
+  {
+    const int qrow = q0 + rw * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = make_uint4(0, 0, 0, 0);
+      if (qrow < L) qf[ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * q_rs + ks * 32 + lg * 8);
+    }
+  }
+  f32x4_t acc_o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc_o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+  }
+  S* Pw = Ps + w * 16 * LDP;
+  const int row_keys = CAUSAL ? min(L, q0 + rw * 16 + 16) : L;  // keys this wave's rows can see
+  stash();
+  __syncthreads();
+  DL_PSTAMP(1);  // first round staged
+
+  for (int rd = 0; rd < n_rounds; ++rd) {
+    const bool more = rd + 1 < n_rounds;
+    if (more) fetch((rd + 1) * NKEY);
+    const int key0 = rd * NKEY + kw * kBN;  // this wave's 64 keys of the round
+    if (key0 < row_keys) {                  // wave-uniform
+      f32x4_t acc_s[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc_s[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (kw * kBN + nt * 16 + lr) * LDK + ks * 32 + lg * 8);
+          acc_s[nt] = mfma16<T>(qf[ks], kf, acc_s[nt]);
+        }
+      }
+      float alpha[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + rw * 16 + lg * 4 + r;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ki = key0 + nt * 16 + lr;
+          float sv = acc_s[nt][r] * scale;
+          if (ki >= L || (CAUSAL && ki > qi)) sv = -INFINITY;
+          acc_s[nt][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+        mx = row16_max(mx);
+        const float mn = fmaxf(m[r], mx);
+        const float ms = mn == -INFINITY ? 0.f : mn;
+        alpha[r] = __expf(m[r] - ms);
+        float rs = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float p = __expf(acc_s[nt][r] - ms);
+          acc_s[nt][r] = p;
+          rs += p;
+        }
+        rs = row16_sum(rs);
+        l[r] = l[r] * alpha[r] + rs;
+        m[r] = mn;
+      }
+      if (rd > 0) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha[r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pw[(lg * 4 + r) * LDP + nt * 16 + lr] = Elem<T>::from_f(acc_s[nt][r]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ks = 0; ks < kBN / 32; ++ks) {
+        const uint4 pf = *reinterpret_cast<const uint4*>(Pw + lr * LDP + ks * 32 + lg * 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int pair = kw * 8 + ks * 4 + lg;  // keys kw*64 + ks*32 + lg*8 .. +8 of the round, un-swizzled with dim / 16 = dt
+          const uint4 vf = *reinterpret_cast<const uint4*>(Vt + (dt * 16 + lr) * LDV + (((pair & ~7) | ((pair ^ (SW * dt)) & 7)) << 3));
+          acc_o[dt] = mfma16<T>(pf, vf, acc_o[dt]);
+        }
+      }
+    }
+    __syncthreads();  // the round's K / V^T are dead
+    if (more) {
+      stash();
+      __syncthreads();
+    }
+  }
+  DL_PSTAMP(2);  // all rounds
+  if (kw > 0) {
+    float* pp = part + ((rw * (KW - 1)) + (kw - 1)) * kPartF;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[(dt * 4 + r) * 64 + lane] = acc_o[dt][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pp[(DT * 4 + r) * 64 + lane] = m[r];
+      pp[(DT * 4 + 4 + r) * 64 + lane] = l[r];
+    }
+  }
+  __syncthreads();
+  DL_PSTAMP(3);  // partials exchanged
+  if (kw > 0) return;
+  // ---- merge in key order ----
+#pragma unroll
+  for (int j = 1; j < KW; ++j) {
+    const float* pp = part + ((rw * (KW - 1)) + (j - 1)) * kPartF;
+    float a_own[4], a_oth[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mo = pp[(DT * 4 + r) * 64 + lane], lo = pp[(DT * 4 + 4 + r) * 64 + lane];
+      const float mn = fmaxf(m[r], mo);
+      const float ms = mn == -INFINITY ? 0.f : mn;
+      a_own[r] = __expf(m[r] - ms);
+      a_oth[r] = __expf(mo - ms);
+      l[r] = l[r] * a_own[r] + lo * a_oth[r];
+      m[r] = mn;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_o[dt][r] = acc_o[dt][r] * a_own[r] + pp[(dt * 4 + r) * 64 + lane] * a_oth[r];
+  }
+  // ---- epilogue: C layout -> LDS -> 16-byte row stores ----
+  S* Ow = Os + rw * 16 * LDO;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) Ow[(lg * 4 + r) * LDO + dt * 16 + lr] = Elem<T>::from_f(acc_o[dt][r] * inv);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  S* ob = reinterpret_cast<S*>(out_) + (int64_t)tok0 * out_rs + (int64_t)h * D;
+#pragma unroll
+  for (int i = 0; i < (16 * CPR) / 64; ++i) {
+    const int c = i * 64 + lane;
+    const int row = c / CPR, ch = c % CPR;
+    const int qi = q0 + rw * 16 + row;
+    if (qi < L) *reinterpret_cast<uint4*>(ob + (int64_t)qi * out_rs + ch * 8) = *reinterpret_cast<const uint4*>(Ow + row * LDO + ch * 8);
+  }
+  DL_PSTAMP(7);
+}
+
 // ---- generic path: one wave per query row, lanes over keys (scores) then over dims (output) ----
 template <typename T>
 __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
@@ -520,6 +779,37 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
     } else {                                                                                                                             \
       DL_LAUNCH_PLAIN(NWV, CAUS)                                                                                                         \
     }                                                                                                                                    \
+  }
+  // key-split kernel (one workgroup per CU: 90-120 KB of LDS): fresh prefill while the launch fits the chip in a single round of
+  // workgroups -- at larger batches the plain kernel's three resident workgroups per CU win.
+  //   head_dim 128, causal, 64 < rows <= 192 (decoder layers >= 2 at B=1): 32 rows x (2 | 3) key tiles, one round  (T=170: 15.2 -> 8.9 us)
+  //   head_dim 64, full, rows > 128 (CLIP tower, vision predictor): 64 rows x 4 key tiles, rounds of 256 keys
+  if constexpr (D == 128 || D == 64) {
+    bool ksplit = false;
+    if (D == 128) ksplit = causal && !kv_len && max_seqlen > 64 && max_seqlen <= 192 && (int64_t)B * n_heads * ((max_seqlen + 31) / 32) <= 256;
+    if (D == 64) ksplit = !causal && !kv_len && max_seqlen > 128 && (int64_t)B * n_heads * ((max_seqlen + 63) / 64) <= 256;
+    if (const char* e = getenv("DL_PF_KSPLIT")) ksplit = ksplit && atoi(e) != 0;  // tuning experiments only
+    if (ksplit) {
+#define DL_LAUNCH_KS(CAUS, RWV, KWV)                                                                                                     \
+  {                                                                                                                                      \
+    const dim3 grid((unsigned)((max_seqlen + 16 * RWV - 1) / (16 * RWV)), (unsigned)n_heads, (unsigned)B);                              \
+    const size_t smem = (size_t)(KWV * 64 * (D + kPad) + D * (KWV * 64 + kPad) + RWV * KWV * 16 * (kBN + kPad)) * 2;                     \
+    auto kfn = attn_prefill_keysplit_kernel<T, D, CAUS, RWV, KWV>;                                                                       \
+    static bool attr_set = false;                                                                                                        \
+    if (!attr_set) {                                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);             \
+      attr_set = true;                                                                                                                   \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL(kfn, grid, dim3(RWV * KWV * 64), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale);                  \
+  }
+      if constexpr (D == 128) {
+        if (max_seqlen <= 128) DL_LAUNCH_KS(true, 2, 2) else DL_LAUNCH_KS(true, 2, 3)
+      } else {
+        DL_LAUNCH_KS(false, 4, 4)
+      }
+#undef DL_LAUNCH_KS
+      return;
+    }
   }
   if (causal) {
     if (nw == 4) DL_LAUNCH_PF(4, true) else if (nw == 2) DL_LAUNCH_PF(2, true) else DL_LAUNCH_PF(1, true)

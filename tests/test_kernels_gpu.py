@@ -230,7 +230,7 @@ def _sdpa_ref(q, k, v, causal):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (4, 2, 128, [129]), (4, 2, 128, [300, 631, 17, 257]), (2, 2, 32, [37, 150, 5])])
+@pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (16, 16, 64, [577]), (4, 2, 64, [129, 300]), (4, 2, 128, [129]), (32, 32, 128, [170]), (4, 4, 128, [117, 65, 192, 3]), (4, 4, 128, [128, 66]), (4, 2, 128, [300, 631, 17, 257]), (2, 2, 32, [37, 150, 5])])
 def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
     g = torch.Generator().manual_seed(8)
     total = sum(lens)

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   hipEventCreate(&e1);
   const char* q = (const char*)qkv;
   for (int it = 0; it < 8; ++it) {
-    hipMemsetAsync(flush, it, flush_bytes, st);
+    if (!getenv("DL_PF_WARM")) hipMemsetAsync(flush, it, flush_bytes, st);
     hipStreamSynchronize(st);
     hipEventRecord(e0, st);
     int rc = dl_attn_prefill(q, q + (size_t)H * 2, q + (size_t)2 * H * 2, 3 * H, 3 * H, out, H, cu, 1, T, nH, nH, d, 1, DL_BF16, st);
@@ -36,7 +36,11 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     long long s[16];
     hipMemcpyFromSymbol(s, HIP_SYMBOL(dl::g_pf_stamps), sizeof(s));
-    if (it >= 6)
+    if (it >= 6 && getenv("DL_PF_RAW")) {
+      printf("T=%d: event %.2f us | stamps since entry:", T, ms * 1e3);
+      for (int i = 1; i < 8; ++i) printf(" [%d] %.2f", i, (s[i] - s[0]) * 0.01);
+      printf("\n");
+    } else if (it >= 6)
       printf("T=%d: event %.2f us | staged %.2f | S %.2f | softmax %.2f | P->LDS %.2f | PV %.2f | remaining tiles %.2f | epilogue %.2f us\n", T, ms * 1e3,
              (s[1] - s[0]) * 0.01, (s[2] - s[1]) * 0.01, (s[3] - s[2]) * 0.01, (s[4] - s[3]) * 0.01, (s[5] - s[4]) * 0.01, (s[6] - s[5]) * 0.01,
              (s[7] - s[6]) * 0.01);
