@@ -557,3 +557,58 @@ class Oracle:
                 lens = [t.clone() for t in pkv[1]]
                 trace.append(dict(logits=logits[:, -1].clone(), text_decision=self.records.get("text_decision"), true_cache_length=lens, kv_len_last=pkv[0][-1][0].shape[-2]))
         return torch.stack(out, dim=1), pkv
+
+
+# --------------------------------------------------------------------------------------------
+# N5: training-time ops (checker for dynamic_llava_amd/train_ops.py)
+# --------------------------------------------------------------------------------------------
+def softmax_with_policy(attn, policy, eps=1e-6):
+    """DML:913-930.  attn [B,H,N,N] scores (mask already added), policy [B,N,1] keep decisions (differentiable).
+    A dropped key j keeps weight only on the diagonal (i == j); `eps / N` is added to EVERY entry, masked ones included."""
+    B, N, _ = policy.size()
+    attn_policy = policy.reshape(B, 1, 1, N)
+    eye = torch.eye(N, dtype=attn_policy.dtype, device=attn_policy.device).view(1, 1, N, N)
+    attn_policy = attn_policy + (1.0 - attn_policy) * eye
+    max_att = torch.max(attn, dim=-1, keepdim=True)[0]
+    attn = attn - max_att
+    attn = attn.to(torch.float32).exp_() * attn_policy.to(torch.float32)
+    attn = (attn + eps / N) / (attn.sum(dim=-1, keepdim=True) + eps)
+    return attn.type_as(max_att)
+
+
+def sdpa_with_policy(query, key, value, attn_mask=None, is_causal=False, scale=None, policy=None):
+    """DML:933-970 with dropout_p = 0 (`attention_dropout` is 0.0 in every shipped config).  [B,H,L,d] tensors."""
+    B = query.size(0)
+    L, S = query.size(-2), key.size(-2)
+    scale_factor = 1 / math.sqrt(query.size(-1)) if scale is None else scale
+    if attn_mask is not None:
+        attn_bias = torch.zeros_like(attn_mask, dtype=query.dtype)
+    else:
+        attn_bias = torch.zeros(B, 1, L, S, dtype=query.dtype, device=query.device)
+    if is_causal:
+        assert attn_mask is None
+        temp_mask = torch.ones(B, 1, L, S, dtype=torch.bool, device=query.device).tril(diagonal=0)
+        attn_bias.masked_fill_(temp_mask.logical_not(), float("-inf"))
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            attn_bias.masked_fill_(attn_mask.logical_not(), float("-inf"))
+        else:
+            attn_bias += attn_mask
+    attn_weight = query @ key.transpose(-2, -1) * scale_factor
+    attn_weight += attn_bias
+    if policy is not None:
+        attn_weight = softmax_with_policy(attn_weight, policy=policy)
+    else:
+        attn_weight = torch.softmax(attn_weight, dim=-1)
+    return attn_weight @ value
+
+
+def gumbel_hard_keep(log_probs, gumbels, tau, prev_decision):
+    """DML:1868-1876: `F.gumbel_softmax(log_probs, tau, hard=True)[:, :, 0:1] * prev_decision` with the Gumbel noise
+    passed in (torch draws it as `-empty_like(logits).exponential_().log()`); straight-through estimator."""
+    y = (log_probs + gumbels) / tau
+    y_soft = y.softmax(-1)
+    index = y_soft.max(-1, keepdim=True)[1]
+    y_hard = torch.zeros_like(log_probs).scatter_(-1, index, 1.0)
+    ret = y_hard - y_soft.detach() + y_soft
+    return ret[:, :, 0:1] * prev_decision

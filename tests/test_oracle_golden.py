@@ -122,3 +122,52 @@ def test_dense_keep_rate_one_is_identity(golden_dir):
     n = g["position_ids"].shape[1]
     np.testing.assert_array_equal(g["position_ids"][0], np.arange(n))
     assert g["kv_len_last"][0] == g["kv_len_first"][0]
+
+
+# ---- N5: training-time ops (goldens from oracle/make_golden_train.py = the reference's own functions + autograd) ----
+def _train_golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "train_ops.npz"))
+
+
+@pytest.mark.parametrize("name,dtype,causal,n_pad", [("f32_causal", torch.float32, True, 0), ("bf16_causal", torch.bfloat16, True, 0),
+                                                     ("f32_mask", torch.float32, False, 7), ("bf16_mask", torch.bfloat16, False, 7)])
+def test_train_ops_sdpa_with_policy_oracle_equals_reference(name, dtype, causal, n_pad):
+    """oracle.sdpa_with_policy (DML:913-970 restated) forward and autograd gradients == the reference's, bit for bit."""
+    from oracle import ref_cpu as O
+    from oracle.make_golden_train import case_inputs, hf_mask
+
+    G = _train_golden()
+    q, k, v, do, pol = case_inputs(11, 2, 2, 40, 32, dtype)
+    q, k, v, pol = (t.clone().requires_grad_(True) for t in (q, k, v, pol))
+    mask = None if causal else hf_mask(2, 40, n_pad, dtype)
+    o = O.sdpa_with_policy(q, k, v, attn_mask=mask, is_causal=causal, policy=pol)
+    o.backward(do)
+    for key, t in [("o", o), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad), ("dpolicy", pol.grad)]:
+        np.testing.assert_array_equal(t.detach().float().numpy(), G[f"sdpa_{name}_{key}"], err_msg=key)
+
+
+def test_train_ops_softmax_with_policy_oracle_equals_reference():
+    from oracle import ref_cpu as O
+
+    G = _train_golden()
+    out = O.softmax_with_policy(torch.from_numpy(G["softmax_in_attn"]), torch.from_numpy(G["softmax_in_policy"]))
+    np.testing.assert_array_equal(out.numpy(), G["softmax_out"])
+    # a dropped key keeps weight on the diagonal only (up to the eps / N floor)
+    pol = G["softmax_in_policy"][0, :, 0]
+    j = int(np.where(pol == 0)[0][0])
+    off_diag = np.delete(out.numpy()[0, 0, :, j], j)
+    assert off_diag.max() < 1e-6 and out.numpy()[0, 0, j, j] > 1e-4
+
+
+@pytest.mark.parametrize("name,dtype", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_train_ops_gumbel_hard_keep_oracle_equals_reference(name, dtype):
+    from oracle import ref_cpu as O
+
+    G = _train_golden()
+    lp = torch.from_numpy(G[f"gumbel_{name}_logp"]).to(dtype).requires_grad_(True)
+    keep = O.gumbel_hard_keep(lp, torch.from_numpy(G[f"gumbel_{name}_noise"]).to(dtype), 0.7, torch.from_numpy(G[f"gumbel_{name}_prev"]).to(dtype))
+    keep.backward(torch.from_numpy(G[f"gumbel_{name}_w"]).to(dtype))
+    np.testing.assert_array_equal(keep.detach().float().numpy(), G[f"gumbel_{name}_keep"])
+    np.testing.assert_array_equal(lp.grad.float().numpy(), G[f"gumbel_{name}_dlogp"])
