@@ -102,6 +102,13 @@ SIGNATURES = {
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
+    "dl_attn_policy_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
+    "dl_attn_policy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "dl_attn_policy_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int64, c_int64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "dl_gumbel_hard_keep_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
+    "dl_gumbel_hard_keep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
     "dl_kv_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dl_decode_persistent_sync_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -461,6 +468,64 @@ def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos
         "dl_decode_advance",
     )
     return next_ids
+
+
+def _strides3(t):
+    assert t.dim() == 4 and t.stride(3) == 1
+    return (c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def attn_policy_workspace(B, H, L, d, device):
+    return torch.empty(int(lib().dl_attn_policy_workspace_floats(B, H, L, d)), device=device, dtype=torch.float32)
+
+
+def _bias_args(bias, B, L):
+    if bias is None:
+        return None, 0, 0
+    assert bias.dim() == 4 and bias.shape[1] == 1 and bias.shape[2] == L and bias.shape[3] == L and bias.stride(3) == 1 and bias.shape[0] in (1, B)
+    return bias, (bias.stride(0) if bias.shape[0] == B else 0), bias.stride(2)
+
+
+def attn_policy_fwd(q, k, v, out, policy, bias, row_max, row_denom, workspace, causal, scale, eps, n_for_eps):
+    """q/k/v/out: [B,H,L,d] views (d contiguous; q, k, v with equal strides); policy fp32 [B,L]; see include/dynllava.h."""
+    _dev(q, k, v, out, policy, bias, row_max, row_denom, workspace)
+    B, H, L, d = q.shape
+    assert k.stride() == q.stride() and v.stride() == q.stride() and policy.dtype == torch.float32 and policy.is_contiguous()
+    bias, bsb, bsl = _bias_args(bias, B, L)
+    _check(
+        lib().dl_attn_policy_fwd(_p(q), _p(k), _p(v), _strides3(q), _p(out), _strides3(out), _p(policy), _p(bias), bsb, bsl, _p(row_max), _p(row_denom), _p(workspace),
+                                 B, H, L, d, int(bool(causal)), float(scale), float(eps), int(n_for_eps), dtype_code(q.dtype), _stream()),
+        "dl_attn_policy_fwd",
+    )
+    return out
+
+
+def attn_policy_bwd(q, k, v, out, d_out, dq, dk, dv, policy, bias, row_max, row_denom, dpolicy_heads, workspace, causal, scale, eps, n_for_eps):
+    _dev(q, k, v, out, d_out, dq, dk, dv, policy, bias, row_max, row_denom, dpolicy_heads, workspace)
+    B, H, L, d = q.shape
+    assert k.stride() == q.stride() and v.stride() == q.stride()
+    assert d_out.stride() == out.stride() and dq.stride() == out.stride() and dk.stride() == out.stride() and dv.stride() == out.stride()
+    bias, bsb, bsl = _bias_args(bias, B, L)
+    _check(
+        lib().dl_attn_policy_bwd(_p(q), _p(k), _p(v), _strides3(q), _p(out), _p(d_out), _p(dq), _p(dk), _p(dv), _strides3(out), _p(policy), _p(bias), bsb, bsl,
+                                 _p(row_max), _p(row_denom), _p(dpolicy_heads), _p(workspace), B, H, L, d, int(bool(causal)), float(scale), float(eps), int(n_for_eps),
+                                 dtype_code(q.dtype), _stream()),
+        "dl_attn_policy_bwd",
+    )
+
+
+def gumbel_hard_keep_fwd(log_probs, gumbels, prev, keep, y_soft, tau):
+    _dev(log_probs, gumbels, prev, keep, y_soft)
+    assert log_probs.is_contiguous() and gumbels.is_contiguous() and prev.is_contiguous() and log_probs.shape[-1] == 2
+    n = log_probs.numel() // 2
+    _check(lib().dl_gumbel_hard_keep_fwd(_p(log_probs), _p(gumbels), _p(prev), _p(keep), _p(y_soft), n, float(tau), dtype_code(log_probs.dtype), _stream()), "dl_gumbel_hard_keep_fwd")
+
+
+def gumbel_hard_keep_bwd(d_keep, prev, y_soft, d_log_probs, tau, d_prev=None):
+    _dev(d_keep, prev, y_soft, d_log_probs, d_prev)
+    assert d_keep.is_contiguous() and prev.is_contiguous() and y_soft.is_contiguous()
+    n = y_soft.numel() // 2
+    _check(lib().dl_gumbel_hard_keep_bwd(_p(d_keep), _p(prev), _p(y_soft), _p(d_log_probs), _p(d_prev), n, float(tau), dtype_code(y_soft.dtype), _stream()), "dl_gumbel_hard_keep_bwd")
 
 
 def launch_probe(grid=1, block=64):

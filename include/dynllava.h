@@ -317,6 +317,38 @@ int dl_add_rmsnorm_parts(void* h, const float* parts, int n_slices, const void* 
                          int dtype, void* stream);
 int dl_silu_mul_parts(const float* parts, int n_slices, void* out, int64_t rows, int I, int dtype, void* stream);
 
+/* ---- N5: training-time ops.
+ * dl_attn_policy_fwd / _bwd replace `scaled_dot_product_attention_with_policy` + `softmax_with_policy` (DML:913-970) and their
+ * autograd graph: self-attention whose softmax is gated by a differentiable per-key keep policy,
+ *   A_ij = (exp(s_ij - max_j s_ij) * p'_ij + eps / N) / (sum_j exp(..) * p'_ij + eps),  p'_ij = policy[b,j] (1 on the diagonal),
+ * without materialising the [B,H,N,N] tensors.  q, k, v: [B,H,L,d] views with element strides qkv_strides = {b, h, l} (d contiguous;
+ * the same strides for all three); out / d_out / dq / dk / dv: [B,H,L,d] views with o_strides.  policy: fp32 [B,L].
+ * Masking: causal != 0 (is_causal=True, DML:944-950) or `bias` = additive mask in the model dtype, [B or 1, 1, L, L] with element
+ * strides bias_stride_b / bias_stride_row (DML:952-957; finfo.min as transformers builds it, or -inf), or neither.
+ * row_max / row_denom: fp32 [B,H,L] saved by the forward for the backward.  n_for_eps: the N of eps / N (the padded key count).
+ * workspace: dl_attn_policy_workspace_floats(B, H, L, d) floats, the same buffer for both calls.
+ * dpolicy_heads: fp32 [B,H,L]; dpolicy[b,j] = sum_h dpolicy_heads[b,h,j] (summed by the caller: deterministic, no atomics).
+ * bf16 / f16, head_dim 64 or 128; dropout_p must be 0 (attention_dropout = 0.0 in every shipped config).  The O(eps) gradient through
+ * max_j is not propagated. */
+int64_t dl_attn_policy_workspace_floats(int B, int H, int L, int head_dim);
+int dl_attn_policy_fwd(const void* q, const void* k, const void* v, const int64_t* qkv_strides, void* out, const int64_t* o_strides,
+                       const float* policy, const void* bias, int64_t bias_stride_b, int64_t bias_stride_row, float* row_max,
+                       float* row_denom, float* workspace, int B, int H, int L, int head_dim, int causal, float scale, float eps,
+                       int n_for_eps, int dtype, void* stream);
+int dl_attn_policy_bwd(const void* q, const void* k, const void* v, const int64_t* qkv_strides, const void* out, const void* d_out,
+                       void* dq, void* dk, void* dv, const int64_t* o_strides, const float* policy, const void* bias,
+                       int64_t bias_stride_b, int64_t bias_stride_row, const float* row_max, const float* row_denom,
+                       float* dpolicy_heads, float* workspace, int B, int H, int L, int head_dim, int causal, float scale, float eps,
+                       int n_for_eps, int dtype, void* stream);
+/* Gumbel hard keep mask, DML:1868-1876: keep = F.gumbel_softmax(log_probs, tau, hard=True)[..., 0] * prev_decision with the noise
+ * drawn by the caller (`-empty_like(log_probs).exponential_().log()`, torch's generator).  log_probs / gumbels / y_soft /
+ * d_log_probs: [n,2]; prev_decision / keep / d_keep / d_prev (may be NULL): [n]; all in `dtype` (f32 / f16 / bf16), rounded where the
+ * eager ops round. */
+int dl_gumbel_hard_keep_fwd(const void* log_probs, const void* gumbels, const void* prev_decision, void* keep, void* y_soft, int64_t n,
+                            float tau, int dtype, void* stream);
+int dl_gumbel_hard_keep_bwd(const void* d_keep, const void* prev_decision, const void* y_soft, void* d_log_probs, void* d_prev, int64_t n,
+                            float tau, int dtype, void* stream);
+
 /* ---- diagnostics: one empty kernel (launch-floor measurements, tools/bench_launch_floor.py). */
 int dl_launch_probe(int grid, int block, void* stream);
 
