@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restri
   S* Ks = reinterpret_cast<S*>(smem);        // [64][LDR]
   S* Vt = Ks + kTpTile * St::LDR;            // [D][LDT] swizzled
   S* Ps = Vt + D * St::LDT;                  // [4][16][LDP]
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;  // causal: longest rows first
   const int q0 = qt * kTpTile;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const S* qb = reinterpret_cast<const S*>(q_) + b * qs.b + h * qs.h;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dq_kernel(const void* __res
   S* Vs = Ks + kTpTile * St::LDR;            // [64][LDR]
   S* Kt = Vs + kTpTile * St::LDR;            // [D][LDT] swizzled
   S* Ps = Kt + D * St::LDT;                  // [4][16][LDP]
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;  // causal: longest rows first
   const int q0 = qt * kTpTile;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const S* qb = reinterpret_cast<const S*>(q_) + b * qs.b + h * qs.h;
