@@ -582,6 +582,35 @@ def test_harness_long_text_kv_length_curve_matches_reference_golden(golden_dir):
     assert len(rec["max_memory"]) == n and all(m > 0 for m in rec["max_memory"])
 
 
+def test_harness_long_text_time_no_cache_drives_the_reference_loop(golden_dir):
+    """SURVEY A9 / BLTN:316-357: tools/harness_long_text_time_no_cache.py runs the reference's no-KV-cache timing loop
+    (`model(total_input_ids, images=, past_key_values=None, use_cache=False)` per label token, teacher forcing) with its record format,
+    on the golden no-cache case: the loop must reach the same final logits as the golden's last step."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("harness_bltn", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "harness_long_text_time_no_cache.py"))
+    h = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(h)
+    name = "tiny_fp32_nocache"
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    forced = torch.from_numpy(g["forced"]).cuda()
+    n = g["step_logits"].shape[0]
+    images = fx.make_images(cfg, ids.shape[0], seed=0).to(dtype).cuda()
+    rec = h.run(model, ids, forced[:n].t().contiguous(), images)
+    assert rec["output_token_length"] == list(range(1, n + 1)) and len(rec["step_time_ms"]) == n and all(t > 0 for t in rec["step_time_ms"])
+    assert all(m > 0 for m in rec["max_memory"]) and abs(rec["total_time_ms"] - sum(rec["step_time_ms"])) < 1e-6
+    # the stateful answer_indice left behind by the loop is the reference's: one more direct call reproduces the golden's next step
+    total = torch.cat([ids, forced[: n - 1].t()], dim=1)
+    model2 = _build(cfg, sd, clip, dtype)
+    for j in range(n):
+        out = model2(torch.cat([ids, forced[:j].t()], dim=1), images=images, use_cache=False)
+    assert total.shape[1] == ids.shape[1] + n - 1
+    assert np.abs(out.logits[:, -1].cpu().numpy() - g["step_logits"][n - 1]).max() < 1e-3
+
+
 @pytest.mark.parametrize("side,tmax", [("right", None), ("left", None), ("right", 42), ("left", 42)])
 def test_prepare_inputs_padding_side_and_truncation_vs_oracle(side, tmax):
     """ARCH:493-579 (the oracle is pinned to the live reference for exactly these cases in tests/test_oracle_vs_reference.py): ragged
