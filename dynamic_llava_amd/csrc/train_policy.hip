@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void tp_delta_kernel(const void* __restrict__ 
 }
 
 // ---- forward ----
-template <typename T, int D, bool CAUSAL>
+// RT row tiles of 16 per wave (a workgroup = 64 * RT query rows): every K / V^T fragment read from LDS feeds RT MFMAs.  With one row
+// tile per wave the kernel is LDS-bound (34 KB of fragment reads per 32 MFMAs and wave; 8 waves per CU share 128 B/clk).
+template <typename T, int D, bool CAUSAL, int RT>
 __global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
                                                             TpStrides qs, void* __restrict__ o_, TpStrides os, const float* __restrict__ policy,
                                                             const void* __restrict__ bias_, int64_t bias_sb, int64_t bias_sl,
@@ -179,39 +181,45 @@ __global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restri
   using S = uint16_t;
   using St = TpStage<D>;
   constexpr int KS = D / 32, DT = D / 16, NT = kTpTile / 16, LDP = kTpTile + kTpPad;
+  constexpr int kRows = kTpTile * RT;  // query rows per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S* Ks = reinterpret_cast<S*>(smem);        // [64][LDR]
   S* Vt = Ks + kTpTile * St::LDR;            // [D][LDT] swizzled
-  S* Ps = Vt + D * St::LDT;                  // [4][16][LDP]
+  S* Ps = Vt + D * St::LDT;                  // [4][RT][16][LDP]
   const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;  // causal: longest rows first
-  const int q0 = qt * kTpTile;
+  const int q0 = qt * kRows;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const S* qb = reinterpret_cast<const S*>(q_) + b * qs.b + h * qs.h;
   const S* kb = reinterpret_cast<const S*>(k_) + b * qs.b + h * qs.h;
   const S* vb = reinterpret_cast<const S*>(v_) + b * qs.b + h * qs.h;
   const float* pol = policy + (int64_t)b * L;
   const S* bias = bias_ ? reinterpret_cast<const S*>(bias_) + b * bias_sb : nullptr;
+  const int wrow0 = q0 + w * 16 * RT;  // this wave's first row; row tile rt covers wrow0 + rt*16 .. +16
 
-  uint4 qf[KS];
-  {
-    const int qrow = q0 + w * 16 + lr;
+  uint4 qf[RT][KS];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int qrow = wrow0 + rt * 16 + lr;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      qf[ks] = make_uint4(0, 0, 0, 0);
-      if (qrow < L) qf[ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * qs.l + ks * 32 + lg * 8);
+      qf[rt][ks] = make_uint4(0, 0, 0, 0);
+      if (qrow < L) qf[rt][ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * qs.l + ks * 32 + lg * 8);
     }
   }
-  tp_f32x4_t acc_o[DT];
+  tp_f32x4_t acc_o[RT][DT];
+  float m[RT][4], l[RT][4];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) acc_o[i] = tp_f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m[4], l[4];
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    m[r] = -INFINITY;
-    l[r] = 0.f;
+    for (int i = 0; i < DT; ++i) acc_o[rt][i] = tp_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m[rt][r] = -INFINITY;
+      l[rt][r] = 0.f;
+    }
   }
-  S* Pw = Ps + w * 16 * LDP;
-  const int n_tiles = CAUSAL ? min((L + kTpTile - 1) / kTpTile, qt + 1) : (L + kTpTile - 1) / kTpTile;
+  S* Pw = Ps + w * RT * 16 * LDP;
+  const int n_tiles = CAUSAL ? min((L + kTpTile - 1) / kTpTile, (q0 + kRows - 1) / kTpTile + 1) : (L + kTpTile - 1) / kTpTile;
   uint4 kreg[St::RIT], vreg[St::TIT][4];
   tp_fetch_rows<D>(kb, qs.l, 0, L, tid, kreg);
   tp_fetch_t<D>(vb, qs.l, 0, L, tid, vreg);
@@ -224,86 +232,101 @@ __global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restri
       tp_fetch_rows<D>(kb, qs.l, key0 + kTpTile, L, tid, kreg);
       tp_fetch_t<D>(vb, qs.l, key0 + kTpTile, L, tid, vreg);
     }
-    float pk[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int ki = key0 + nt * 16 + lr;
-      pk[nt] = ki < L ? pol[ki] : 0.f;
-    }
-    tp_f32x4_t acc_s[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      acc_s[nt] = tp_f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (nt * 16 + lr) * St::LDR + ks * 32 + lg * 8);
-        acc_s[nt] = tp_mfma<T>(qf[ks], kf, acc_s[nt]);
-      }
-    }
-    float alpha[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qi = q0 + w * 16 + lg * 4 + r;
-      float mx = -INFINITY;
+    if (!CAUSAL || key0 <= wrow0 + 16 * RT - 1) {  // wave-uniform: tiles wholly in this wave's future are skipped
+      float pk[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int ki = key0 + nt * 16 + lr;
-        float sv = acc_s[nt][r] * scale;
-        if (bias && qi < L && ki < L) sv += Elem<T>::to_f(bias[(int64_t)qi * bias_sl + ki]);
-        if (ki >= L || (CAUSAL && ki > qi)) sv = -INFINITY;
-        acc_s[nt][r] = sv;
-        mx = fmaxf(mx, sv);
+        pk[nt] = ki < L ? pol[ki] : 0.f;
       }
-      mx = row16_max(mx);
-      const float mn = fmaxf(m[r], mx);
-      const float ms = mn == -INFINITY ? 0.f : mn;
-      alpha[r] = __expf(m[r] - ms);
-      float rs = 0.f;
+      tp_f32x4_t acc_s[RT][NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int ki = key0 + nt * 16 + lr;
-        const float p = __expf(acc_s[nt][r] - ms) * (ki == qi ? 1.0f : pk[nt]);
-        acc_s[nt][r] = p;
-        rs += p;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc_s[rt][nt] = tp_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (nt * 16 + lr) * St::LDR + ks * 32 + lg * 8);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc_s[rt][nt] = tp_mfma<T>(qf[rt][ks], kf, acc_s[rt][nt]);
+        }
       }
-      rs = row16_sum(rs);
-      l[r] = l[r] * alpha[r] + rs;
-      m[r] = mn;
-    }
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int rt = 0; rt < RT; ++rt) {
+        float alpha[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha[r];
+        for (int r = 0; r < 4; ++r) {
+          const int qi = wrow0 + rt * 16 + lg * 4 + r;
+          float mx = -INFINITY;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+          for (int nt = 0; nt < NT; ++nt) {
+            const int ki = key0 + nt * 16 + lr;
+            float sv = acc_s[rt][nt][r] * scale;
+            if (bias && qi < L && ki < L) sv += Elem<T>::to_f(bias[(int64_t)qi * bias_sl + ki]);
+            if (ki >= L || (CAUSAL && ki > qi)) sv = -INFINITY;
+            acc_s[rt][nt][r] = sv;
+            mx = fmaxf(mx, sv);
+          }
+          mx = row16_max(mx);
+          const float mn = fmaxf(m[rt][r], mx);
+          const float ms = mn == -INFINITY ? 0.f : mn;
+          alpha[r] = __expf(m[rt][r] - ms);
+          float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Pw[(lg * 4 + r) * LDP + nt * 16 + lr] = Elem<T>::from_f(acc_s[nt][r]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+          for (int nt = 0; nt < NT; ++nt) {
+            const int ki = key0 + nt * 16 + lr;
+            const float p = __expf(acc_s[rt][nt][r] - ms) * (ki == qi ? 1.0f : pk[nt]);
+            acc_s[rt][nt][r] = p;
+            rs += p;
+          }
+          rs = row16_sum(rs);
+          l[rt][r] = l[rt][r] * alpha[r] + rs;
+          m[rt][r] = mn;
+        }
 #pragma unroll
-    for (int ks = 0; ks < kTpTile / 32; ++ks) {
-      const uint4 pf = *reinterpret_cast<const uint4*>(Pw + lr * LDP + ks * 32 + lg * 8);
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc_o[dt] = tp_mfma<T>(pf, tp_tfrag<D>(Vt, dt, ks, lr, lg), acc_o[dt]);
+          for (int r = 0; r < 4; ++r) acc_o[rt][dt][r] *= alpha[r];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Pw[(rt * 16 + lg * 4 + r) * LDP + nt * 16 + lr] = Elem<T>::from_f(acc_s[rt][nt][r]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ks = 0; ks < kTpTile / 32; ++ks) {
+        uint4 pf[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) pf[rt] = *reinterpret_cast<const uint4*>(Pw + (rt * 16 + lr) * LDP + ks * 32 + lg * 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const uint4 vf = tp_tfrag<D>(Vt, dt, ks, lr, lg);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc_o[rt][dt] = tp_mfma<T>(pf[rt], vf, acc_o[rt][dt]);
+        }
+      }
     }
     __syncthreads();  // Ks / Vt are rewritten at the top of the next iteration
   }
   S* ob = reinterpret_cast<S*>(o_) + b * os.b + h * os.h;
   const float* sv = sumv + ((int64_t)b * H + h) * D;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = q0 + w * 16 + lg * 4 + r;
-    if (qi < L) {
-      const float dn = l[r] + eps;
-      const float inv = 1.0f / dn;
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) ob[(int64_t)qi * os.l + dt * 16 + lr] = Elem<T>::from_f((acc_o[dt][r] + c_leak * sv[dt * 16 + lr]) * inv);
-      if (lr == 0) {
-        Mout[((int64_t)b * H + h) * L + qi] = m[r];
-        Dnout[((int64_t)b * H + h) * L + qi] = dn;
+    for (int r = 0; r < 4; ++r) {
+      const int qi = wrow0 + rt * 16 + lg * 4 + r;
+      if (qi < L) {
+        const float dn = l[rt][r] + eps;
+        const float inv = 1.0f / dn;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ob[(int64_t)qi * os.l + dt * 16 + lr] = Elem<T>::from_f((acc_o[rt][dt][r] + c_leak * sv[dt * 16 + lr]) * inv);
+        if (lr == 0) {
+          Mout[((int64_t)b * H + h) * L + qi] = m[rt][r];
+          Dnout[((int64_t)b * H + h) * L + qi] = dn;
+        }
       }
     }
-  }
 }
 
 // ---- backward, query side: dQ_i = scale * sum_j dS_ij k_j ----
@@ -611,10 +634,11 @@ __global__ __launch_bounds__(256) void tp_gumbel_bwd_kernel(const void* __restri
   store1<T>(dlogp_, 2 * i + 1, Elem<T>::round(d1 / tau));
 }
 
+constexpr int kTpFwdRT = 2;  // row tiles per wave in the forward (128 query rows per workgroup)
 template <typename T, int D>
 static size_t tp_smem_fwd() {
   using St = TpStage<D>;
-  return (size_t)(kTpTile * St::LDR + D * St::LDT + 4 * 16 * (kTpTile + kTpPad)) * 2;
+  return (size_t)(kTpTile * St::LDR + D * St::LDT + 4 * kTpFwdRT * 16 * (kTpTile + kTpPad)) * 2;
 }
 template <typename T, int D>
 static size_t tp_smem_dq() {
@@ -643,10 +667,11 @@ static int tp_fwd_go(const void* q, const void* k, const void* v, TpStrides qs, 
                      int64_t bias_sb, int64_t bias_sl, float* sumv, float* M, float* Dn, int B, int H, int L, float scale, float eps, float c_leak,
                      hipStream_t st) {
   hipLaunchKernelGGL((tp_colsum_kernel<T>), dim3((unsigned)H, (unsigned)B), dim3(256), 0, st, v, qs, (const float*)nullptr, sumv, H, L, D);
-  auto kfn = tp_fwd_kernel<T, D, CAUSAL>;
+  auto kfn = tp_fwd_kernel<T, D, CAUSAL, kTpFwdRT>;
   const size_t smem = tp_smem_fwd<T, D>();
   if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)((L + kTpTile - 1) / kTpTile), (unsigned)H, (unsigned)B), dim3(kTpThreads), smem, st, q, k, v, qs, o, os, policy,
+  constexpr int kRows = kTpTile * kTpFwdRT;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((L + kRows - 1) / kRows), (unsigned)H, (unsigned)B), dim3(kTpThreads), smem, st, q, k, v, qs, o, os, policy,
                      bias, bias_sb, bias_sl, (const float*)sumv, M, Dn, H, L, scale, eps, c_leak);
   return DL_OK;
 }
