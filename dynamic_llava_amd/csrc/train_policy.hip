@@ -634,7 +634,9 @@ __global__ __launch_bounds__(256) void tp_gumbel_bwd_kernel(const void* __restri
   store1<T>(dlogp_, 2 * i + 1, Elem<T>::round(d1 / tau));
 }
 
-constexpr int kTpFwdRT = 2;  // row tiles per wave in the forward (128 query rows per workgroup)
+constexpr int kTpFwdRT = 1;  // row tiles per wave in the forward.  2 (128 query rows per workgroup, every K / V fragment feeding two MFMAs) was
+                             // measured SLOWER: 473 vs 347 us at L=2048 -- 349 registers leave one wave per SIMD, and latency hiding
+                             // matters more here than the LDS fragment traffic
 template <typename T, int D>
 static size_t tp_smem_fwd() {
   using St = TpStage<D>;
