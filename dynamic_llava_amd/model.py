@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -440,6 +441,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.use_persistent_decode = False
         self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         self.smallm_max_decode_batch = 16  # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM
+        if os.environ.get("DL_SMALLM_MAX_B"):  # tuning experiments only
+            self.smallm_max_decode_batch = int(os.environ["DL_SMALLM_MAX_B"])
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
         self.eval()
 

@@ -22,9 +22,9 @@ def run(B, n_new):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 
-for B in (1, 2, 3, 4, 8, 16, 20, 32):
-    for maxb in (0, 16):  # 0: dl_gemm_smallm off (library GEMM past the dl_gemv range)
-        if (B <= 3 or B > 16) and maxb == 0:
+for B in (1, 2, 3, 4, 8, 16, 20, 24, 32):
+    for maxb in (0, 32):  # 0: dl_gemm_smallm off (library GEMM past the dl_gemv range)
+        if B <= 3 and maxb == 0:
             continue
         model.smallm_max_decode_batch = maxb
         model._dstate = None
