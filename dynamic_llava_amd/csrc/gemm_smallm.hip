@@ -116,16 +116,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_kernel(const void* __rest
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int m = nb * 16 + lr;
-        if (m < M) {
+        const sm_f32x4_t v = acc[nb][0] + acc[nb][1];
+        if (m < M && n < N) {  // N % 4 == 0: a lane's 4 neurons are all inside or all outside
+          if (direct) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = acc[nb][0][e] + acc[nb][1][e];
-            if (n + e < N) {
-              if (direct)
-                store1<T>(Y_, (int64_t)m * ldy + n + e, v);
-              else
-                part[((int64_t)slice * M + m) * N + n + e] = v;
-            }
+            for (int e = 0; e < 4; ++e) store1<T>(Y_, (int64_t)m * ldy + n + e, v[e]);
+          } else {  // one 16-byte store per lane: 16 rows x 64 contiguous bytes per instruction (was four 4-byte stores behind branches)
+            *reinterpret_cast<float4*>(part + ((int64_t)slice * M + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
         acc[nb][0] = acc[nb][1] = sm_f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -229,16 +226,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_smallm_staged_kernel(const void*
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int m = nb * 16 + lr;
-        if (m < M) {
+        const sm_f32x4_t v = acc[nb][0] + acc[nb][1];
+        if (m < M && n < N) {  // N % 4 == 0: a lane's 4 neurons are all inside or all outside
+          if (direct) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = acc[nb][0][e] + acc[nb][1][e];
-            if (n + e < N) {
-              if (direct)
-                store1<T>(Y_, (int64_t)m * ldy + n + e, v);
-              else
-                part[((int64_t)slice * M + m) * N + n + e] = v;
-            }
+            for (int e = 0; e < 4; ++e) store1<T>(Y_, (int64_t)m * ldy + n + e, v[e]);
+          } else {  // one 16-byte store per lane: 16 rows x 64 contiguous bytes per instruction (was four 4-byte stores behind branches)
+            *reinterpret_cast<float4*>(part + ((int64_t)slice * M + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
         acc[nb][0] = acc[nb][1] = sm_f32x4_t{0.f, 0.f, 0.f, 0.f};
