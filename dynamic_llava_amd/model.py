@@ -440,7 +440,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # MI355X (3.56 vs 2.65 ms/token at 7B: DESIGN.md section 4b), so it is opt-in
         self.use_persistent_decode = False
         self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
-        self.smallm_max_decode_batch = 16  # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM
+        # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM.  tools/bench_decode_batch.py: 3.87 / 3.95 /
+        # 4.24 ms per step at B = 4 / 8 / 16 against 5.1-5.3 on the library; a wash at 20-24 (4.64 / 4.80 vs 4.66 / 4.75) where the hand-written
+        # path is kept for being deterministic and batch-invariant; 4 % behind at 32 (5.09 vs 4.89)
+        self.smallm_max_decode_batch = 24
         if os.environ.get("DL_SMALLM_MAX_B"):  # tuning experiments only
             self.smallm_max_decode_batch = int(os.environ["DL_SMALLM_MAX_B"])
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)

@@ -162,9 +162,9 @@ def test_c5_13b_width_long_decode_with_eviction():
                 break  # a boundary decision may flip between summation orders: the caches diverge from here on
 
 
-@pytest.mark.parametrize("B", [4, 7, 16])
+@pytest.mark.parametrize("B", [4, 7, 16, 20, 24])
 def test_mid_batch_decode_smallm_rows_equal_b1(B):
-    """Decode batches 4..16 run on dl_gemm_smallm (+ partial-sum consumers).  Every row of a ragged batch must match its own B=1 run
+    """Decode batches 4..24 run on dl_gemm_smallm (+ partial-sum consumers).  Every row of a ragged batch must match its own B=1 run
     (dl_gemv path): greedy tokens and per-step eviction decisions away from decision boundaries, logits in the same noise class."""
     dtype = torch.bfloat16
     cfg = fx.llava7b_config(num_hidden_layers=3)
