@@ -25,7 +25,7 @@ __device__ __forceinline__ f32x4_t mfma16_lin<f16_t>(const uint4& a, const uint4
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-constexpr int kTM = 64, kTN = 64, kTK = 64, kLd = kTK + 8;
+constexpr int kTM = 64, kTN = 64;
 
 template <typename T>
 __device__ __forceinline__ float epilogue(float acc, float bias, const void* R, int64_t ridx, int flags) {
@@ -35,11 +35,13 @@ __device__ __forceinline__ float epilogue(float acc, float bias, const void* R, 
   return v;
 }
 
-template <typename T>
+// TK: K slab per step (64; 128 for K >= 1024 -- half the barriers of the long serial K loops of in_conv / the FF down projection)
+template <typename T, int kTK>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const void* __restrict__ A_, int64_t lda, const void* __restrict__ W_,
                                                            const void* __restrict__ bias_, void* C_, int64_t ldc, const void* R_,
                                                            int64_t ldr, int M, int N, int K, int flags) {
   using S = uint16_t;
+  constexpr int kLd = kTK + 8, CPR = kTK / 8, IT = (kTM * CPR) / 256;
   __shared__ __attribute__((aligned(16))) S As[kTM * kLd];
   __shared__ __attribute__((aligned(16))) S Ws[kTN * kLd];
   const S* A = reinterpret_cast<const S*>(A_);
@@ -54,20 +56,34 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const void* __restrict
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // software-pipelined over K: the next 64-wide slab of A and W is in flight in registers while the MFMAs of the current one run
+  // (the launches here are small -- 36 to 288 workgroups, up to 64 K steps -- so an exposed global round trip per step was most of
+  // their time: in_conv [576,4096]x[512,4096] 100 -> see DESIGN)
+  uint4 a4[IT], w4[IT];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {  // 64 rows x CPR chunks per operand
+      const int idx = it * 256 + tid;
+      const int r = idx / CPR, ch = (idx % CPR) * 8;
+      a4[it] = make_uint4(0, 0, 0, 0);
+      w4[it] = make_uint4(0, 0, 0, 0);
+      if (k0 + ch < K) {
+        if (m0 + r < M) a4[it] = *reinterpret_cast<const uint4*>(A + (int64_t)(m0 + r) * lda + k0 + ch);
+        if (n0 + r < N) w4[it] = *reinterpret_cast<const uint4*>(W + (int64_t)(n0 + r) * K + k0 + ch);
+      }
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += kTK) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {  // 64 rows x 8 chunks = 512 chunks per operand
+    for (int it = 0; it < IT; ++it) {
       const int idx = it * 256 + tid;
-      const int r = idx >> 3, ch = (idx & 7) * 8;
-      uint4 a4 = make_uint4(0, 0, 0, 0), w4 = make_uint4(0, 0, 0, 0);
-      if (k0 + ch < K) {
-        if (m0 + r < M) a4 = *reinterpret_cast<const uint4*>(A + (int64_t)(m0 + r) * lda + k0 + ch);
-        if (n0 + r < N) w4 = *reinterpret_cast<const uint4*>(W + (int64_t)(n0 + r) * K + k0 + ch);
-      }
-      *reinterpret_cast<uint4*>(As + r * kLd + ch) = a4;
-      *reinterpret_cast<uint4*>(Ws + r * kLd + ch) = w4;
+      const int r = idx / CPR, ch = (idx % CPR) * 8;
+      *reinterpret_cast<uint4*>(As + r * kLd + ch) = a4[it];
+      *reinterpret_cast<uint4*>(Ws + r * kLd + ch) = w4[it];
     }
     __syncthreads();
+    if (k0 + kTK < K) fetch(k0 + kTK);
 #pragma unroll
     for (int ks = 0; ks < kTK / 32; ++ks) {
       uint4 af[2], bf[2];
@@ -152,9 +168,11 @@ int linear_launch(const void* A, int64_t lda, const void* W, const void* bias, v
   if (dtype == DL_F32) {
     hipLaunchKernelGGL((linear_simple_kernel<f32_t>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
   } else if (dtype == DL_BF16) {
-    hipLaunchKernelGGL((linear_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
+    if (K >= 1024) hipLaunchKernelGGL((linear_mfma_kernel<bf16_t, 128>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
+    else hipLaunchKernelGGL((linear_mfma_kernel<bf16_t, 64>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
   } else if (dtype == DL_F16) {
-    hipLaunchKernelGGL((linear_mfma_kernel<f16_t>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
+    if (K >= 1024) hipLaunchKernelGGL((linear_mfma_kernel<f16_t, 128>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
+    else hipLaunchKernelGGL((linear_mfma_kernel<f16_t, 64>), grid, dim3(256), 0, st, A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags);
   } else {
     return DL_ERR_ARG;
   }
