@@ -1124,6 +1124,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._rope_tables(max(cache.full_len_host) + 2)
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
+            st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
             self._decode_step_kernels(st, cache, False)
             sc_ = self.config.sparse_config
             use_tp = bool(sc_["use_text_predictor"] and sc_["use_output_text_predictor"]) and sc_["sparse_layer"] < self.config.num_hidden_layers
@@ -1381,6 +1382,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)
         st.step.zero_(); st.finished.zero_(); st.decision.fill_(1)
+        # the in-kernel split merge of the decode attention validates its granules by tag = (position of the new token, layer): within one
+        # request positions only grow, so a slot left by an earlier step never matches -- but a slot left by an EARLIER REQUEST at the same
+        # position would.  Tag 0 is never expected: one clear per request makes every older granule unmatchable.
+        st.attn_ws.zero_()
         self._eos = -1 if eos is None else eos
         self._pad = pad
         self._min_new = min_new

@@ -106,7 +106,10 @@ int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, cons
  * call_tag >= 0 (with keys_in_flight = 64, chunk_keys = 0, n_splits > 1 and a grid of <= 1024 workgroups): the splits are merged
  * INSIDE this launch by the workgroup of split 0 (partials travel through `workspace` as self-validating 8-byte granules; same
  * merge order and bits as the two-launch form).  call_tag must differ between consecutive calls that share `workspace` at the same
- * pos_base (the layer index does); -1: always the separate merge launch. */
+ * pos_base (the layer index does); -1: always the separate merge launch.  A granule is accepted when its tag equals
+ * f(pos_base[b], call_tag): within one sequence positions only grow, so granules of earlier steps never match, but granules left by
+ * ANOTHER sequence that visited the same position with the same call_tag would -- the caller must clear `workspace` (all-zero bytes: tag
+ * 0 is never expected) whenever the sequence a row belongs to changes (model.py: once per generate(), every eager decode forward()). */
 int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
                         const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab,
                         int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride,

@@ -712,3 +712,41 @@ def test_device_prompt_layout_kernel_and_generate_fast_path():
     model.device_prompt_layout = False
     b_ = model.generate(q.cuda(), images=images.cuda(), max_new_tokens=4, eos_token_id=None)
     assert torch.equal(a, b_)
+
+
+def test_decode_attention_merge_granules_of_an_earlier_request_cannot_be_consumed():
+    """The in-kernel split merge of dl_attn_decode_rope accepts a granule whose tag equals f(position, layer).  A request that reaches a
+    position an EARLIER request left granules at must not consume them: generate() and the eager decode forward() clear the workspace.
+    The workspace is poisoned with correctly-tagged garbage for the first decode position of layers 0 and 1 (full-length rows, two
+    splits) before each run; results must equal the unpoisoned run."""
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=5, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=6)
+    model = _build(cfg, sd, clip, torch.float32)
+    assert model.attn_inkernel_combine
+    ids = fx.make_prompt(cfg, 6, 40, seed=3)[None].cuda()
+    images = fx.make_images(cfg, 1, seed=3).cuda()
+    n_full = ids.shape[1] - 1 + fx.n_image_tokens(cfg)
+    assert n_full > 64, "layers 0-1 must run with two KV splits for the merge to happen at all"
+    clean = model.generate(ids, images=images, max_new_tokens=6, eos_token_id=None).cpu()
+    clean_logits = model.last_prefill_logits.float().cpu().clone()
+
+    def poison(layer):
+        st = model._dstate
+        tag = (((n_full & 0x7FFFFF) << 8) | layer) + 1  # the tag the first decode step of this prompt expects at `layer`
+        g = (tag << 32) | int(np.float32(1e4).view(np.uint32))
+        st.attn_ws.view(torch.int64).fill_(g if g < 2**63 else g - 2**64)
+
+    for layer in (0, 1):
+        poison(layer)
+        out = model.generate(ids, images=images, max_new_tokens=6, eos_token_id=None).cpu()
+        assert torch.equal(out, clean), f"generate() consumed stale merge granules at layer {layer}"
+        assert torch.equal(model.last_prefill_logits.float().cpu(), clean_logits)
+    # eager forward() decode on a fresh cache, poisoned right before the decode call
+    o = model(ids, images=images)
+    ref = model(clean[:, :1].cuda(), past_key_values=o.past_key_values).logits.cpu()
+    for layer in (0, 1):
+        o = model(ids, images=images)
+        poison(layer)
+        got = model(clean[:, :1].cuda(), past_key_values=o.past_key_values).logits.cpu()
+        assert torch.equal(got, ref), f"forward() consumed stale merge granules at layer {layer}"
