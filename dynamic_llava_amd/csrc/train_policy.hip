@@ -19,6 +19,8 @@
 // Kernels: MFMA 16x16x32 flash-style tiles, 64 query rows x 64 keys, 4 waves.  The backward is two deterministic passes (no atomics):
 // one workgroup per KEY tile accumulates dK / dV / dpolicy over the query tiles, one per QUERY tile accumulates dQ over the key tiles.
 // Transposed operands (V^T, K^T, Q^T, dO^T) are built in LDS from coalesced row loads with 8-byte writes into an XOR-swizzled image.
+#include <type_traits>
+
 #include "dl_common.h"
 
 namespace dl {
@@ -45,43 +47,44 @@ struct TpStrides {
 };
 
 // ---- tile staging: 64 rows x D of a [.., L, D] operand -> LDS, row-major and / or transposed ----
-template <int D>
+template <int D, int NTHR = kTpThreads>
 struct TpStage {
   static constexpr int CPR = D / 8;                                   // 16-byte chunks per row
-  static constexpr int RIT = (kTpTile * CPR) / kTpThreads;            // row-major chunks per thread
+  static constexpr int RIT = (kTpTile * CPR) / NTHR;                  // row-major chunks per thread
   static constexpr int TITEMS = (kTpTile / 4) * CPR;                  // transposed items (4 rows x one chunk)
-  static constexpr int TIT = (TITEMS + kTpThreads - 1) / kTpThreads;  // per thread
+  static constexpr int TIT = (TITEMS + NTHR - 1) / NTHR;              // per thread
+  static_assert((kTpTile * CPR) % NTHR == 0, "row staging must divide evenly");
   static constexpr int SW = D == 64 ? 2 : 1;                          // swizzle step (a half-wave spans 128 / D row pairs)
   static constexpr int LDR = D + kTpPad, LDT = kTpTile + kTpPad;
 };
 
 // rows [row0, row0+64) of x (row stride sl), zeros beyond n_rows
-template <int D>
-__device__ __forceinline__ void tp_fetch_rows(const uint16_t* __restrict__ x, int64_t sl, int row0, int n_rows, int tid, uint4 (&r)[TpStage<D>::RIT]) {
-  using St = TpStage<D>;
+template <int D, int NTHR = kTpThreads>
+__device__ __forceinline__ void tp_fetch_rows(const uint16_t* __restrict__ x, int64_t sl, int row0, int n_rows, int tid, uint4 (&r)[TpStage<D, NTHR>::RIT]) {
+  using St = TpStage<D, NTHR>;
 #pragma unroll
   for (int it = 0; it < St::RIT; ++it) {
-    const int idx = it * kTpThreads + tid;
+    const int idx = it * NTHR + tid;
     const int row = row0 + idx / St::CPR, ch = idx % St::CPR;
     r[it] = make_uint4(0, 0, 0, 0);
     if (row < n_rows) r[it] = *reinterpret_cast<const uint4*>(x + (int64_t)row * sl + ch * 8);
   }
 }
-template <int D>
-__device__ __forceinline__ void tp_stash_rows(uint16_t* __restrict__ Xs, int tid, const uint4 (&r)[TpStage<D>::RIT]) {
-  using St = TpStage<D>;
+template <int D, int NTHR = kTpThreads>
+__device__ __forceinline__ void tp_stash_rows(uint16_t* __restrict__ Xs, int tid, const uint4 (&r)[TpStage<D, NTHR>::RIT]) {
+  using St = TpStage<D, NTHR>;
 #pragma unroll
   for (int it = 0; it < St::RIT; ++it) {
-    const int idx = it * kTpThreads + tid;
+    const int idx = it * NTHR + tid;
     *reinterpret_cast<uint4*>(Xs + (idx / St::CPR) * St::LDR + (idx % St::CPR) * 8) = r[it];
   }
 }
-template <int D>
-__device__ __forceinline__ void tp_fetch_t(const uint16_t* __restrict__ x, int64_t sl, int row0, int n_rows, int tid, uint4 (&r)[TpStage<D>::TIT][4]) {
-  using St = TpStage<D>;
+template <int D, int NTHR = kTpThreads>
+__device__ __forceinline__ void tp_fetch_t(const uint16_t* __restrict__ x, int64_t sl, int row0, int n_rows, int tid, uint4 (&r)[TpStage<D, NTHR>::TIT][4]) {
+  using St = TpStage<D, NTHR>;
 #pragma unroll
   for (int it = 0; it < St::TIT; ++it) {
-    const int item = it * kTpThreads + tid;  // chunk fastest: the lanes of a row group read one whole row (coalesced)
+    const int item = it * NTHR + tid;  // chunk fastest: the lanes of a row group read one whole row (coalesced)
     const int rg = item / St::CPR, ch = item % St::CPR;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -93,12 +96,12 @@ __device__ __forceinline__ void tp_fetch_t(const uint16_t* __restrict__ x, int64
 }
 // X^T[dim][row]: the 16-byte row pairs (8 rows) of a dim are XOR-swizzled by dim / 16 so that the 8-byte transposing writes of a
 // half-wave (dims 8 apart: only two bank offsets) spread over all banks; tp_tfrag() un-swizzles on the read side.
-template <int D>
-__device__ __forceinline__ void tp_stash_t(uint16_t* __restrict__ Xt, int tid, const uint4 (&r)[TpStage<D>::TIT][4]) {
-  using St = TpStage<D>;
+template <int D, int NTHR = kTpThreads>
+__device__ __forceinline__ void tp_stash_t(uint16_t* __restrict__ Xt, int tid, const uint4 (&r)[TpStage<D, NTHR>::TIT][4]) {
+  using St = TpStage<D, NTHR>;
 #pragma unroll
   for (int it = 0; it < St::TIT; ++it) {
-    const int item = it * kTpThreads + tid;
+    const int item = it * NTHR + tid;
     if (item < St::TITEMS) {
       const int rg = item / St::CPR, ch = item % St::CPR;
       const int pair = rg >> 1;
@@ -172,20 +175,22 @@ __global__ __launch_bounds__(256) void tp_delta_kernel(const void* __restrict__ 
 // ---- forward ----
 // RT row tiles of 16 per wave (a workgroup = 64 * RT query rows): every K / V^T fragment read from LDS feeds RT MFMAs.  With one row
 // tile per wave the kernel is LDS-bound (34 KB of fragment reads per 32 MFMAs and wave; 8 waves per CU share 128 B/clk).
-template <typename T, int D, bool CAUSAL, int RT>
-__global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
+// NWF waves per workgroup share one staged K / V^T tile.
+template <typename T, int D, bool CAUSAL, int RT, int NWF>
+__global__ __launch_bounds__(NWF * 64) void tp_fwd_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
                                                             TpStrides qs, void* __restrict__ o_, TpStrides os, const float* __restrict__ policy,
                                                             const void* __restrict__ bias_, int64_t bias_sb, int64_t bias_sl,
                                                             const float* __restrict__ sumv, float* __restrict__ Mout, float* __restrict__ Dnout, int H, int L,
                                                             float scale, float eps, float c_leak) {
   using S = uint16_t;
-  using St = TpStage<D>;
+  constexpr int NTHR = NWF * 64;
+  using St = TpStage<D, NTHR>;
   constexpr int KS = D / 32, DT = D / 16, NT = kTpTile / 16, LDP = kTpTile + kTpPad;
-  constexpr int kRows = kTpTile * RT;  // query rows per workgroup
+  constexpr int kRows = NWF * 16 * RT;  // query rows per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S* Ks = reinterpret_cast<S*>(smem);        // [64][LDR]
   S* Vt = Ks + kTpTile * St::LDR;            // [D][LDT] swizzled
-  S* Ps = Vt + D * St::LDT;                  // [4][RT][16][LDP]
+  S* Ps = Vt + D * St::LDT;                  // [NWF][RT][16][LDP]
   const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;  // causal: longest rows first
   const int q0 = qt * kRows;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lg = lane >> 4;
@@ -221,16 +226,16 @@ __global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restri
   S* Pw = Ps + w * RT * 16 * LDP;
   const int n_tiles = CAUSAL ? min((L + kTpTile - 1) / kTpTile, (q0 + kRows - 1) / kTpTile + 1) : (L + kTpTile - 1) / kTpTile;
   uint4 kreg[St::RIT], vreg[St::TIT][4];
-  tp_fetch_rows<D>(kb, qs.l, 0, L, tid, kreg);
-  tp_fetch_t<D>(vb, qs.l, 0, L, tid, vreg);
+  tp_fetch_rows<D, NTHR>(kb, qs.l, 0, L, tid, kreg);
+  tp_fetch_t<D, NTHR>(vb, qs.l, 0, L, tid, vreg);
   for (int jt = 0; jt < n_tiles; ++jt) {
     const int key0 = jt * kTpTile;
-    tp_stash_rows<D>(Ks, tid, kreg);
-    tp_stash_t<D>(Vt, tid, vreg);
+    tp_stash_rows<D, NTHR>(Ks, tid, kreg);
+    tp_stash_t<D, NTHR>(Vt, tid, vreg);
     __syncthreads();
     if (jt + 1 < n_tiles) {  // next tile in flight during the MFMAs
-      tp_fetch_rows<D>(kb, qs.l, key0 + kTpTile, L, tid, kreg);
-      tp_fetch_t<D>(vb, qs.l, key0 + kTpTile, L, tid, vreg);
+      tp_fetch_rows<D, NTHR>(kb, qs.l, key0 + kTpTile, L, tid, kreg);
+      tp_fetch_t<D, NTHR>(vb, qs.l, key0 + kTpTile, L, tid, vreg);
     }
     if (!CAUSAL || key0 <= wrow0 + 16 * RT - 1) {  // wave-uniform: tiles wholly in this wave's future are skipped
       float pk[NT];
@@ -330,22 +335,24 @@ __global__ __launch_bounds__(kTpThreads) void tp_fwd_kernel(const void* __restri
 }
 
 // ---- backward, query side: dQ_i = scale * sum_j dS_ij k_j ----
-template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kTpThreads) void tp_bwd_dq_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
+// NWQ waves of 16 query rows each share the staged K / V / K^T tile (8 waves: two per SIMD, as in the key-side kernel).
+template <typename T, int D, bool CAUSAL, int NWQ>
+__global__ __launch_bounds__(NWQ * 64) void tp_bwd_dq_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
                                                                TpStrides qs, const void* __restrict__ do_, void* __restrict__ dq_, TpStrides os,
                                                                const float* __restrict__ policy, const void* __restrict__ bias_, int64_t bias_sb,
                                                                int64_t bias_sl, const float* __restrict__ Mx, const float* __restrict__ Dn,
                                                                const float* __restrict__ delta, int H, int L, float scale) {
   using S = uint16_t;
-  using St = TpStage<D>;
+  constexpr int NTHR = NWQ * 64, kRows = NWQ * 16;
+  using St = TpStage<D, NTHR>;
   constexpr int KS = D / 32, DT = D / 16, NT = kTpTile / 16, LDP = kTpTile + kTpPad;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S* Ks = reinterpret_cast<S*>(smem);        // [64][LDR]
   S* Vs = Ks + kTpTile * St::LDR;            // [64][LDR]
   S* Kt = Vs + kTpTile * St::LDR;            // [D][LDT] swizzled
-  S* Ps = Kt + D * St::LDT;                  // [4][16][LDP]
+  S* Ps = Kt + D * St::LDT;                  // [NWQ][16][LDP]
   const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;  // causal: longest rows first
-  const int q0 = qt * kTpTile;
+  const int q0 = qt * kRows;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const S* qb = reinterpret_cast<const S*>(q_) + b * qs.b + h * qs.h;
   const S* kb = reinterpret_cast<const S*>(k_) + b * qs.b + h * qs.h;
@@ -379,22 +386,23 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dq_kernel(const void* __res
 #pragma unroll
   for (int i = 0; i < DT; ++i) acc_q[i] = tp_f32x4_t{0.f, 0.f, 0.f, 0.f};
   S* Pw = Ps + w * 16 * LDP;
-  const int n_tiles = CAUSAL ? min((L + kTpTile - 1) / kTpTile, qt + 1) : (L + kTpTile - 1) / kTpTile;
+  const int n_tiles = CAUSAL ? min((L + kTpTile - 1) / kTpTile, (q0 + kRows - 1) / kTpTile + 1) : (L + kTpTile - 1) / kTpTile;
   uint4 kreg[St::RIT], vreg[St::RIT], ktreg[St::TIT][4];
-  tp_fetch_rows<D>(kb, qs.l, 0, L, tid, kreg);
-  tp_fetch_rows<D>(vb, qs.l, 0, L, tid, vreg);
-  tp_fetch_t<D>(kb, qs.l, 0, L, tid, ktreg);
+  tp_fetch_rows<D, NTHR>(kb, qs.l, 0, L, tid, kreg);
+  tp_fetch_rows<D, NTHR>(vb, qs.l, 0, L, tid, vreg);
+  tp_fetch_t<D, NTHR>(kb, qs.l, 0, L, tid, ktreg);
   for (int jt = 0; jt < n_tiles; ++jt) {
     const int key0 = jt * kTpTile;
-    tp_stash_rows<D>(Ks, tid, kreg);
-    tp_stash_rows<D>(Vs, tid, vreg);
-    tp_stash_t<D>(Kt, tid, ktreg);
+    tp_stash_rows<D, NTHR>(Ks, tid, kreg);
+    tp_stash_rows<D, NTHR>(Vs, tid, vreg);
+    tp_stash_t<D, NTHR>(Kt, tid, ktreg);
     __syncthreads();
     if (jt + 1 < n_tiles) {
-      tp_fetch_rows<D>(kb, qs.l, key0 + kTpTile, L, tid, kreg);
-      tp_fetch_rows<D>(vb, qs.l, key0 + kTpTile, L, tid, vreg);
-      tp_fetch_t<D>(kb, qs.l, key0 + kTpTile, L, tid, ktreg);
+      tp_fetch_rows<D, NTHR>(kb, qs.l, key0 + kTpTile, L, tid, kreg);
+      tp_fetch_rows<D, NTHR>(vb, qs.l, key0 + kTpTile, L, tid, vreg);
+      tp_fetch_t<D, NTHR>(kb, qs.l, key0 + kTpTile, L, tid, ktreg);
     }
+    if (!CAUSAL || key0 <= q0 + w * 16 + 15) {  // wave-uniform: tiles wholly in this wave's future are skipped
     float pk[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -436,6 +444,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dq_kernel(const void* __res
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) acc_q[dt] = tp_mfma<T>(pf, tp_tfrag<D>(Kt, dt, ks, lr, lg), acc_q[dt]);
     }
+    }
     __syncthreads();
   }
   S* dqb = reinterpret_cast<S*>(dq_) + b * os.b + h * os.h;
@@ -450,25 +459,28 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dq_kernel(const void* __res
 }
 
 // ---- backward, key side: dK_j, dV_j, dpolicy_j (per head) ----
-template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kTpThreads) void tp_bwd_dkv_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
+// NWK waves of 16 keys each per workgroup share one staged query tile (Q, dO, Q^T, dO^T: ~73 KB of LDS whatever NWK is): 8 waves put two
+// waves on every SIMD where 4 left one (LDS allows a single workgroup per CU).
+template <typename T, int D, bool CAUSAL, int NWK>
+__global__ __launch_bounds__(NWK * 64) void tp_bwd_dkv_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_,
                                                                 TpStrides qs, const void* __restrict__ do_, void* __restrict__ dk_, void* __restrict__ dv_,
                                                                 TpStrides os, const float* __restrict__ policy, const void* __restrict__ bias_,
                                                                 int64_t bias_sb, int64_t bias_sl, const float* __restrict__ Mx, const float* __restrict__ Dn,
                                                                 const float* __restrict__ delta, const float* __restrict__ gsum,
                                                                 float* __restrict__ dpol_heads, int H, int L, float scale, float c_leak) {
   using S = uint16_t;
-  using St = TpStage<D>;
+  constexpr int NTHR = NWK * 64, kKeys = NWK * 16;
+  using St = TpStage<D, NTHR>;
   constexpr int KS = D / 32, DT = D / 16, NT = kTpTile / 16, LDP = kTpTile + kTpPad;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S* Qs = reinterpret_cast<S*>(smem);        // [64][LDR]
   S* Os = Qs + kTpTile * St::LDR;            // dO [64][LDR]
   S* Qt = Os + kTpTile * St::LDR;            // [D][LDT] swizzled
   S* Ot = Qt + D * St::LDT;                  // dO^T
-  S* Ps = Ot + D * St::LDT;                  // [4][2][16][LDP]: A^T and dS^T of each wave
-  float* stat = reinterpret_cast<float*>(Ps + 4 * 2 * 16 * LDP);  // [3][64]: m, 1/Dn, delta of the query tile
+  S* Ps = Ot + D * St::LDT;                  // [NWK][2][16][LDP]: A^T and dS^T of each wave
+  float* stat = reinterpret_cast<float*>(Ps + NWK * 2 * 16 * LDP);  // [3][64]: m, 1/Dn, delta of the query tile
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int key0 = kt * kTpTile;
+  const int key0 = kt * kKeys;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const S* qb = reinterpret_cast<const S*>(q_) + b * qs.b + h * qs.h;
   const S* kb = reinterpret_cast<const S*>(k_) + b * qs.b + h * qs.h;
@@ -503,14 +515,14 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dkv_kernel(const void* __re
   S* Aw = Ps + w * 2 * 16 * LDP;
   S* Dw = Aw + 16 * LDP;
   const int n_qt = (L + kTpTile - 1) / kTpTile;
-  const int qt0 = CAUSAL ? kt : 0;
+  const int qt0 = CAUSAL ? key0 / kTpTile : 0;  // first query tile that can see this workgroup's first key
   uint4 qreg[St::RIT], oreg[St::RIT], qtreg[St::TIT][4], otreg[St::TIT][4];
   float sreg[3] = {0.f, 0.f, 0.f};
   auto fetch = [&](int q0) {
-    tp_fetch_rows<D>(qb, qs.l, q0, L, tid, qreg);
-    tp_fetch_rows<D>(dob, os.l, q0, L, tid, oreg);
-    tp_fetch_t<D>(qb, qs.l, q0, L, tid, qtreg);
-    tp_fetch_t<D>(dob, os.l, q0, L, tid, otreg);
+    tp_fetch_rows<D, NTHR>(qb, qs.l, q0, L, tid, qreg);
+    tp_fetch_rows<D, NTHR>(dob, os.l, q0, L, tid, oreg);
+    tp_fetch_t<D, NTHR>(qb, qs.l, q0, L, tid, qtreg);
+    tp_fetch_t<D, NTHR>(dob, os.l, q0, L, tid, otreg);
     if (tid < 192) {
       const int which = tid >> 6, qi = q0 + (tid & 63);
       float x = 0.f;
@@ -521,13 +533,14 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dkv_kernel(const void* __re
   fetch(qt0 * kTpTile);
   for (int qt = qt0; qt < n_qt; ++qt) {
     const int q0 = qt * kTpTile;
-    tp_stash_rows<D>(Qs, tid, qreg);
-    tp_stash_rows<D>(Os, tid, oreg);
-    tp_stash_t<D>(Qt, tid, qtreg);
-    tp_stash_t<D>(Ot, tid, otreg);
+    tp_stash_rows<D, NTHR>(Qs, tid, qreg);
+    tp_stash_rows<D, NTHR>(Os, tid, oreg);
+    tp_stash_t<D, NTHR>(Qt, tid, qtreg);
+    tp_stash_t<D, NTHR>(Ot, tid, otreg);
     if (tid < 192) stat[tid] = sreg[0];
     __syncthreads();
     if (qt + 1 < n_qt) fetch(q0 + kTpTile);
+    if (!CAUSAL || key0 + w * 16 <= q0 + kTpTile - 1) {  // wave-uniform: a tile wholly before this wave's keys contributes nothing
     // S^T = K Q^T and dA^T = V dO^T: rows = this wave's keys, columns = the tile's query rows
     tp_f32x4_t acc_s[NT], acc_a[NT];
 #pragma unroll
@@ -570,6 +583,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_bwd_dkv_kernel(const void* __re
         acc_v[dt] = tp_mfma<T>(af, tp_tfrag<D>(Ot, dt, ks, lr, lg), acc_v[dt]);
         acc_k[dt] = tp_mfma<T>(df, tp_tfrag<D>(Qt, dt, ks, lr, lg), acc_k[dt]);
       }
+    }
     }
     __syncthreads();
   }
@@ -637,20 +651,20 @@ __global__ __launch_bounds__(256) void tp_gumbel_bwd_kernel(const void* __restri
 constexpr int kTpFwdRT = 1;  // row tiles per wave in the forward.  2 (128 query rows per workgroup, every K / V fragment feeding two MFMAs) was
                              // measured SLOWER: 473 vs 347 us at L=2048 -- 349 registers leave one wave per SIMD, and latency hiding
                              // matters more here than the LDS fragment traffic
-template <typename T, int D>
+template <typename T, int D, int NW>
 static size_t tp_smem_fwd() {
   using St = TpStage<D>;
-  return (size_t)(kTpTile * St::LDR + D * St::LDT + 4 * kTpFwdRT * 16 * (kTpTile + kTpPad)) * 2;
+  return (size_t)(kTpTile * St::LDR + D * St::LDT + NW * kTpFwdRT * 16 * (kTpTile + kTpPad)) * 2;
 }
-template <typename T, int D>
+template <typename T, int D, int NW>
 static size_t tp_smem_dq() {
   using St = TpStage<D>;
-  return (size_t)(2 * kTpTile * St::LDR + D * St::LDT + 4 * 16 * (kTpTile + kTpPad)) * 2;
+  return (size_t)(2 * kTpTile * St::LDR + D * St::LDT + NW * 16 * (kTpTile + kTpPad)) * 2;
 }
-template <typename T, int D>
+template <typename T, int D, int NW>
 static size_t tp_smem_dkv() {
   using St = TpStage<D>;
-  return (size_t)(2 * kTpTile * St::LDR + 2 * D * St::LDT + 8 * 16 * (kTpTile + kTpPad)) * 2 + 3 * 64 * sizeof(float);
+  return (size_t)(2 * kTpTile * St::LDR + 2 * D * St::LDT + NW * 2 * 16 * (kTpTile + kTpPad)) * 2 + 3 * 64 * sizeof(float);
 }
 
 template <typename K>
@@ -669,13 +683,18 @@ static int tp_fwd_go(const void* q, const void* k, const void* v, TpStrides qs, 
                      int64_t bias_sb, int64_t bias_sl, float* sumv, float* M, float* Dn, int B, int H, int L, float scale, float eps, float c_leak,
                      hipStream_t st) {
   hipLaunchKernelGGL((tp_colsum_kernel<T>), dim3((unsigned)H, (unsigned)B), dim3(256), 0, st, v, qs, (const float*)nullptr, sumv, H, L, D);
-  auto kfn = tp_fwd_kernel<T, D, CAUSAL, kTpFwdRT>;
-  const size_t smem = tp_smem_fwd<T, D>();
-  if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
-  constexpr int kRows = kTpTile * kTpFwdRT;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)((L + kRows - 1) / kRows), (unsigned)H, (unsigned)B), dim3(kTpThreads), smem, st, q, k, v, qs, o, os, policy,
-                     bias, bias_sb, bias_sl, (const float*)sumv, M, Dn, H, L, scale, eps, c_leak);
-  return DL_OK;
+  auto go = [&](auto nw_tag) -> int {
+    constexpr int NW = decltype(nw_tag)::value;
+    auto kfn = tp_fwd_kernel<T, D, CAUSAL, kTpFwdRT, NW>;
+    const size_t smem = tp_smem_fwd<T, D, NW>();
+    if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
+    constexpr int kRows = NW * 16 * kTpFwdRT;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((L + kRows - 1) / kRows), (unsigned)H, (unsigned)B), dim3(NW * 64), smem, st, q, k, v, qs, o, os, policy,
+                       bias, bias_sb, bias_sl, (const float*)sumv, M, Dn, H, L, scale, eps, c_leak);
+    return DL_OK;
+  };
+  // 8 waves sharing a K / V^T tile measured the same as 4 (358 vs 361 us at L=2048): the forward already runs two workgroups per CU
+  return go(std::integral_constant<int, 4>{});
 }
 
 template <typename T, int D, bool CAUSAL>
@@ -684,21 +703,30 @@ static int tp_bwd_go(const void* q, const void* k, const void* v, TpStrides qs, 
                      float* dpol_heads, int B, int H, int L, float scale, float c_leak, hipStream_t st) {
   hipLaunchKernelGGL((tp_delta_kernel<T>), dim3((unsigned)((L + 3) / 4), (unsigned)H, (unsigned)B), dim3(256), 0, st, o, d_o, os, delta, H, L, D);
   hipLaunchKernelGGL((tp_colsum_kernel<T>), dim3((unsigned)H, (unsigned)B), dim3(256), 0, st, d_o, os, Dn, gsum, H, L, D);
-  const dim3 grid((unsigned)((L + kTpTile - 1) / kTpTile), (unsigned)H, (unsigned)B);
-  {
-    auto kfn = tp_bwd_dkv_kernel<T, D, CAUSAL>;
-    const size_t smem = tp_smem_dkv<T, D>();
-    if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kfn, grid, dim3(kTpThreads), smem, st, q, k, v, qs, d_o, dk, dv, os, policy, bias, bias_sb, bias_sl, M, Dn, (const float*)delta,
-                       (const float*)gsum, dpol_heads, H, L, scale, c_leak);
-  }
-  {
-    auto kfn = tp_bwd_dq_kernel<T, D, CAUSAL>;
-    const size_t smem = tp_smem_dq<T, D>();
-    if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kfn, grid, dim3(kTpThreads), smem, st, q, k, v, qs, d_o, dq, os, policy, bias, bias_sb, bias_sl, M, Dn, (const float*)delta, H, L, scale);
-  }
-  return DL_OK;
+  // waves per workgroup of the two backward kernels (16 keys / 16 query rows each, sharing one staged tile of the other side): 8 at
+  // head_dim 128 once the launch still has >= 256 workgroups (two waves per SIMD where four leave one: L=2048 1160 -> 685 us), else 4
+  // (head_dim 64 already fits two 4-wave workgroups per CU; short rows need the workgroup count: L=631 187 vs 229 us)
+  const bool wide = D == 128 && (int64_t)B * H * ((L + 127) / 128) >= 256;
+  auto go = [&](auto nw_tag) -> int {
+    constexpr int NW = decltype(nw_tag)::value;
+    const dim3 grid((unsigned)((L + NW * 16 - 1) / (NW * 16)), (unsigned)H, (unsigned)B);
+    {
+      auto kfn = tp_bwd_dkv_kernel<T, D, CAUSAL, NW>;
+      const size_t smem = tp_smem_dkv<T, D, NW>();
+      if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
+      hipLaunchKernelGGL(kfn, grid, dim3(NW * 64), smem, st, q, k, v, qs, d_o, dk, dv, os, policy, bias, bias_sb, bias_sl, M, Dn, (const float*)delta,
+                         (const float*)gsum, dpol_heads, H, L, scale, c_leak);
+    }
+    {
+      auto kfn = tp_bwd_dq_kernel<T, D, CAUSAL, NW>;
+      const size_t smem = tp_smem_dq<T, D, NW>();
+      if (!tp_raise_lds(kfn, smem)) return DL_ERR_LAUNCH;
+      hipLaunchKernelGGL(kfn, grid, dim3(NW * 64), smem, st, q, k, v, qs, d_o, dq, os, policy, bias, bias_sb, bias_sl, M, Dn, (const float*)delta, H, L, scale);
+    }
+    return DL_OK;
+  };
+  if (wide) return go(std::integral_constant<int, 8>{});
+  return go(std::integral_constant<int, 4>{});
 }
 
 }  // namespace dl

@@ -48,7 +48,8 @@ def _oracle(q, k, v, do, pol, mask, causal, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,L,d,kind", [(2, 4, 200, 128, "causal"), (1, 2, 64, 128, "causal"), (2, 2, 131, 64, "causal"), (2, 3, 150, 128, "additive"),
-                                          (2, 2, 70, 64, "bool"), (1, 2, 96, 128, "none"), (1, 8, 333, 128, "causal")])
+                                          (2, 2, 70, 64, "bool"), (1, 2, 96, 128, "none"), (1, 8, 333, 128, "causal"),
+                                          (2, 32, 520, 128, "causal"), (2, 32, 449, 128, "additive")])  # the last two: >= 256 workgroups -> the 8-wave backward kernels
 def test_sdpa_with_policy_forward_backward(dtype, B, H, L, d, kind):
     from dynamic_llava_amd.train_ops import scaled_dot_product_attention_with_policy
 
