@@ -102,6 +102,7 @@ SIGNATURES = {
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
+    "dl_linear_splitk": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_attn_policy_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "dl_attn_policy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p]),
@@ -526,6 +527,18 @@ def gumbel_hard_keep_bwd(d_keep, prev, y_soft, d_log_probs, tau, d_prev=None):
     assert d_keep.is_contiguous() and prev.is_contiguous() and y_soft.is_contiguous()
     n = y_soft.numel() // 2
     _check(lib().dl_gumbel_hard_keep_bwd(_p(d_keep), _p(prev), _p(y_soft), _p(d_log_probs), _p(d_prev), n, float(tau), dtype_code(y_soft.dtype), _stream()), "dl_gumbel_hard_keep_bwd")
+
+
+def linear_splitk(a, w, parts, n_slices):
+    """parts[s] = a @ w[:, slice s]^T in fp32 (no bias); a [M,K] (row stride a.stride(0)), w [N,K]; parts: fp32, >= n_slices*M*N elements.
+    Returns the [n_slices, M, N] view for add_rmsnorm_parts."""
+    _dev(a, w, parts)
+    assert a.dim() == 2 and a.stride(1) == 1 and w.is_contiguous() and parts.dtype == torch.float32
+    M, K = a.shape
+    N = w.shape[0]
+    assert parts.numel() >= n_slices * M * N
+    _check(lib().dl_linear_splitk(_p(a), a.stride(0), _p(w), _p(parts), M, N, K, int(n_slices), dtype_code(a.dtype), _stream()), "dl_linear_splitk")
+    return parts[: n_slices * M * N].view(n_slices, M, N)
 
 
 def launch_probe(grid=1, block=64):

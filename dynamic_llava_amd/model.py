@@ -814,19 +814,28 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             o = F.linear(attn, layer.self_attn.o_proj.weight)
             x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
             act = ops.silu_mul(F.linear(x, layer.w_gu))
-            dn = F.linear(act, layer.mlp.down_proj.weight)
-            if i + 1 == L:
-                x = ops.add_rmsnorm(h, dn, self.model.norm.weight, eps)
-            elif i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"]):
-                ops.add_rmsnorm(h, dn, None, eps)  # residual add only: layer SL's norm runs after compaction
+            nw_next = self.model.norm.weight if i + 1 == L else (None if i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"])  # residual add only: layer SL's norm runs after compaction
+                                                               else self.model.layers[i + 1].input_layernorm.weight)
+            if dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024:
+                # down_proj at <= 192 packed rows (the compacted layers at B=1): the library streams [H, I] at 1.8 TB/s there; dl_linear_splitk
+                # cuts K into 8 slices and the residual-add / RMSNorm launch adds them in order (tools/bench_linear_splitk.py: 44 vs 54 us)
+                x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(act.shape[0], h.shape[1]), 8), nw_next, eps)
             else:
-                x = ops.add_rmsnorm(h, dn, self.model.layers[i + 1].input_layernorm.weight, eps)
+                x_new = ops.add_rmsnorm(h, F.linear(act, layer.mlp.down_proj.weight), nw_next, eps)
+            x = x if nw_next is None else x_new
         cache.lens.copy_(p["lens_dev"])  # layers < SL hold the full prompt, layers >= SL the compacted one
         if p["instruct_drop"]:
             cache.lens[1] -= p["instruct_drop"]
         if last_only:
             x = x.index_select(0, p["last_rows"] - p["instruct_drop"])
         return x
+
+    def _splitk_ws(self, rows, H):
+        """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
+        ws = getattr(self, "_splitk_buf", None)
+        if ws is None or ws.numel() < 8 * 192 * H:
+            ws = self._splitk_buf = torch.empty(8 * 192 * H, dtype=torch.float32, device=self.device)
+        return ws
 
     def _prefill_host_update(self, p, cache, indices):
         """Host mirrors of what `_prefill_run` did on the device (also the reference's in-place index shift, DML:1986-1994)."""

@@ -352,6 +352,12 @@ int dl_gumbel_hard_keep_fwd(const void* log_probs, const void* gumbels, const vo
 int dl_gumbel_hard_keep_bwd(const void* d_keep, const void* prev_decision, const void* y_soft, void* d_log_probs, void* d_prev, int64_t n,
                             float tau, int dtype, void* stream);
 
+/* ---- split-K projection for the prefill's narrow nn.Linear calls (o_proj DML:1127, down_proj DML:328 at M = 100..256 rows):
+ * parts[s][m][n] = sum over K slice s of A[m,k] W[n,k], fp32, s < n_slices (<= K / 128); the consumer adds the slices in order
+ * (dl_add_rmsnorm_parts: residual add + RMSNorm; dl_gemm_smallm_reduce semantics).  A [M,K] row stride lda, W [N,K] contiguous.
+ * bf16 / f16; N % 4 == 0, K % 8 == 0.  parts: n_slices * M * N floats. */
+int dl_linear_splitk(const void* A, int64_t lda, const void* W, float* parts, int M, int N, int K, int n_slices, int dtype, void* stream);
+
 /* ---- diagnostics: one empty kernel (launch-floor measurements, tools/bench_launch_floor.py). */
 int dl_launch_probe(int grid, int block, void* stream);
 

@@ -662,3 +662,28 @@ def test_attn_decode_rope_oproj_fused_equals_two_launches(ops, dtype, nH, nKV, N
         assert torch.equal(attn_b, attn_a), (rep, "attention output")
         assert torch.equal(y_b, y_a), (rep, "o_proj output", float((y_b.float() - y_a.float()).abs().max()))
         assert torch.equal(ka.nan_to_num(7.0), kb.nan_to_num(7.0)) and torch.equal(va.nan_to_num(7.0), vb.nan_to_num(7.0))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,s", [(170, 4096, 11008, 8), (117, 4096, 4096, 4), (1, 256, 1024, 2), (192, 320, 1088, 8), (200, 512, 2048, 4), (631, 4096, 1024, 1), (33, 256, 128, 1)])
+def test_linear_splitk(ops, dtype, M, N, K, s):
+    """Split-K projection: the slices summed in order == F.linear with fp32 accumulation (both tilings: all rows in one tile up to 192 rows,
+    64x64 beyond), ragged M / N / K tails, strided A, deterministic; with dl_add_rmsnorm_parts == library GEMM + dl_add_rmsnorm up to rounding."""
+    g = torch.Generator().manual_seed(77)
+    a_full = torch.randn(M, K + 24, generator=g).to(dtype).cuda()
+    a = a_full[:, :K]
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).cuda()
+    ws = torch.full((s * M * N + 16,), float("nan"), dtype=torch.float32, device="cuda")
+    parts = ops.linear_splitk(a, w, ws, s)
+    assert parts.shape == (s, M, N) and torch.isnan(ws[s * M * N :]).all()
+    ref = F.linear(a.float(), w.float())
+    got = parts.sum(0)
+    assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())) * math.sqrt(K / 1024 + 1)
+    assert torch.equal(parts, ops.linear_splitk(a, w, torch.empty_like(ws), s))
+    h0 = torch.randn(M, N, generator=g).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).cuda()
+    h1, h2 = h0.clone(), h0.clone()
+    x1 = ops.add_rmsnorm_parts(h1, parts.contiguous(), nw, 1e-5)
+    x2 = ops.add_rmsnorm(h2, ref.to(dtype), nw, 1e-5)
+    assert torch.equal(h1, h2) or float((h1.float() - h2.float()).abs().max()) <= 2 * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * float(h2.float().abs().max())
+    _close_ulp(x1, x2, dtype, 2.0, atol=2e-2)
