@@ -14,7 +14,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdynllava_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP vectoriser pairs independent fp32 operations into v_pk_{fma,mul,add}_f32 and broadcasts an operand through
+# op_sel.  On gfx950 (ROCm 7.2) the form whose LOW half takes src1's HIGH register (op_sel:[.,1,...]) returns wrong values while a wave of
+# ANOTHER kernel executes MFMA on the same SIMD (tools/pkfma_probe.hip: 0 mismatches in 1.6e10 threads alone, ~3 % of threads beside an MFMA
+# kernel on a second stream; this is what made two ranks sharing one GPU disagree -- DESIGN.md section 5).  Scalar fp32 VALU code has the
+# same rounding, so results do not change; tests/test_host_cpu.py disassembles the library and fails if such an instruction comes back.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _sources():

@@ -368,15 +368,6 @@ static int gemv_launch(int mode, const void* W, int N, int K, const void* x, int
 
 using namespace dl;
 
-__global__ void launch_probe_kernel() {}
-
-extern "C" int dl_launch_probe(int grid, int block, void* stream) {
-  DL_REQUIRE(grid >= 1 && block >= 1 && block <= 1024, "dl_launch_probe: bad arguments");
-  hipLaunchKernelGGL(launch_probe_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream);
-  DL_CHECK_LAUNCH("dl_launch_probe");
-  return DL_OK;
-}
-
 extern "C" int dl_gemv_max_batch(int K, int dtype) {
   const int es = dtype == DL_F32 ? 4 : 2;
   int b = (int)((size_t)(150 * 1024) / ((size_t)K * es));

@@ -101,7 +101,6 @@ SIGNATURES = {
     "dl_text_predictor_workspace_bytes": (c_int64, [c_int, c_int]),
     "dl_gemv_max_batch": (c_int, [c_int, c_int]),
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "dl_launch_probe": (c_int, [c_int, c_int, c_void_p]),
     "dl_linear_splitk": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_attn_policy_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "dl_attn_policy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
@@ -539,10 +538,6 @@ def linear_splitk(a, w, parts, n_slices):
     assert parts.numel() >= n_slices * M * N
     _check(lib().dl_linear_splitk(_p(a), a.stride(0), _p(w), _p(parts), M, N, K, int(n_slices), dtype_code(a.dtype), _stream()), "dl_linear_splitk")
     return parts[: n_slices * M * N].view(n_slices, M, N)
-
-
-def launch_probe(grid=1, block=64):
-    _check(lib().dl_launch_probe(int(grid), int(block), _stream()), "dl_launch_probe")
 
 
 def gemm_smallm_ok(M, N, K, dtype):

@@ -406,8 +406,7 @@ class _DecodeState:
             ops.gemm_smallm_ok(B, n, k, dtype) for n, k in (((nH + 2 * nKV) * d, H), (H, nH * d), (2 * I, H), (H, I), (V, H))
         )
         self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
-        self.graph = None
-        self.graph_key = None
+        self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
         # persistent decode step (one launch per step): batch 1, 16-bit dtypes, head_dim 128
         self.ptable = None
         self.ptable_key = None
@@ -569,7 +568,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             base += n
         if all(i is None for i in indices):
             indices = None
-        sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, hash(tuple(text_src)), len(text_src))
+        sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, tuple(text_src))
         return dict(sig=sig, B=B, lens=lens, indices=indices, text_src=text_src, text_dst=text_dst, img_dst=img_dst, img_rows=img_rows, total=base, n_feat=n_feat,
                     img_src=img_src if truncated else None)
 
@@ -578,6 +577,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         H = self.config.hidden_size
         embeds = torch.empty((lay["total"], H), dtype=self.dtype, device=self.device)
         ids = input_ids.reshape(-1).index_select(0, dev_idx["text_src"])
+        if lay["sig"][0] == "dev":
+            # device layout (speculative: every row is ASSUMED to hold one image token).  A row with several leaves IMAGE_TOKEN_INDEX (-200)
+            # among the gathered ids; that run is discarded and repeated on the host layout (the kernel raises its error flag), but the
+            # gather itself must stay inside the embedding table
+            ids = ids.clamp_min(0)
         embeds.index_copy_(0, dev_idx["text_dst"], self.model.embed_tokens(ids))
         if lay["img_dst"] and lay.get("img_src") is not None:  # rows cut inside their image span: only some features are placed
             f = image_features.to(self.dtype).reshape(-1, H).index_select(0, dev_idx["img_src"])
@@ -816,10 +820,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             act = ops.silu_mul(F.linear(x, layer.w_gu))
             nw_next = self.model.norm.weight if i + 1 == L else (None if i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"])  # residual add only: layer SL's norm runs after compaction
                                                                else self.model.layers[i + 1].input_layernorm.weight)
-            if dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024:
+            if dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024 and act.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
                 # down_proj at <= 192 packed rows (the compacted layers at B=1): the library streams [H, I] at 1.8 TB/s there; dl_linear_splitk
                 # cuts K into 8 slices and the residual-add / RMSNorm launch adds them in order (tools/bench_linear_splitk.py: 44 vs 54 us)
-                x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(act.shape[0], h.shape[1]), 8), nw_next, eps)
+                x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(h.shape[1]), 8), nw_next, eps)
             else:
                 x_new = ops.add_rmsnorm(h, F.linear(act, layer.mlp.down_proj.weight), nw_next, eps)
             x = x if nw_next is None else x_new
@@ -830,7 +834,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             x = x.index_select(0, p["last_rows"] - p["instruct_drop"])
         return x
 
-    def _splitk_ws(self, rows, H):
+    def _splitk_ws(self, H):
         """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
         ws = getattr(self, "_splitk_buf", None)
         if ws is None or ws.numel() < 8 * 192 * H:
@@ -1081,12 +1085,20 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
     def _run_decode_steps(self, st, cache, n_steps):
         """Enqueue n greedy steps (graph replay when enabled)."""
-        key = (self.use_persistent_decode, cache.slab.data_ptr(), cache.t_cap, cache.logical_cap, cache.sparse_cap, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0), repr(self.config.sparse_config))
+        # what the captured launches depend on: the slab (pointers, strides), the split-KV factor of each length group (the only thing
+        # the REQUESTED capacity changes -- keying on logical_cap / sparse_cap themselves would re-capture for every new prompt
+        # length of a variable-length workload such as the VQA loader), tables, stop ids and the switches that pick kernels
+        cfg = self.config
+        nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
+        splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
+        key = (self.use_persistent_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
+               repr(cfg.sparse_config), self.attn_oproj_fused, self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)
             return
-        if st.graph is None or st.graph_key != key:
+        g = st.graphs.get(key)
+        if g is None:
             # the warm-up executes one real step: snapshot / restore the state it advances
             snap = (st.cur_ids.clone(), st.out_ids.clone(), st.step.clone(), st.finished.clone(), cache.lens.clone(), st.decision.clone())
 
@@ -1095,9 +1107,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
             g, _ = self._capture(lambda: self._decode_step_kernels(st, cache, True), warm)
             st.cur_ids.copy_(snap[0]); st.out_ids.copy_(snap[1]); st.step.copy_(snap[2]); st.finished.copy_(snap[3]); cache.lens.copy_(snap[4]); st.decision.copy_(snap[5])
-            st.graph, st.graph_key = g, key
+            if len(st.graphs) >= 6:
+                st.graphs.pop(next(iter(st.graphs)))
+            st.graphs[key] = g
         for _ in range(n_steps):
-            st.graph.replay()
+            g.replay()
 
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
@@ -1487,6 +1501,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             # the caller keeps this cache (the reference returns an independent one per call): detach it from the pool, the next
             # generate() allocates a fresh slab instead of overwriting this one
             self._cache_pool = None
+            ptr = cache.slab.data_ptr()  # captured graphs hold raw pointers into the slab the caller now owns (and may free): drop them
+            self._prefill_graphs = {k: v for k, v in self._prefill_graphs.items() if ptr not in k}
+            st.graphs = {k: v for k, v in st.graphs.items() if ptr not in k}
             res = {"sequences": out, "past_key_values": cache}
             if want_scores:
                 res["scores"] = tuple(scores)

@@ -358,9 +358,6 @@ int dl_gumbel_hard_keep_bwd(const void* d_keep, const void* prev_decision, const
  * bf16 / f16; N % 4 == 0, K % 8 == 0.  parts: n_slices * M * N floats. */
 int dl_linear_splitk(const void* A, int64_t lda, const void* W, float* parts, int M, int N, int K, int n_slices, int dtype, void* stream);
 
-/* ---- diagnostics: one empty kernel (launch-floor measurements, tools/bench_launch_floor.py). */
-int dl_launch_probe(int grid, int block, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -515,6 +515,8 @@ class Oracle:
                 elif past_len and h.shape[1] == 1 and sc["use_output_text_predictor"]:  # DML:2377-2391
                     tl = text_predictor(self.sd, "model.output_text_score_predictor.", h).reshape(B, -1, 2)
                     text_decision = tl[:, :, 0] > tl[:, :, 1]
+                    if getattr(self, "force_text_decision", None) is not None:  # test hook: continue a comparison past a keep/evict logit pair that sits on the boundary
+                        text_decision = self.force_text_decision.to(text_decision.device).bool().reshape(text_decision.shape)
                     rec.update(text_logit=tl, text_decision=text_decision)
             h = self._layer(i, h, mask, position_ids, cache, init_n, sparse_layer, text_decision)
             attention_mask = None  # DML:2554

@@ -26,7 +26,7 @@ def test_configs1_32_layers_prefill_and_decode_vs_oracle():
     ids = fx.make_prompt(cfg, N_SYS, N_Q, seed=0)[None]
     images = torch.randn((1, 3, 336, 336), generator=g).to(dtype)
     feats = model.encode_images(images.cuda())  # the same projector output feeds both sides (CLIP parity: test_kernels_gpu)
-    n_steps = 5
+    n_steps = 8
     forced = fx.make_forced_tokens(cfg, n_steps, 1, seed=5)
     # ---- HIP path, the reference's own driver loop (BLTM:310-337) ----
     model.debug_records = {}
@@ -68,29 +68,45 @@ def test_configs1_32_layers_prefill_and_decode_vs_oracle():
             l_ref, p_ref = o.forward(ids, image_features=feats.cpu())
             pos_ref = o.records["position_ids"]
         assert torch.equal(pos_hip.long().view(-1), pos_ref.long().view(-1)), "position ids after compaction"
+        def step(orc, j, pkv_):
+            """One decode step of an oracle.  A keep/evict logit pair that sits on the boundary (|gap| <= 0.5 on either side) may
+            legitimately fall the other way: the step is then repeated with the HIP path's decision forced (oracle test hook), so that
+            every LATER step is still compared instead of the comparison ending here.  Away from the boundary a difference is an error."""
+            l_, p_ = orc.forward(forced[j][:, None], past_key_values=pkv_)
+            tl_ = orc.records["text_logit"]
+            gap_ = float((tl_[0, 0, 0] - tl_[0, 0, 1]).abs())
+            was_forced = False
+            if int(orc.records["text_decision"][0, 0]) != dec_hip[j]:
+                assert min(gap_, gap_hip[j]) <= 0.5, f"eviction decision differs away from the boundary, step {j}: oracle gap {gap_}, hip gap {gap_hip[j]}"
+                orc.force_text_decision = torch.tensor([[dec_hip[j]]])
+                l_, p_ = orc.forward(forced[j][:, None], past_key_values=pkv_)
+                orc.force_text_decision = None
+                was_forced = True
+            return l_, p_, was_forced
+
         ref_logits = [l_ref[0, -1].float()]
-        dec_ref = []
+        forced_steps = {"bf16": [], "fp32": []}
         for j in range(n_steps):
-            l_ref, p_ref = o.forward(forced[j][:, None], past_key_values=p_ref)
+            l_ref, p_ref, f_ = step(o, j, p_ref)
             ref_logits.append(l_ref[0, -1].float())
-            dec_ref.append(int(o.records["text_decision"][0, 0]))
+            if f_:
+                forced_steps["bf16"].append(j)
+        lens_ref = p_ref[1]
+        assert int(lens_ref[-1][0]) == int(lens[-1][0]) and int(lens_ref[0][0]) == int(lens[0][0]), "KV lengths after the decode steps"
         del o, p_ref
         o32 = Oracle(cfg, sd, torch.float32)  # casts the bf16 tensors up: identical parameter values
         o32.force_keep_index = keep_hip  # the fp32 run must follow the same kept set to be a ground truth for these logits
         l_32, p_32 = o32.forward(ids, image_features=feats.cpu().float())
         truth = [l_32[0, -1]]
         for j in range(n_steps):
-            l_32, p_32 = o32.forward(forced[j][:, None], past_key_values=p_32)
+            l_32, p_32, f_ = step(o32, j, p_32)
             truth.append(l_32[0, -1])
-            gap32 = float((o32.records["text_logit"][0, 0, 0] - o32.records["text_logit"][0, 0, 1]).abs())
-            if min(gap32, gap_hip[j]) > 0.5:
-                assert dec_hip[j] == dec_ref[j] == int(o32.records["text_decision"][0, 0]), f"eviction decision, step {j}"
-            else:
-                n_steps = j  # a boundary decision: the caches may diverge from here on; compare what came before
-                break
+            if f_:
+                forced_steps["fp32"].append(j)
     ulp = 2.0**-7
-    for j in range(n_steps + 1):
+    for j in range(n_steps + 1):  # EVERY step is compared (no early exit): boundary decisions were forced, not skipped
         e_hip = float((hip_logits[j] - truth[j]).abs().max())
         e_ref = float((ref_logits[j] - truth[j]).abs().max())
         assert e_hip <= 2.0 * e_ref + 2 * ulp * float(truth[j].abs().max()), f"step {j}: hip err {e_hip} vs reference err {e_ref}"
-    assert n_steps >= 1, "no decode step could be compared"
+    print(f"full depth: kept set {'forced to the HIP set (near-tied boundary)' if forced_keep is not None else 'bit-exact'}; "
+          f"eviction decisions forced at steps {forced_steps} of {n_steps}; evicted {n_steps - sum(dec_hip)} of {n_steps}")

@@ -105,3 +105,31 @@ def test_segment_indices_match_oracle():
     labels = [-100] * 9 + [5] * 4
     (_, _, _, _, _, _), (idx2,) = o.prepare_inputs_labels_for_multimodal(torch.tensor([ids]), None, None, None, torch.tensor([labels]), None, image_features=feats)
     assert m._segments(ids, labels, 36) == idx2[0]
+
+
+def test_library_has_no_packed_f32_op_that_reads_src1_high_half_into_the_low_lane(tmp_path):
+    """gfx950 / ROCm 7.2 (tools/pkfma_probe.hip): v_pk_{fma,mul,add}_f32 with op_sel[1] = 1 -- the low half of the
+    packed operation takes src1's HIGH register, which is how hipcc's SLP vectoriser broadcasts an operand to two independent fp32
+    chains -- returns wrong values whenever a wave of another kernel runs MFMA on the same SIMD (two processes on one GPU, or two
+    streams of one process).  The library is built with -fno-slp-vectorize; this test disassembles what was built and fails if that
+    instruction form is back."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    from dynamic_llava_amd import build_ext
+
+    so = tmp_path / "lib.so"
+    shutil.copy(build_ext.build(verbose=False), so)
+    subprocess.run([objdump, "--offloading", so.name], cwd=tmp_path, check=True, capture_output=True)  # extracts the gfx950 code objects next to the copy
+    objs = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert objs, "no gfx950 code object found in the library"
+    bad, n_mfma = [], 0
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", o], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        n_mfma += dis.count("v_mfma")
+        bad += [ln.strip() for ln in dis.splitlines() if re.search(r"v_pk_(fma|mul|add)_f32", ln) and re.search(r"op_sel:\[[01],1", ln)]
+    assert n_mfma > 0, "disassembly looks empty"
+    assert not bad, f"{len(bad)} packed fp32 instructions with op_sel[1]=1, e.g. {bad[:3]}"

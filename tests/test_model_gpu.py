@@ -21,6 +21,7 @@ from oracle.make_golden import CASES, SD_SEED, case_config  # noqa: E402
 from oracle.ref_cpu import Oracle  # noqa: E402
 
 ULP = {torch.float32: 2.0**-23, torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
+NEAR_TIED_KEPT_SETS = []  # golden cases that continued against the oracle on the HIP kept set (recorded, never skipped)
 
 
 def _build(cfg_ns, sd, clip, dtype):
@@ -52,11 +53,12 @@ def test_forward_loop_vs_reference_golden(name, golden_dir):
     forced = torch.from_numpy(g["forced"]) if "forced" in g.files else None
     tol = 1e-3 if dtype == torch.float32 else None
     # fp32 ground truth for the 16-bit noise-class bound
-    truth = None
     if dtype != torch.float32:
         o32 = Oracle(cfg, {k: v.to(dtype) for k, v in sd.items()}, torch.float32, clip=copy.deepcopy(clip).to(dtype))
     pkv, cur = None, ids
     ties = "ties" in name
+    alt = None  # set when a 16-bit kept set differs inside the rounding band: the oracle then continues on the HIP path's set
+    p32 = None
     for j in range(g["step_logits"].shape[0]):
         out = model(cur, images=images if j == 0 else None, past_key_values=pkv)
         pkv = out.past_key_values
@@ -75,8 +77,16 @@ def test_forward_loop_vs_reference_golden(name, golden_dir):
                 diff = set(pos[0].tolist()) ^ set(g["position_ids"][0].tolist())
                 assert all(n_sys <= p_ < n_sys + fx.n_image_tokens(cfg) for p_ in diff), diff
                 assert all(abs(ref_score[p_ - n_sys] - kth) <= 4 * ULP[dtype] * max(1.0, abs(kth)) for p_ in diff), (diff, kth)
-                return  # different (near-tied) kept sets: everything downstream legitimately differs
-            if not ties:
+                # both are valid top-k sets of scores that agree to the last bit of the dtype.  The golden's downstream values belong to
+                # the other set, so the rest of this case (logits, decisions, KV lengths) is checked against the ORACLE (pinned to the
+                # reference, same dtype) continuing on the HIP path's set -- nothing is skipped; the outcome is recorded.
+                alt = Oracle(cfg, {k_: v.to(dtype) for k_, v in sd.items()}, dtype, clip=copy.deepcopy(clip).to(dtype))
+                alt.force_keep_index = model.debug_records["keep_index"].cpu().long()
+                o32.force_keep_index = alt.force_keep_index
+                alt_pkv = None
+                NEAR_TIED_KEPT_SETS.append(name)
+                print(f"[{name}] kept set differs from the golden inside the rounding band ({sorted(diff)}): continuing against the oracle on the HIP set")
+            elif not ties:
                 np.testing.assert_array_equal(pos, g["position_ids"], err_msg="kept-token index set / position ids")
             else:  # tie-aware invariant: {s > s_k} subset kept subset {s >= s_k}, |kept| = k
                 score = model.debug_records["vision_score"].float().cpu().numpy()[0]
@@ -86,30 +96,43 @@ def test_forward_loop_vs_reference_golden(name, golden_dir):
             if "vision_logit" in g.files:
                 vl = model.debug_records["vision_logit"].float().cpu().numpy()
                 assert np.abs(vl - g["vision_logit"]).max() < (1e-3 if dtype == torch.float32 else 64 * ULP[dtype] * max(1.0, np.abs(g["vision_logit"]).max()))
+        ref_dec, ref_len_first, ref_len_last = g["text_decision"][j], g["len_first"][j], g["len_last"][j]
+        if alt is not None:
+            with torch.no_grad():
+                l_alt, alt_pkv = alt.forward(cur.cpu(), images=images.cpu() if j == 0 else None, past_key_values=alt_pkv)
+            ref = l_alt[:, -1].float().numpy()
+            td = alt.records.get("text_decision")
+            ref_dec = np.full_like(g["text_decision"][j], -1) if td is None else td.reshape(-1).to(torch.int32).numpy()
+            ref_len_first, ref_len_last = alt_pkv[1][0].numpy(), alt_pkv[1][-1].numpy()
+            np.testing.assert_array_equal(model.debug_records["position_ids"].cpu().numpy().reshape(-1), alt.records["position_ids"].numpy().reshape(-1)) if j == 0 else None
         if tol is not None:
             assert np.abs(last - ref).max() < tol, f"{name} step {j}: max |logit diff| {np.abs(last - ref).max()}"
         elif not ties:
-            if truth is None:
-                truth = []
-                p32, c32 = None, ids.cpu()
-                with torch.no_grad():
-                    for jj in range(g["step_logits"].shape[0]):
-                        l32, p32 = o32.forward(c32, images=images.cpu().float() if jj == 0 else None, past_key_values=p32)
-                        truth.append(l32[:, -1].numpy())
-                        c32 = (l32[:, -1].argmax(-1) if forced is None else forced[jj])[:, None]
-            err_hip = np.abs(last - truth[j]).max()
-            err_ref = np.abs(ref - truth[j]).max()
-            assert err_hip <= 2.0 * err_ref + 2 * ULP[dtype] * np.abs(truth[j]).max(), f"{name} step {j}: hip err {err_hip} vs reference err {err_ref}"
+            # fp32 truth in lockstep: the same input tokens as the HIP path (and the same kept set when it was forced)
+            with torch.no_grad():
+                l32, p32 = o32.forward(cur.cpu(), images=images.cpu().float() if j == 0 else None, past_key_values=p32)
+            truth_j = l32[:, -1].numpy()
+            err_hip = np.abs(last - truth_j).max()
+            err_ref = np.abs(ref - truth_j).max()
+            assert err_hip <= 2.0 * err_ref + 2 * ULP[dtype] * np.abs(truth_j).max(), f"{name} step {j}: hip err {err_hip} vs reference err {err_ref}"
         dec = model.debug_records.get("text_decision")
-        if j > 0 and (g["text_decision"][j] >= 0).all() and not ties:
-            np.testing.assert_array_equal(dec.cpu().numpy(), g["text_decision"][j], err_msg=f"text decision, step {j}")
+        if j > 0 and (ref_dec >= 0).all() and not ties:
+            np.testing.assert_array_equal(dec.cpu().numpy(), ref_dec, err_msg=f"text decision, step {j}")
         if not ties:
-            np.testing.assert_array_equal(pkv[1][0].numpy(), g["len_first"][j])
-            np.testing.assert_array_equal(pkv[1][-1].numpy(), g["len_last"][j])
-            assert pkv[0][0][0].shape[-2] == g["kv_len_first"][j] and pkv[0][-1][0].shape[-2] == g["kv_len_last"][j]
+            np.testing.assert_array_equal(pkv[1][0].numpy(), ref_len_first)
+            np.testing.assert_array_equal(pkv[1][-1].numpy(), ref_len_last)
+            if alt is None:
+                assert pkv[0][0][0].shape[-2] == g["kv_len_first"][j] and pkv[0][-1][0].shape[-2] == g["kv_len_last"][j]
+            else:
+                assert pkv[0][0][0].shape[-2] == alt_pkv[0][0][0].shape[-2] and pkv[0][-1][0].shape[-2] == alt_pkv[0][-1][0].shape[-2]
         if dtype == torch.float32:
             np.testing.assert_array_equal(out.logits[:, -1].argmax(-1).cpu().numpy(), g["ids"][j])
         cur = (out.logits[:, -1].argmax(-1) if forced is None else forced[j].cuda())[:, None]
+
+
+def test_near_tied_kept_sets_are_reported():
+    """Runs after the golden cases (file order): says how many 16-bit cases took the oracle-continuation branch on this GPU."""
+    print(f"golden cases whose kept set differed from the golden inside the rounding band: {NEAR_TIED_KEPT_SETS or 'none'}")
 
 
 def test_generate_greedy_matches_reference_golden(golden_dir):
@@ -688,6 +711,14 @@ def test_device_prompt_layout_kernel_and_generate_fast_path():
         assert int(seg[b, 1]) == ix["last_instruct"][0] - ix["instruct"][0], b
     assert out["text_src"].cpu().tolist() == lay["text_src"] and out["text_dst"].cpu().tolist() == lay["text_dst"]
     assert out["img_dst"].cpu().tolist() == lay["img_dst"] and out["img_start"].cpu().tolist() == [ix["image"][0] for ix in lay["indices"]]
+    # ... and directly against the ORACLE's segment table (pinned to the reference, ARCH:330-489): image start, last "USER:" offset
+    o = Oracle(cfg, sd, torch.float32, clip=clip)
+    feats = torch.zeros(B, n_feat, cfg.hidden_size)
+    (_, _, _, _, _, _), (o_idx,) = o.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None, image_features=feats)
+    for b in range(B):
+        assert int(seg[b, 0]) == o_idx[b]["image"][0], b
+        assert int(seg[b, 1]) == o_idx[b]["last_instruct"][0] - o_idx[b]["instruct"][0], (b, seg[b].tolist(), o_idx[b])
+        assert int(out["img_start"][b]) == o_idx[b]["image"][0]
     bad = ids.clone()
     bad[2, img_pos[2]] = 5  # no image token in row 2
     assert int(ops.prompt_layout(bad.cuda().contiguous(), n_feat, IMAGE_TOKEN_INDEX, USER_IDS)["err"].item()) == 3
@@ -712,6 +743,92 @@ def test_device_prompt_layout_kernel_and_generate_fast_path():
     model.device_prompt_layout = False
     b_ = model.generate(q.cuda(), images=images.cuda(), max_new_tokens=4, eos_token_id=None)
     assert torch.equal(a, b_)
+
+
+def test_userprompt_golden_layout_kernel_vs_oracle_and_generate(golden_dir):
+    """The golden case WITH "USER:" tokens in its prompt (tiny_fp32_userprompt, made by running the reference): (i) dl_prompt_layout's
+    "USER:" scan against the oracle's segment table on exactly these ids; (ii) generate() on this case -- the instruct predictor is on, so
+    the last-instruct span that the scan found decides which tokens are dropped -- reproduces the golden's first token, its KV lengths
+    and the oracle's greedy continuation, with and without a captured graph."""
+    from dynamic_llava_amd import hip_ops as ops
+    from dynamic_llava_amd.config import IMAGE_TOKEN_INDEX
+    from dynamic_llava_amd.model import USER_IDS
+
+    name = "tiny_fp32_userprompt"
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ids = torch.from_numpy(g["input_ids"])
+    assert any(int(ids[0, j]) == USER_IDS[0] and int(ids[0, j + 1]) == USER_IDS[1] for j in range(ids.shape[1] - 1)), "the golden prompt must contain USER:"
+    n_feat = fx.n_image_tokens(cfg)
+    o = Oracle(cfg, sd, dtype, clip=clip)
+    (_, _, _, _, _, _), (o_idx,) = o.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None, image_features=torch.zeros(1, n_feat, cfg.hidden_size))
+    out = ops.prompt_layout(ids.cuda().contiguous(), n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
+    seg = out["seg"].cpu()
+    assert int(out["err"].item()) == 0
+    assert int(seg[0, 0]) == o_idx[0]["image"][0] and int(seg[0, 2]) == 1
+    assert int(seg[0, 1]) == o_idx[0]["last_instruct"][0] - o_idx[0]["instruct"][0] > 0, (seg[0].tolist(), o_idx[0])
+    model = _build(cfg, sd, clip, dtype)
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    ref, _ = Oracle(cfg, sd, dtype, clip=clip).greedy(ids, images=images.cpu(), max_new_tokens=8, eos_token_id=None)
+    for graph in (False, True):
+        model.use_hip_graph = graph
+        one = model.generate(ids.cuda(), images=images, max_new_tokens=1, eos_token_id=None)
+        assert int(model.last_cache[1][-1][0]) == int(g["len_last"][0][0]) and int(model.last_cache[1][0][0]) == int(g["len_first"][0][0]), graph
+        assert abs(model.last_prefill_logits.cpu().numpy()[0] - g["step_logits"][0][0]).max() < 1e-3
+        assert int(one[0, 0]) == int(g["step_logits"][0][0].argmax())
+        got = model.generate(ids.cuda(), images=images, max_new_tokens=8, eos_token_id=None)
+        assert got.cpu().tolist() == ref.tolist(), graph
+
+
+def test_device_layout_speculation_is_memory_safe_for_multi_image_rows():
+    """a row with TWO image tokens on the (speculative) device-layout path used to gather embedding row -200 inside the captured
+    graph before the error flag was looked at.  The gathered ids are clamped now; the call must end in the host layout's clean
+    NotImplementedError (ARCH:330-332 calls .item() on the image position: exactly one image per row), and a text-only row mixed with an
+    image row must still fall back and match the host layout."""
+    from dynamic_llava_amd.config import IMAGE_TOKEN_INDEX
+
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1)
+    model = _build(cfg, sd, clip, torch.float32)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, cfg.vocab_size, (2, 12), generator=g)
+    ids[0, 4] = IMAGE_TOKEN_INDEX
+    ids[1, 2], ids[1, 9] = IMAGE_TOKEN_INDEX, IMAGE_TOKEN_INDEX  # two images in row 1
+    images = fx.make_images(cfg, 2, seed=0).cuda()
+    model.device_prompt_layout = True
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.cuda(), images=images, max_new_tokens=3, eos_token_id=None)
+    torch.cuda.synchronize()  # no sticky device fault was left behind
+    ok = ids.clone()
+    ok[1, 2], ok[1, 9] = 5, 6  # row 1 text-only
+    a = model.generate(ok.cuda(), images=images, max_new_tokens=3, eos_token_id=None)
+    model.device_prompt_layout = False
+    b_ = model.generate(ok.cuda(), images=images, max_new_tokens=3, eos_token_id=None)
+    assert torch.equal(a, b_)
+
+
+def test_decode_graph_is_reused_across_prompt_lengths():
+    """the captured decode step is keyed by what its launches depend on (slab, split-KV factors), not by the requested
+    capacity: prompts of different lengths that share a pooled slab and the same split factors replay ONE graph."""
+    from dynamic_llava_amd.config import IMAGE_TOKEN_INDEX
+
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1)
+    model = _build(cfg, sd, clip, torch.float32)
+    images = fx.make_images(cfg, 1, seed=0).cuda()
+    g = torch.Generator().manual_seed(6)
+    outs = {}
+    for W in (20, 14, 17, 20):
+        ids = torch.randint(3, cfg.vocab_size, (1, W), generator=torch.Generator().manual_seed(W))
+        ids[0, 3] = IMAGE_TOKEN_INDEX
+        out = model.generate(ids.cuda(), images=images, max_new_tokens=6, eos_token_id=None)
+        ref, _ = Oracle(cfg, sd, torch.float32, clip=clip).greedy(ids, images=images.cpu(), max_new_tokens=6, eos_token_id=None)
+        assert out.cpu().tolist() == ref.tolist(), W
+        outs.setdefault(W, out)
+        assert torch.equal(outs[W], out)
+    assert len(model._dstate.graphs) == 1, list(model._dstate.graphs)
 
 
 def test_decode_attention_merge_granules_of_an_earlier_request_cannot_be_consumed():

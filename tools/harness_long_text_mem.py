@@ -19,47 +19,53 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 
+class _Curve:
+    """The record the reference harness writes (same JSON keys, BLTM:128-142 / 346-351) plus the per-step time."""
+
+    KEYS = ("total_token_length", "kv_cache_length", "max_memory", "without_model_memory", "step_time_ms")
+
+    def __init__(self, model_memory, result_file):
+        self.rows = {k: [] for k in self.KEYS}
+        self.model_memory, self.result_file = model_memory, result_file
+
+    def add(self, n_tokens, kv_len, ms):
+        peak = torch.cuda.max_memory_allocated()
+        for k, v in zip(self.KEYS, (n_tokens, int(kv_len), peak, peak - self.model_memory, ms)):
+            self.rows[k].append(v)
+        if self.result_file:  # rewritten after every token, so that an interrupted run leaves its curve behind
+            with open(self.result_file, "w", encoding="utf-8") as f:
+                json.dump(self.rows, f, ensure_ascii=False, indent=4)
+
+
+def _tokens_fed(step_ids, step_images, patch=14):
+    """The reference's accounting of one call (BLTM:317-323): every image patch counts, the <image> placeholder does not."""
+    n = step_ids.shape[-1]
+    if step_images is not None:
+        n += (step_images.shape[-2] // patch) * (step_images.shape[-1] // patch) - 1
+    return n
+
+
+@torch.inference_mode()
 def run(model, cfg, input_ids, label_ids, images, model_memory=0, result_file=None, verbose=True):
-    """The BLTM:310-351 loop.  input_ids [B, n] (with one -200 per row), label_ids [B, T].  Returns the record dict."""
-    record = {"total_token_length": [], "kv_cache_length": [], "max_memory": [], "without_model_memory": [], "step_time_ms": []}
-    start_event = torch.cuda.Event(enable_timing=True)
-    end_event = torch.cuda.Event(enable_timing=True)
-    total_token_length = 0
-    past_key_values = None
-    for j in range(label_ids.shape[1]):
-        label_id = label_ids[:, j : j + 1]
-        if j > 0:
-            images = None
-        with torch.inference_mode():
-            if images is not None:
-                total_token_length += images.shape[-2] * images.shape[-1] // 14 // 14
-                total_token_length += input_ids.shape[-1] - 1
-            else:
-                total_token_length += input_ids.shape[-1]
-            start_event.record()
-            outputs = model(input_ids, images=images, past_key_values=past_key_values)
-            end_event.record()
-            torch.cuda.synchronize()
-            elapsed_time_ms = start_event.elapsed_time(end_event)
-        input_ids = label_id
-        past_key_values = outputs.past_key_values
-        total_cache_length = past_key_values[0][-1][0].shape[-2]
-        max_memory = torch.cuda.max_memory_allocated()
-        record["total_token_length"].append(total_token_length)
-        record["kv_cache_length"].append(int(total_cache_length))
-        record["max_memory"].append(max_memory)
-        record["without_model_memory"].append(max_memory - model_memory)
-        record["step_time_ms"].append(elapsed_time_ms)
-        if result_file:
-            with open(result_file, "w", encoding="utf-8") as f:
-                json.dump(record, f, ensure_ascii=False, indent=4)
-        if verbose and total_token_length % 100 == 0:
-            print("\n#--------------------------------------------------#")
-            print("total_token_length: " + str(total_token_length))
-            print("kv_cache_length: " + str(total_cache_length))
-            print("max_memory: " + str(max_memory / (1024**3)) + "G")
-            print("without_model_memory (kv cache): " + str((max_memory - model_memory) / (1024**3)) + "G")
-    return record
+    """Teacher-forced walk over `label_ids` [B, T] starting from `input_ids` [B, n] (one -200 per row): call 0 is the multimodal prefill,
+    every later call feeds the previous label column with the cache the model handed back; after each call the LAST layer's KV length is
+    read through the legacy indexing the reference harness uses (`pkv[0][-1][0].shape[-2]`).  Returns the record dict."""
+    curve = _Curve(model_memory, result_file)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fed, pkv = 0, None
+    feeds = [(input_ids, images)] + [(label_ids[:, j : j + 1], None) for j in range(label_ids.shape[1] - 1)]
+    for step_ids, step_images in feeds:
+        fed += _tokens_fed(step_ids, step_images)
+        t0.record()
+        pkv = model(step_ids, images=step_images, past_key_values=pkv).past_key_values
+        t1.record()
+        torch.cuda.synchronize()
+        curve.add(fed, pkv[0][-1][0].shape[-2], t0.elapsed_time(t1))
+        if verbose and fed % 100 == 0:
+            r = curve.rows
+            print(f"[{fed} tokens] last-layer KV {r['kv_cache_length'][-1]}, peak {r['max_memory'][-1] / 2**30:.3f} GiB "
+                  f"({r['without_model_memory'][-1] / 2**30:.3f} GiB beyond the weights)")
+    return curve.rows
 
 
 def main():

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel count / total / avg / min / max, like --stats CSV.
-usage: python tools_prof_summary.py gpurun_out/prof1/bench_results.db [top_n]"""
+usage: python tools/prof_summary.py gpurun_out/prof1/bench_results.db [top_n] [--after KERNEL_SUBSTRING]
+--after: only dispatches that START after the last dispatch whose name contains the substring (a marker kernel the traced script launches
+once its set-up -- weight init, warm-up -- is over)."""
 import re
 import sqlite3
 import sys
@@ -13,11 +15,21 @@ def short(name):
 
 
 def main():
-    db = sys.argv[1]
-    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    args = list(sys.argv[1:])
+    after = None
+    if "--after" in args:
+        i = args.index("--after")
+        after = args[i + 1]
+        del args[i : i + 2]
+    db = args[0]
+    top = int(args[1]) if len(args) > 1 else 40
     c = sqlite3.connect(db)
-    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     rows = c.execute("select name, start, end from kernels").fetchall()
+    if after is not None:
+        marks = [e for name, s, e in rows if after in name]
+        if not marks:
+            raise SystemExit(f"no dispatch named *{after}* in {db}")
+        rows = [r for r in rows if r[1] >= max(marks)]
     agg = {}
     for name, s, e in rows:
         a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
