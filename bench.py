@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-gpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--persistent", action="store_true", help="decode steps as ONE persistent launch (opt-in: measured slower than the launch path, DESIGN.md 4b)")
+    ap.add_argument("--persistent", action="store_true", help="decode: the four weight-streaming launches between two attentions as ONE launch on the LDS-DMA engine (dl_decode_block; opt-in: measured slower than the launch path, DESIGN.md 4b)")
     ap.add_argument("--predictor-gain", type=float, default=50.0, help="'trained-like' predictor scaling (no score ties); 1.0 = plain random init")
     ap.add_argument("--no-calibrate", action="store_true", help="leave the random-init output-text predictor as is (it then keeps or evicts everything)")
     return ap.parse_args()
@@ -426,7 +426,7 @@ def main():
     cfg = DynamicLlavaConfig(num_hidden_layers=args.layers)  # LLaVA-1.5-7B defaults, sparse_layer=2, keep 0.2
     model = build_random_model(cfg, dtype=dtype, device=device, seed=0, predictor_gain=args.predictor_gain)
     model.use_hip_graph = not args.no_graph
-    model.use_persistent_decode = args.persistent
+    model.use_block_decode = args.persistent
     model.tp_side_stream = os.environ.get("DL_TP_SIDE", "0") == "1"
     prompt, images = make_inputs(cfg, device, dtype)
     n_prompt = N_SYS + N_IMG + N_Q

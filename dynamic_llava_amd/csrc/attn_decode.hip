@@ -174,9 +174,8 @@ using namespace dl;
 
 extern "C" int64_t dl_attn_decode_workspace_bytes(int B, int n_heads, int head_dim, int n_splits) {
   if (n_splits <= 1) return 0;
-  // float partials [D + 4] (separate combine launch) or 8-byte granules [D + 2] (in-kernel combine) + the attention-output pairs
-  // that dl_attn_decode_rope_oproj hands to its GEMV workgroups: sized for the largest
-  return ((int64_t)B * n_heads * n_splits * (head_dim + kAttnPartPad) + (int64_t)B * n_heads * (head_dim / 2)) * (int64_t)sizeof(u64_t);
+  // float partials [D + 4] (separate combine launch) or 8-byte granules [D + 2] (in-kernel combine): sized for the larger
+  return (int64_t)B * n_heads * n_splits * (head_dim + kAttnPartPad) * (int64_t)sizeof(u64_t);
 }
 
 extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t slab_stride_b,

@@ -35,19 +35,14 @@ class VpWeights(Structure):
     ]
 
 
-class DecodePhase(Structure):
-    """Mirror of DlDecodePhase (include/dynllava.h): one phase of the persistent decode step."""
+class BlockPhase(Structure):
+    """Mirror of dl_block_phase (include/dynllava.h): one GEMV phase of dl_decode_block."""
 
-    _fields_ = [
-        ("kind", c_int32), ("flags", c_int32), ("N", c_int32), ("K", c_int32), ("in_region", c_int64), ("out_region", c_int64),
-        ("in_expect", c_int32), ("n_splits", c_int32), ("len_group", c_int32), ("reserved", c_int32),
-        ("W", c_void_p), ("norm_w", c_void_p), ("out", c_void_p), ("dump", c_void_p), ("k_slab", c_void_p), ("v_slab", c_void_p),
-    ]
+    _fields_ = [("W", c_void_p), ("norm_w", c_void_p), ("out", c_void_p), ("x_in", c_void_p), ("h_in", c_void_p), ("h_out", c_void_p),
+                ("N", c_int32), ("K", c_int32), ("flags", c_int32), ("reserved", c_int32)]
 
 
-PHASE_EMBED, PHASE_GEMV, PHASE_ATTN = 0, 1, 2
-PHASE_ADDNORM, PHASE_OUT_SILU_PAIR, PHASE_OUT_GLOBAL, PHASE_HAS_DELTA = 1, 2, 4, 8
-REGION_QKV, REGION_ATTN, REGION_O, REGION_ACT, REGION_DN = 0, 1, 2, 3, 4
+BLK_ADDNORM, BLK_SILU_PAIR = 1, 2
 
 
 class TpWeights(Structure):
@@ -83,11 +78,6 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
-    "dl_attn_decode_rope_oproj": (
-        c_int,
-        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
-         c_int, c_void_p],
-    ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "dl_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -111,13 +101,8 @@ SIGNATURES = {
     "dl_gumbel_hard_keep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
     "dl_kv_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dl_decode_persistent_sync_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "dl_decode_persistent_region": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int64)]),
-    "dl_decode_persistent": (
-        c_int,
-        [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
-    ),
+    "dl_decode_block_sync_bytes": (c_int64, [c_int]),
+    "dl_decode_block": (c_int, [POINTER(BlockPhase), c_int, c_void_p, c_int64, c_void_p, c_int, ctypes.c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dl_gemm_smallm_max_m": (c_int, []),
     "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "dl_gemm_smallm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -308,20 +293,6 @@ def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, works
         "dl_attn_decode_rope",
     )
     return out
-
-
-def attn_decode_rope_oproj(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, attn_out, workspace, n_splits, call_tag, n_heads, n_kv_heads, head_dim, w_o, y):
-    """Batch 1: fused RoPE + KV append + split-KV attention + o_proj GEMV in one launch (include/dynllava.h)."""
-    _dev(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, attn_out, workspace, w_o, y)
-    assert qkv.shape[0] == 1 and qkv.is_contiguous() and w_o.is_contiguous() and y.is_contiguous() and attn_out.is_contiguous()
-    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
-    _check(
-        lib().dl_attn_decode_rope_oproj(_p(qkv), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(1), k_slab.shape[2],
-                                        _p(attn_out), _p(workspace), int(n_splits), int(call_tag), n_heads, n_kv_heads, head_dim, _p(w_o), w_o.shape[0], _p(y),
-                                        dtype_code(qkv.dtype), _stream()),
-        "dl_attn_decode_rope_oproj",
-    )
-    return y
 
 
 def topk_select(score, k):
@@ -603,36 +574,34 @@ def silu_mul_parts(parts, out):
 
 
 # ------------------------------------------------------------------------------------------------
-# persistent decode step (one launch per batch-1 decode step; include/dynllava.h)
+# chained GEMV phases of a batch-1 decode layer in one launch (dl_decode_block; include/dynllava.h)
 # ------------------------------------------------------------------------------------------------
-def decode_persistent_sync_bytes(n_phases, H, I, n_heads, n_kv_heads, head_dim, max_splits):
-    return int(lib().dl_decode_persistent_sync_bytes(int(n_phases), int(H), int(I), int(n_heads), int(n_kv_heads), int(head_dim), int(max_splits)))
+def decode_block_sync(max_k, device):
+    """Granule workspace of dl_decode_block (zeroed: tag 0 is never expected)."""
+    return torch.zeros(int(lib().dl_decode_block_sync_bytes(int(max_k))) // 8, dtype=torch.int64, device=device)
 
 
-def decode_persistent_region(which, n_phases, H, I, n_heads, n_kv_heads, max_splits):
-    off = c_int64(0)
-    _check(lib().dl_decode_persistent_region(int(which), int(n_phases), int(H), int(I), int(n_heads), int(n_kv_heads), int(max_splits), ctypes.byref(off)), "dl_decode_persistent_region")
-    return int(off.value)
+def block_phases(specs):
+    """specs: list of dicts(W=, norm_w=None, out=None, x_in=None, h_in=None, h_out=None, flags=0) -> ctypes array of dl_block_phase."""
+    arr = (BlockPhase * len(specs))()
+    for e, sp in zip(arr, specs):
+        W = sp["W"]
+        assert W.dim() == 2 and W.is_contiguous()
+        e.W, e.N, e.K, e.flags = W.data_ptr(), W.shape[0], W.shape[1], int(sp.get("flags", 0))
+        for k in ("norm_w", "out", "x_in", "h_in", "h_out"):
+            t = sp.get(k)
+            setattr(e, k, None if t is None else t.data_ptr())
+    return arr
 
 
-def decode_phase_table(phases, device):
-    """list[DecodePhase] -> uint8 device tensor holding the packed table."""
-    arr = (DecodePhase * len(phases))(*phases)
-    buf = bytes(arr)
-    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
-
-
-def decode_persistent(table, n_phases, sync_buf, H, I, n_heads, n_kv_heads, head_dim, max_splits, eps, cos, sin, pos_base, kv_len0, kv_len1, cur_ids,
-                      slab_stride_h, T_cap, n_workgroups, dtype, spin_limit=0, stamps=None, stamp_wg=0):
-    _dev(table, sync_buf, cos, sin, pos_base, kv_len0, kv_len1, cur_ids)
-    assert pos_base.dtype == torch.int32 and kv_len0.dtype == torch.int32 and kv_len1.dtype == torch.int32 and cur_ids.dtype == torch.int64
+def decode_block(phases, sync, pos_base, call_tag, eps, dtype, err=None, n_workgroups=0, spin_limit=0, stamps=None, debug_mode=0):
+    """One launch: the chained GEMV phases of a batch-1 decode layer on the LDS-DMA engine (include/dynllava.h, dl_decode_block)."""
+    _dev(sync, pos_base)
+    assert pos_base.dtype == torch.int32 and sync.dtype == torch.int64
     _check(
-        lib().dl_decode_persistent(
-            _p(table), int(n_phases), _p(sync_buf), sync_buf.numel() * sync_buf.element_size(), int(H), int(I), int(n_heads), int(n_kv_heads), int(head_dim),
-            int(max_splits), float(eps), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len0), _p(kv_len1), _p(cur_ids), int(slab_stride_h), int(T_cap),
-            int(n_workgroups), int(spin_limit), _p(stamps), int(stamp_wg), dtype_code(dtype), _stream(),
-        ),
-        "dl_decode_persistent",
+        lib().dl_decode_block(phases, len(phases), _p(sync), sync.numel() * 8, _p(pos_base), int(call_tag), float(eps), None if err is None else _p(err), int(n_workgroups),
+                              int(spin_limit), None if stamps is None else _p(stamps), int(debug_mode), dtype_code(dtype), _stream()),
+        "dl_decode_block",
     )
 
 

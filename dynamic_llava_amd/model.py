@@ -407,10 +407,9 @@ class _DecodeState:
         )
         self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
-        # persistent decode step (one launch per step): batch 1, 16-bit dtypes, head_dim 128
-        self.ptable = None
-        self.ptable_key = None
-        self.psync = None
+        # dl_decode_block (opt-in): granule workspace + error word of the in-launch GEMV chain
+        self.blk_sync = None
+        self.blk_err = torch.zeros(1, dtype=torch.int32, device=device)
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
 
 
@@ -428,16 +427,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._dstate = None
         self._prefill_graphs = {}
         self.use_hip_graph = True
-        # batch-1 decode: attention + o_proj GEMV in ONE launch (dl_attn_decode_rope_oproj, bit-identical).  Measured 17.0 vs 16.3 us per layer for
-        # the two launches (tools/bench_attn_oproj.py): the attention slows down under W_o's stream and the GEMV side still pays two fabric
-        # round trips after it, so it is opt-in
-        self.attn_oproj_fused = False
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
-        # batch-1 decode step as ONE persistent launch (csrc/decode_persistent.hip): bit-identical to the launch path, but measured SLOWER on
-        # MI355X (3.56 vs 2.65 ms/token at 7B: DESIGN.md section 4b), so it is opt-in
-        self.use_persistent_decode = False
+        # batch-1 decode: the four weight-streaming launches between two attentions (o_proj -> gate|up -> down -> next q|k|v) as ONE launch on
+        # the LDS-DMA engine (csrc/decode_block.hip).  Bit-identical to the launch path; measured SLOWER on MI355X (the
+        # in-launch all-gathers cost 8-12 us per edge against ~4.6 us of banked weight stream), so it is opt-in
+        self.use_block_decode = False
         self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM.  tools/bench_decode_batch.py: 3.87 / 3.95 /
         # 4.24 ms per step at B = 4 / 8 / 16 against 5.1-5.3 on the library; a wash at 20-24 (4.64 / 4.80 vs 4.66 / 4.75) where the hand-written
@@ -877,84 +873,23 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
-    def _persistent_ok(self, st: _DecodeState, cache: KVSlabCache) -> bool:
-        """Shapes the persistent decode step takes (everything else runs the launch path, which computes the same bits)."""
+    def _block_ok(self, st: _DecodeState) -> bool:
         cfg = self.config
-        if not (self.use_persistent_decode and st.B == 1 and st.use_gemv and self.dtype in (torch.bfloat16, torch.float16)):
-            return False
-        nH, d, H, I = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
-        if d != 128 or H % 8 or I % 8 or H > 8192 or nH * d != H or st.n_cu < 8:
-            return False
-        ms = max(cache.n_splits(i, nH) for i in range(cfg.num_hidden_layers))
-        return ms <= 32 and nH * ((ms + 1) // 2) <= st.n_cu
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        return (self.use_block_decode and st.B == 1 and st.use_gemv and self.dtype in (torch.bfloat16, torch.float16) and H % 512 == 0 and I % 8 == 0
+                and H <= 8192 and cfg.num_attention_heads * cfg.head_dim == H)
 
-    def _persistent_table(self, st: _DecodeState, cache: KVSlabCache):
-        """Phase table of one decode step (device memory; rebuilt when the slab / split factors / buffers change)."""
-        cfg, sc = self.config, self.config.sparse_config
-        nH, nKV, d, H, I, V = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
-        L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
-        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
-        splits = [cache.n_splits(i, nH) for i in range(L)]
-        key = (cache.slab.data_ptr(), cache.t_cap, tuple(splits), st.logits.data_ptr(), st.tp_x.data_ptr(), use_tp, SL)
-        if st.ptable is not None and st.ptable_key == key:
-            return st.ptable
-        n_ph = 2 + 5 * L
-        ms = max(splits)
-        reg = {k: ops.decode_persistent_region(k, n_ph, H, I, nH, nKV, ms) for k in (ops.REGION_QKV, ops.REGION_ATTN, ops.REGION_O, ops.REGION_ACT, ops.REGION_DN)}
-        G = st.n_cu
-        ph = []
-
-        def add(**kw):
-            e = ops.DecodePhase()
-            for k_, v_ in kw.items():
-                setattr(e, k_, v_)
-            ph.append(e)
-
-        add(kind=ops.PHASE_EMBED, W=self.model.embed_tokens.weight.data_ptr())
-        A, HD, PAIR, OUTG = ops.PHASE_ADDNORM, ops.PHASE_HAS_DELTA, ops.PHASE_OUT_SILU_PAIR, ops.PHASE_OUT_GLOBAL
-        for i, layer in enumerate(self.model.layers):
-            add(kind=ops.PHASE_GEMV, flags=A | (HD if i > 0 else 0), N=layer.w_qkv.shape[0], K=H, in_region=reg[ops.REGION_DN], in_expect=G, out_region=reg[ops.REGION_QKV],
-                W=layer.w_qkv.data_ptr(), norm_w=layer.input_layernorm.weight.data_ptr(), dump=st.tp_x.data_ptr() if (use_tp and i == SL) else None)
-            add(kind=ops.PHASE_ATTN, n_splits=splits[i], len_group=cache.group(i), k_slab=cache.k[i].data_ptr(), v_slab=cache.v[i].data_ptr())
-            add(kind=ops.PHASE_GEMV, flags=0, N=H, K=nH * d, in_region=reg[ops.REGION_ATTN], in_expect=nH, out_region=reg[ops.REGION_O], W=layer.self_attn.o_proj.weight.data_ptr())
-            add(kind=ops.PHASE_GEMV, flags=A | HD | PAIR, N=2 * I, K=H, in_region=reg[ops.REGION_O], in_expect=G, out_region=reg[ops.REGION_ACT], W=layer.w_gu.data_ptr(),
-                norm_w=layer.post_attention_layernorm.weight.data_ptr())
-            add(kind=ops.PHASE_GEMV, flags=0, N=H, K=I, in_region=reg[ops.REGION_ACT], in_expect=G, out_region=reg[ops.REGION_DN], W=layer.mlp.down_proj.weight.data_ptr())
-        add(kind=ops.PHASE_GEMV, flags=A | (HD if L > 0 else 0) | OUTG, N=V, K=H, in_region=reg[ops.REGION_DN], in_expect=G, W=self.lm_head.weight.data_ptr(),
-            norm_w=self.model.norm.weight.data_ptr(), out=st.logits.data_ptr())
-        assert len(ph) == n_ph
-        st.ptable = ops.decode_phase_table(ph, self.device)
-        st.ptable_key = key
-        st.p_n_phases, st.p_max_splits = n_ph, ms
-        nbytes = ops.decode_persistent_sync_bytes(n_ph, H, I, nH, nKV, d, ms)
-        if st.psync is None or st.psync.numel() * 4 < nbytes:
-            st.psync = torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
-        return st.ptable
-
-    def _decode_step_persistent(self, st: _DecodeState, cache: KVSlabCache):
-        """Batch-1 decode step as ONE persistent launch (csrc/decode_persistent.hip): same arithmetic as _decode_step_gemv, bit for bit."""
-        cfg, sc = self.config, self.config.sparse_config
-        tab = self._persistent_table(st, cache)
-        cos, sin = self._rope
-        ops.decode_persistent(tab, st.p_n_phases, st.psync, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
-                              st.p_max_splits, cfg.rms_norm_eps, cos, sin, cache.len_full, cache.lens[0], cache.lens[1], st.cur_ids, cache.k[0].stride(1), cache.t_cap,
-                              st.n_cu, self.dtype, stamps=getattr(self, "_pstamps", None), stamp_wg=getattr(self, "_pstamp_wg", 0))
-        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and sc["sparse_layer"] < cfg.num_hidden_layers
-        if use_tp:  # F6 on the hidden state entering layer SL (dumped by the kernel); only the end-of-step length advance consumes it
-            self.model.output_text_score_predictor.decide(st.tp_x, st.tp_ws, st.tp_logits, st.decision)
-
-    def check_persistent(self):
-        """Raises if a persistent decode step gave up on an in-kernel wait (word 0 of its sync buffer; costs one device->host copy)."""
+    def check_block_decode(self):
+        """Raises if a dl_decode_block launch gave up on an in-kernel wait (costs one device->host copy)."""
         st = self._dstate
-        if st is not None and st.psync is not None:
-            code = int(st.psync[0].item())
+        if st is not None and self.use_block_decode:
+            code = int(st.blk_err.item())
             if code != 0:
-                raise ops.HipOpsError(f"persistent decode step aborted (code {code:#x}): a workgroup was not resident or a producer never published")
+                st.blk_err.zero_()
+                raise ops.HipOpsError(f"dl_decode_block aborted (code {code:#x}): a workgroup was not resident or a producer never published")
 
     def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
-        if self._persistent_ok(st, cache):
-            self._decode_step_persistent(st, cache)
-        elif st.use_gemv:
+        if st.use_gemv:
             self._decode_step_gemv(st, cache)
         else:
             self._decode_step_gemm(st, cache)
@@ -977,12 +912,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
         h_cur, h_alt, delta = st.h, st.h2, None
         A = ops.GEMV_ADDNORM
-        fuse_o = (self.attn_oproj_fused and st.B == 1 and self.dtype in (torch.bfloat16, torch.float16) and d == 128 and L >= 2 and nH * d <= 8192
-                  and self.attn_inkernel_combine)
+        block = self._block_ok(st)
+        if block and st.blk_sync is None:
+            st.blk_sync = ops.decode_block_sync(max(cfg.hidden_size, cfg.intermediate_size), self.device)
         for i, layer in enumerate(self.model.layers):
-            ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
-            if delta is not None:
-                h_cur, h_alt = h_alt, h_cur
+            if not (block and i > 0):  # with dl_decode_block the previous layer's launch already produced this layer's q|k|v
+                ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
+                if delta is not None:
+                    h_cur, h_alt = h_alt, h_cur
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 # only the end-of-step length advance consumes the decision: run the predictor on a side stream (a parallel
                 # branch of the captured graph) on a snapshot of the residual stream, off the layer chain's critical path
@@ -996,17 +933,30 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             lens = cache.len_of_layer(i)
             # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
             # only when the row is long enough to need more than one workgroup per head)
-            if fuse_o:  # attention + o_proj in one launch: W_o streams while the attention runs
-                ops.attn_decode_rope_oproj(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, nH), i & 0xff,
-                                           nH, nKV, d, layer.self_attn.o_proj.weight, st.o)
-            else:
-                ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d,
-                                     call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
-                ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
+            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, cache.n_splits(i, st.B * nH), nH, nKV, d,
+                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
+            if block:
+                # o_proj -> gate|up -> down -> next layer's q|k|v (lm_head after the last layer) in one launch; the residual stream goes
+                # h_cur -> (in LDS) -> h_alt exactly as the two add+norm prologues of the launch path update it
+                last = i + 1 == L
+                nxt_w = self.lm_head.weight if last else self.model.layers[i + 1].w_qkv
+                nxt_norm = self.model.norm.weight if last else self.model.layers[i + 1].input_layernorm.weight
+                ph = ops.block_phases([
+                    dict(W=layer.self_attn.o_proj.weight, x_in=st.attn),
+                    dict(W=layer.w_gu, h_in=h_cur, norm_w=layer.post_attention_layernorm.weight, flags=ops.BLK_ADDNORM | ops.BLK_SILU_PAIR),
+                    dict(W=layer.mlp.down_proj.weight),
+                    dict(W=nxt_w, norm_w=nxt_norm, h_out=h_alt, out=st.logits if last else st.qkv, flags=ops.BLK_ADDNORM),
+                ])
+                ops.decode_block(ph, st.blk_sync, cache.len_full, i & 0xff, eps, self.dtype, err=st.blk_err)
+                h_cur, h_alt = h_alt, h_cur
+                continue
+            ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
             ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
             h_cur, h_alt = h_alt, h_cur
             ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
             delta = st.dn
+        if block:
+            return
         ops.gemv(self.lm_head.weight, st.logits, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=self.model.norm.weight, eps=eps)
         if use_tp and self.tp_side_stream:
             torch.cuda.current_stream().wait_stream(st.tp_stream)  # join before anything reads st.decision
@@ -1091,8 +1041,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cfg = self.config
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
-        key = (self.use_persistent_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
-               repr(cfg.sparse_config), self.attn_oproj_fused, self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch)
+        key = (self.use_block_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
+               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)
@@ -1148,6 +1098,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
+            if st.blk_sync is not None:
+                st.blk_sync.zero_()
             self._decode_step_kernels(st, cache, False)
             sc_ = self.config.sparse_config
             use_tp = bool(sc_["use_text_predictor"] and sc_["use_output_text_predictor"]) and sc_["sparse_layer"] < self.config.num_hidden_layers
@@ -1409,6 +1361,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # request positions only grow, so a slot left by an earlier step never matches -- but a slot left by an EARLIER REQUEST at the same
         # position would.  Tag 0 is never expected: one clear per request makes every older granule unmatchable.
         st.attn_ws.zero_()
+        if st.blk_sync is not None:
+            st.blk_sync.zero_()  # same rule for the granules of dl_decode_block
         self._eos = -1 if eos is None else eos
         self._pad = pad
         self._min_new = min_new
@@ -1479,7 +1433,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if self._eos >= 0 and produced < max_new and bool(st.finished.min().item()):
                 break
         if B == 1:
-            self.check_persistent()
+            self.check_block_decode()
         if dev_layout and int(ent["didx"]["err"].item()) != 0:
             # a row without exactly one image token (text-only row, several images): what was computed is meaningless -- repeat the
             # call with the host-side layout, which handles (or rejects) those rows like the reference does

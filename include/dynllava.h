@@ -116,16 +116,6 @@ int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos
                         void* workspace, int n_splits, int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads,
                         int n_kv_heads, int head_dim, int dtype, void* stream);
 
-/* ---- batch 1: dl_attn_decode_rope (in-kernel combine) AND the o_proj GEMV y = W_o @ attn (DML:1127) in ONE launch: the GEMV
- * workgroups request their weight rows at once -- W_o streams while the attention runs -- and pick the attention output up from
- * granules in `workspace` (dl_attn_decode_workspace_bytes(1, ...)).  Bit-identical to dl_attn_decode_rope + dl_gemv(PLAIN).
- * qkv: [(nH + 2 nKV) * 128] un-rotated; attn_out [nH * 128] is written too; w_o [N, nH * 128]; y [N].  16-bit dtypes, head_dim 128,
- * nH * 128 <= 8192; call_tag as dl_attn_decode_rope (>= 0). */
-int dl_attn_decode_rope_oproj(const void* qkv, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base,
-                              const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_h, int T_cap, void* attn_out,
-                              void* workspace, int n_splits, int call_tag, int n_heads, int n_kv_heads, int head_dim, const void* w_o,
-                              int N, void* y, int dtype, void* stream);
-
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
  * (= stable descending sort; the reference's argsort is non-stable).  n <= 4096. */
@@ -240,55 +230,35 @@ int dl_kv_pack_rows(void* k_slab0, void* v_slab0, int64_t layer_stride, int n_la
 int dl_prompt_layout(const int64_t* input_ids, int B, int W, int n_feat, int image_token, int user_id0, int user_id1, int32_t* seg,
                      int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, void* stream);
 
-/* ---- one whole batch-1 decode step as ONE persistent launch (replaces the per-layer chain dl_gemv x4 + dl_attn_decode_rope of
- * DML:1011-1013 / 1127 / 328 / 2709 + DML:134-139 / 1289 / 1295 + DML:260-285 + CU:109-268 + DML:1114-1122, bit-identical to it).
- * The caller describes the step as a phase table in DEVICE memory (built once per model / cache):
- *   EMBED : h = W[cur_ids[0], :]                                    (W = embedding table [V, H])
- *   GEMV  : y = W @ x.  flags: ADDNORM      x = norm_w * rmsnorm(h [+= delta]) (delta = the vector in in_region when HAS_DELTA)
- *                              else         x = the vector in in_region (K elements)
- *                              OUT_SILU_PAIR W = gate|up fused [2I, K]: y[n] = silu(W[n] x) * (W[I+n] x)
- *                              OUT_GLOBAL   y written to `out` (model dtype, [N]) instead of out_region
- *                       dump (optional, with ADDNORM): the updated residual stream h is also written there ([H], model dtype)
- *                       in_expect: number of workgroups that publish in_region (grid size, or n_heads after an ATTN phase with
- *                       n_splits > 1, or n_heads * ceil(n_splits / 2) ... see dl_decode_persistent_attn_publishers)
- *   ATTN  : RoPE + KV append at slot kv_len + split-KV attention of one layer on the q|k|v vector of the preceding GEMV phase;
- *           n_splits as dl_attn_decode_rope, len_group selects kv_len0 / kv_len1; output -> DL_REGION_ATTN.
- * Regions are offsets (in 8-byte granules) into `sync_buf`, obtained from dl_decode_persistent_region.  sync_buf
- * (dl_decode_persistent_sync_bytes) is zeroed by this call (a small kernel ahead of the step).  n_workgroups: 0 = one per CU.  Every in-kernel wait
- * is bounded by spin_limit (0 = default); on give-up word 0 of sync_buf becomes non-zero (read it after a synchronisation).
- * debug_stamps (NULL in production): int64 [n_workgroups][n_phases][8] wall-clock stamps (100 MHz), tools/persistent_timeline.py. */
-#define DL_PHASE_EMBED 0
-#define DL_PHASE_GEMV 1
-#define DL_PHASE_ATTN 2
-#define DL_PHASE_ADDNORM 1
-#define DL_PHASE_OUT_SILU_PAIR 2
-#define DL_PHASE_OUT_GLOBAL 4
-#define DL_PHASE_HAS_DELTA 8
-#define DL_REGION_QKV 0
-#define DL_REGION_ATTN 1
-#define DL_REGION_O 2
-#define DL_REGION_ACT 3
-#define DL_REGION_DN 4
-typedef struct DlDecodePhase {
-  int32_t kind, flags;
-  int32_t N, K;
-  int64_t in_region, out_region;
-  int32_t in_expect, n_splits, len_group, reserved;
-  const void* W;
-  const void* norm_w;
-  void* out;
-  void* dump;
-  void* k_slab;
-  void* v_slab;
-} DlDecodePhase;
-int64_t dl_decode_persistent_sync_bytes(int n_phases, int H, int I, int n_heads, int n_kv_heads, int head_dim, int max_splits);
-int dl_decode_persistent_region(int which, int n_phases, int H, int I, int n_heads, int n_kv_heads, int max_splits,
-                                int64_t* offset_granules);
-int dl_decode_persistent(const DlDecodePhase* phases_dev, int n_phases, void* sync_buf, int64_t sync_bytes, int H, int I, int n_heads,
-                         int n_kv_heads, int head_dim, int max_splits, float eps, const void* cos_tab, const void* sin_tab, int n_pos,
-                         const int32_t* pos_base, const int32_t* kv_len0, const int32_t* kv_len1, const int64_t* cur_ids,
-                         int64_t slab_stride_h, int T_cap, int n_workgroups, int spin_limit, void* debug_stamps, int debug_wg, int dtype,
-                         void* stream);
+/* ---- the weight-streaming part of a batch-1 decode layer as ONE launch on the LDS-DMA engine (csrc/decode_block.hip): up to 4 chained
+ * GEMV phases, y_i = W_i x_i, where phase 0 reads its input vector from memory (x_in: the attention output) and phase i > 0 consumes
+ * phase i-1's output inside the launch (8-byte {tag, bf16 pair} granules in `sync_buf`); the last phase writes `out` to memory.  The
+ * decode layer is o_proj (DML:1127) -> gate|up with residual add + RMSNorm prologue and SiLU*up epilogue (DML:1289-1295, 134-139, 328)
+ * -> down_proj (DML:328) -> the next layer's q|k|v with add + norm (DML:1011-1013; lm_head DML:2709 after the last layer).  Arithmetic
+ * and order are dl_gemv's: the result is bit-identical to the chain of dl_gemv launches it replaces.
+ *   flags: DL_BLK_ADDNORM   x = norm_w * rmsnorm(h + delta): delta = the phase's input vector, h = h_in (memory) for the first such
+ *                           phase of a block and the block's own running residual afterwards; h_out (may be NULL): the updated
+ *                           residual stream is also written to memory (by one workgroup)
+ *          DL_BLK_SILU_PAIR W = gate|up [2 I, K]: out[o] = cast(cast(silu(y_o)) * y_{I+o}), I = N / 2 outputs
+ * N even, K % 8 == 0, bf16 / f16, batch 1.  pos_base[0] (the new token's position) and call_tag (0..255, e.g. the layer) make the
+ * granule tags of this call unique among calls that reuse `sync_buf` (dl_decode_block_sync_bytes(max K); clear it once per request).
+ * One 256-thread workgroup per CU (n_workgroups: 0 = all CUs), all of which must be resident: every in-kernel wait is bounded
+ * (spin_limit, 0 = default) and a give-up ORs a code into *err_flag (may be NULL).  debug_stamps: NULL; debug_mode: 0 (measurement modes of
+ * tools/bench_block.py: 1 = no arithmetic, 2 = loader wave alone; the outputs are then meaningless). */
+#define DL_BLK_ADDNORM 1
+#define DL_BLK_SILU_PAIR 2
+typedef struct dl_block_phase {
+  const void* W;      /* [N, K] row-major */
+  const void* norm_w; /* [K] (DL_BLK_ADDNORM) */
+  void* out;          /* last phase: [N] (or [N/2] with DL_BLK_SILU_PAIR); NULL otherwise */
+  const void* x_in;   /* phase 0: input vector [K]; NULL otherwise */
+  const void* h_in;   /* first DL_BLK_ADDNORM phase: residual stream [K] */
+  void* h_out;        /* DL_BLK_ADDNORM: updated residual stream [K], or NULL */
+  int32_t N, K, flags, reserved;
+} dl_block_phase;
+int64_t dl_decode_block_sync_bytes(int max_k);
+int dl_decode_block(const dl_block_phase* phases, int n_phases, void* sync_buf, int64_t sync_bytes, const int32_t* pos_base, int call_tag,
+                    float eps, int32_t* err_flag, int n_workgroups, int spin_limit, void* debug_stamps, int debug_mode, int dtype, void* stream);
 
 /* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
  * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;

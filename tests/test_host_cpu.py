@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.dl_version() == 1
     assert isinstance(lib.dl_last_error(), bytes)
     # workspace-size queries are pure host functions
-    assert lib.dl_attn_decode_workspace_bytes(2, 32, 128, 8) == (2 * 32 * 8 * 132 + 2 * 32 * 64) * 8  # split partials (granules) + attention-output pairs
+    assert lib.dl_attn_decode_workspace_bytes(2, 32, 128, 8) == 2 * 32 * 8 * 132 * 8  # split partials (granules)
     assert lib.dl_attn_decode_workspace_bytes(2, 32, 128, 1) == 0
     assert lib.dl_vision_predictor_workspace_bytes(1, 576, 4096, 512, 2048, 2) > 576 * 4096 * 2
 

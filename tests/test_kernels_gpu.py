@@ -632,36 +632,42 @@ def test_kv_pack_rows(ops, dtype, B, nKV, d, T, n_layers):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("nH,nKV,N,T,n_splits", [(32, 32, 4096, 234, 4), (32, 32, 4096, 695, 8), (40, 40, 5120, 2047, 6), (2, 2, 256, 60, 1), (8, 2, 1000, 130, 3)])
-def test_attn_decode_rope_oproj_fused_equals_two_launches(ops, dtype, nH, nKV, N, T, n_splits):
-    """dl_attn_decode_rope_oproj (attention + o_proj GEMV in one launch, W_o streaming while the attention runs) == dl_attn_decode_rope followed
-    by dl_gemv(PLAIN): attention output, appended K/V and y bit-identical; repeated on the same workspace with changing call tags."""
-    d = 128
-    g = torch.Generator().manual_seed(60)
-    T_cap = T + 8
-    k0 = torch.randn(1, nKV, T_cap, d, generator=g).to(dtype)
-    v0 = torch.randn(1, nKV, T_cap, d, generator=g).to(dtype)
-    k0[0, :, T:] = float("nan")
-    v0[0, :, T:] = float("nan")
-    qkv = torch.randn(1, (nH + 2 * nKV) * d, generator=g).to(dtype).cuda()
-    w_o = (torch.randn(N, nH * d, generator=g) / math.sqrt(nH * d)).to(dtype).cuda()
-    cos, sin = orc.rope_table(d, 4096, 10000.0, dtype)
-    lens = torch.tensor([T], dtype=torch.int32).cuda()
-    posd = torch.tensor([T + 461], dtype=torch.int32).cuda()
-    ws = ops.attn_decode_workspace(1, nH, d, 32, "cuda")
-    ka, va = k0.cuda().clone(), v0.cuda().clone()
-    attn_a = torch.empty(1, nH * d, dtype=dtype, device="cuda")
-    ops.attn_decode_rope(qkv, cos.cuda(), sin.cuda(), posd, lens, ka, va, attn_a, ws, n_splits, nH, nKV, d)
-    y_a = torch.empty(1, N, dtype=dtype, device="cuda")
-    ops.gemv(w_o, y_a, x=attn_a)
-    for rep, tag in enumerate([0, 1, 5, 0]):
-        kb, vb = k0.cuda().clone(), v0.cuda().clone()
-        attn_b = torch.full((1, nH * d), float("nan"), dtype=dtype, device="cuda")
-        y_b = torch.full((1, N), float("nan"), dtype=dtype, device="cuda")
-        ops.attn_decode_rope_oproj(qkv, cos.cuda(), sin.cuda(), posd, lens, kb, vb, attn_b, ws, n_splits, tag, nH, nKV, d, w_o, y_b)
-        assert torch.equal(attn_b, attn_a), (rep, "attention output")
-        assert torch.equal(y_b, y_a), (rep, "o_proj output", float((y_b.float() - y_a.float()).abs().max()))
-        assert torch.equal(ka.nan_to_num(7.0), kb.nan_to_num(7.0)) and torch.equal(va.nan_to_num(7.0), vb.nan_to_num(7.0))
+@pytest.mark.parametrize("H,I,NQ", [(4096, 11008, 12288), (5120, 13824, 15360), (512, 1536, 1536), (1024, 2816, 1000)])
+def test_decode_block_bit_identical_to_the_gemv_chain(ops, dtype, H, I, NQ):
+    """dl_decode_block (LDS-DMA loader wave + consumer waves, phase outputs handed over as granules inside the launch) against the chain of
+    dl_gemv launches it replaces: every one-phase block and the whole o -> gate|up -> down -> q|k|v block, bit for bit (7B, 13B, small and
+    ragged shapes: rows of 21.5 / 27 / 5.5 pieces, unit counts that do not divide by the CU count), repeated with other positions / call tags on
+    the same granule workspace (no stale granule may be consumed), residual stream included."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *shape, s=0.02: (torch.randn(*shape, device="cuda", generator=g) * s).to(dtype)
+    Wo, Wgu, Wd, Wq = rnd(H, H), rnd(2 * I, H), rnd(H, I), rnd(NQ, H)
+    nw1, nw2 = 1 + rnd(H, s=0.1), 1 + rnd(H, s=0.1)
+    attn, h0 = rnd(1, H, s=1.0), rnd(1, H, s=1.0)
+    eps = 1e-5
+    mk = lambda n: torch.zeros(1, n, dtype=dtype, device="cuda")
+    o_r, act_r, dn_r, qkv_r, hm_r, ho_r = mk(H), mk(I), mk(H), mk(NQ), mk(H), mk(H)
+    A, P = ops.BLK_ADDNORM, ops.BLK_SILU_PAIR
+    ops.gemv(Wo, o_r, x=attn)
+    ops.gemv(Wgu, act_r, mode=ops.GEMV_ADDNORM | ops.GEMV_OUT_SILU_PAIR, h_in=h0, h_out=hm_r, delta=o_r, norm_w=nw1, eps=eps)
+    ops.gemv(Wd, dn_r, x=act_r)
+    ops.gemv(Wq, qkv_r, mode=ops.GEMV_ADDNORM, h_in=hm_r, h_out=ho_r, delta=dn_r, norm_w=nw2, eps=eps)
+    pos = torch.tensor([77], dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sync = ops.decode_block_sync(max(H, I), "cuda")
+    one = lambda spec, tag: ops.decode_block(ops.block_phases([spec]), sync, pos, tag, eps, dtype, err=err)
+    y, y2, hm, y3, y4, ho = mk(H), mk(I), mk(H), mk(H), mk(NQ), mk(H)
+    one(dict(W=Wo, x_in=attn, out=y), 1)
+    one(dict(W=Wgu, x_in=o_r, h_in=h0, h_out=hm, norm_w=nw1, out=y2, flags=A | P), 2)
+    one(dict(W=Wd, x_in=act_r, out=y3), 3)
+    one(dict(W=Wq, x_in=dn_r, h_in=hm_r, h_out=ho, norm_w=nw2, out=y4, flags=A), 4)
+    assert torch.equal(y, o_r) and torch.equal(y2, act_r) and torch.equal(hm, hm_r) and torch.equal(y3, dn_r) and torch.equal(y4, qkv_r) and torch.equal(ho, ho_r)
+    for rep in range(12):
+        pos.fill_(100 + rep // 2)  # the same position under another call tag, then the next position
+        qkv_b, ho_b = mk(NQ), mk(H)
+        ph = ops.block_phases([dict(W=Wo, x_in=attn), dict(W=Wgu, h_in=h0, norm_w=nw1, flags=A | P), dict(W=Wd), dict(W=Wq, norm_w=nw2, h_out=ho_b, out=qkv_b, flags=A)])
+        ops.decode_block(ph, sync, pos, rep & 1, eps, dtype, err=err)
+        assert torch.equal(qkv_b, qkv_r) and torch.equal(ho_b, ho_r), rep
+    assert int(err.item()) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
