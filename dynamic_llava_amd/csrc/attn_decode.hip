@@ -8,6 +8,8 @@
 // groups merge through LDS once per workgroup, splits merge in attn_decode_combine_kernel.
 // Per-row lengths are read from the device (kv_len[b] + extra): no host sync, graph-capturable,
 // and a slot beyond the true length (an evicted token) is simply never read.
+#include <mutex>
+
 #include "attn_decode_body.h"
 #include "granule.h"
 
@@ -36,7 +38,8 @@ __device__ long long g_attn_stamps[8];
 // merges them itself -- same merge code, same order, same bits as attn_decode_combine_kernel -- instead of a second launch (4.7 us +
 // a ~1.2 us boundary per layer at batch 1).  tag = f(position of the new token, call_tag): the writes that precede a launch in the same
 // slot come from the previous layer / step, so a stale granule never carries the expected tag.  Needs every workgroup of the grid
-// resident (the host only selects INK for grids of <= 1024 workgroups); the wait is bounded and poisons the output with NaN on give-up.
+// resident (the host selects INK only for grids the device can hold at once: ink_resident_capacity); the wait is bounded and poisons the
+// output with NaN on give-up.
 template <typename T, int D, int NW, bool FUSED, int U, bool INK = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     const void* __restrict__ q_, int64_t q_row_stride, const void* k_slab_, const void* v_slab_, int64_t stride_b, int64_t stride_h,
@@ -144,6 +147,29 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
   store1<T>(out_, (int64_t)b * out_row_stride + (int64_t)h * D + d, o[0]);
 }
 
+// workgroups of `kfn` (block threads, dynamic LDS bytes) the current device holds at once, at most 4 per CU (the regime the spin-wait of the
+// in-kernel combine was validated in); 0 when the device cannot be queried.  Cached per (kernel, device).
+static int64_t ink_resident_capacity(const void* kfn, int threads, size_t smem) {
+  struct Entry { const void* k; int dev; int64_t cap; };
+  static std::mutex mu;
+  static Entry cache[16];
+  static int n_cache = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < n_cache; ++i)
+    if (cache[i].k == kfn && cache[i].dev == dev) return cache[i].cap;
+  int n_cu = 0, per_cu = 0;
+  int64_t cap = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, smem > 4096 ? smem : 4096) == hipSuccess)
+    cap = (int64_t)n_cu * (per_cu < 4 ? per_cu : 4);
+  else
+    (void)hipGetLastError();
+  if (n_cache < 16) cache[n_cache++] = Entry{kfn, dev, cap};
+  return cap;
+}
+
 template <typename T, int D, int NW, bool FUSED, int U>
 static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t stride_b, int64_t stride_h,
                          const int32_t* kv_len, int extra, void* out, int64_t out_row_stride, void* workspace, int n_splits, int B,
@@ -151,8 +177,11 @@ static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab
                          int T_cap, int chunk_keys, hipStream_t st, int call_tag = -1) {
   const float scale = 1.0f / sqrtf((float)D);
   if constexpr (FUSED) {
-    // in-kernel combine: only when every workgroup of the grid is certainly resident (<= 4 per CU) and the caller gave a call tag
-    if (call_tag >= 0 && n_splits > 1 && (int64_t)n_splits * n_heads * B <= 1024) {
+    // in-kernel combine: only when every workgroup of the grid is certainly resident -- what THIS device (CU count of the current
+    // partition mode, occupancy of this kernel with its merge buffer) can hold at once, capped at 4 per CU -- and the caller gave a tag
+    if (call_tag >= 0 && n_splits > 1 &&
+        (int64_t)n_splits * n_heads * B <= ink_resident_capacity((const void*)attn_decode_split_kernel<T, D, NW, true, U, true>, NW * 64,
+                                                                  (size_t)n_splits * (D + kAttnPartPad) * sizeof(float))) {
       const size_t smem = (size_t)n_splits * (D + kAttnPartPad) * sizeof(float);
       hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, true, U, true>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64),
                          smem, st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,

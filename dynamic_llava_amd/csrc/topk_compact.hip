@@ -227,6 +227,66 @@ extern "C" int dl_compact_tokens(const void* h_in, void* h_out, const int64_t* k
   return DL_OK;
 }
 
+// ---- rows of ONE packed sequence kept or dropped by a device-side decision over a span (the instruct predictor's prefill compaction,
+// DML:2261-2375: tokens [span0, span0 + n_span) of the last instruct turn survive where decision != 0, everything else always).  One workgroup
+// per INPUT row: its destination = its index minus the drops in front of it (a block sum over the span's decisions: n_span is a few dozen),
+// 16-byte row copy + the original position id.  The kept count never goes to the host: it is written to `counts` = {kept rows, kept rows - 1}
+// and `cu_out` = {0, kept rows}, which the following launches (grids sized for the UPPER bound `total`) read from device memory. ----
+namespace dl {
+template <typename T>
+__global__ __launch_bounds__(256) void compact_rows_by_mask_kernel(const void* __restrict__ h_in, const int32_t* __restrict__ pos_in, const int32_t* __restrict__ dec,
+                                                                   int span0, int n_span, int total, int H, void* __restrict__ h_out,
+                                                                   int32_t* __restrict__ pos_out, int32_t* __restrict__ cu_out, int64_t* __restrict__ counts) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  __shared__ int red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  // drops in front of row i, and (workgroup 0) in total
+  const int upto = i < span0 ? 0 : (i - span0 < n_span ? i - span0 : n_span);
+  int before = 0, all = 0;
+  for (int j = tid; j < n_span; j += 256) {
+    const int drop = dec[j] != 0 ? 0 : 1;
+    all += drop;
+    before += j < upto ? drop : 0;
+  }
+  before = (int)wave_sum((float)before);  // exact: counts are far below 2^24
+  all = (int)wave_sum((float)all);
+  if ((tid & 63) == 0) red[tid >> 6] = before;
+  __syncthreads();
+  before = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = all;
+  __syncthreads();
+  all = red[0] + red[1] + red[2] + red[3];
+  if (i == 0 && tid == 0) {
+    cu_out[0] = 0;
+    cu_out[1] = total - all;
+    counts[0] = total - all;
+    counts[1] = total - all - 1;
+  }
+  const bool keep = i < span0 || i >= span0 + n_span || dec[i - span0] != 0;
+  if (!keep) return;
+  const int dst = i - before;
+  const S* src = reinterpret_cast<const S*>(h_in) + (int64_t)i * H;
+  S* out = reinterpret_cast<S*>(h_out) + (int64_t)dst * H;
+  for (int v = tid; v < H / V; v += 256) *reinterpret_cast<uint4*>(out + v * V) = *reinterpret_cast<const uint4*>(src + v * V);
+  if (tid == 0) pos_out[dst] = pos_in ? pos_in[i] : i;
+}
+}  // namespace dl
+
+extern "C" int dl_compact_rows_by_mask(const void* h_in, const int32_t* pos_in, const int32_t* decision, int span0, int n_span, int total, int H, void* h_out,
+                                       int32_t* pos_out, int32_t* cu_out, int64_t* counts, int dtype, void* stream) {
+  DL_REQUIRE(h_in && h_out && pos_out && cu_out && counts && (decision || n_span == 0), "dl_compact_rows_by_mask: NULL pointer");
+  DL_REQUIRE(total > 0 && H > 0 && span0 >= 0 && n_span >= 0 && span0 + n_span <= total, "dl_compact_rows_by_mask: bad span [%d, %d) of %d rows", span0, span0 + n_span, total);
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % Elem<T>::kVec == 0, "dl_compact_rows_by_mask: H=%d must be a multiple of %d", H, Elem<T>::kVec);
+    hipLaunchKernelGGL((compact_rows_by_mask_kernel<T>), dim3((unsigned)total), dim3(256), 0, as_stream(stream), h_in, pos_in, decision, span0, n_span, total, H, h_out,
+                       pos_out, cu_out, counts);
+  });
+  DL_CHECK_LAUNCH("dl_compact_rows_by_mask");
+  return DL_OK;
+}
+
 // ---- device-side prompt layout: one workgroup per row ----
 namespace dl {
 __global__ __launch_bounds__(256) void prompt_layout_kernel(const int64_t* __restrict__ ids, int W, int n_feat, int image_token, int u0, int u1,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "dl_gumbel_hard_keep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
     "dl_kv_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dl_compact_rows_by_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dl_decode_block_sync_bytes": (c_int64, [c_int]),
     "dl_decode_block": (c_int, [POINTER(BlockPhase), c_int, c_void_p, c_int64, c_void_p, c_int, ctypes.c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dl_gemm_smallm_max_m": (c_int, []),
@@ -319,6 +320,22 @@ def compact_tokens(h_in, keep_idx, cu_in, cu_out, img_start, n_img, k, total_out
         "dl_compact_tokens",
     )
     return (h_out, pos) if norm_w is None else (h_out, pos, x_out)
+
+
+def compact_rows_by_mask(h_in, pos_in, decision, span0, n_span):
+    """One packed sequence: rows [span0, span0 + n_span) kept where decision != 0 -> (h_out [total,H] zero past the kept rows, pos int32[total],
+    cu int32[2] = {0, kept}, counts int64[2] = {kept, kept - 1}); nothing is read back."""
+    _dev(h_in, pos_in, decision)
+    assert h_in.is_contiguous() and decision.dtype == torch.int32 and (pos_in is None or pos_in.dtype == torch.int32)
+    total, H = h_in.shape
+    dev = h_in.device
+    h_out = torch.zeros_like(h_in)
+    pos = torch.zeros(total, dtype=torch.int32, device=dev)
+    cu = torch.empty(2, dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    _check(lib().dl_compact_rows_by_mask(_p(h_in), _p(pos_in), _p(decision), int(span0), int(n_span), total, H, _p(h_out), _p(pos), _p(cu), _p(counts), dtype_code(h_in.dtype), _stream()),
+           "dl_compact_rows_by_mask")
+    return h_out, pos, cu, counts
 
 
 def linear(a, w, bias=None, flags=0, residual=None, out=None):

@@ -688,6 +688,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             drop_v = (n_img - k) if vision_on else 0
             p["li"] = (indices[0]["last_instruct"][0] - drop_v, indices[0]["last_instruct"][1] - drop_v)
         p["instruct_drop"] = 0
+        p["instruct_dev"] = None  # device-side {kept rows, last row} of the instruct compaction (generate(): no host copy)
         p["nocache"] = False
         p["nocache_lens"] = None
         lens2 = list(lens)
@@ -754,6 +755,16 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     dec = torch.empty(n_span, dtype=torch.int32, device=dev)
                     lg = torch.empty((n_span, 2), dtype=torch.float32, device=dev)
                     tp.decide(h[li0 : li1 - 1], ops.text_predictor_workspace(n_span, tp.d_model, dev), lg, dec)
+                    if p.get("device_instruct"):
+                        # generate(): the kept count stays on the device.  Every following launch is sized for the UPPER bound (no row
+                        # dropped) and reads the true length from device memory (cu); the rows past it are zeros that nobody consumes.
+                        # Host-visible bookkeeping (the reference shifts its index dicts by the drop count, DML:2365-2375) is internal here.
+                        h, pos, cu, counts = ops.compact_rows_by_mask(h, pos, dec, li0, n_span)
+                        p["instruct_dev"] = counts
+                        continue_host = False
+                    else:
+                        continue_host = True
+                if n_span > 0 and continue_host:
                     keep_rel = torch.nonzero(dec).flatten()
                     idx = torch.cat([torch.arange(0, li0, device=dev), keep_rel + li0, torch.arange(li1 - 1, total, device=dev)])
                     if pos is None:
@@ -824,6 +835,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 x_new = ops.add_rmsnorm(h, F.linear(act, layer.mlp.down_proj.weight), nw_next, eps)
             x = x if nw_next is None else x_new
         cache.lens.copy_(p["lens_dev"])  # layers < SL hold the full prompt, layers >= SL the compacted one
+        if p.get("instruct_dev") is not None:  # device-side instruct compaction (B == 1): kept rows / last row index live on the device
+            cache.lens[1].copy_(p["instruct_dev"][:1])
+            if last_only:
+                x = x.index_select(0, p["instruct_dev"][1:2])
+            return x
         if p["instruct_drop"]:
             cache.lens[1] -= p["instruct_drop"]
         if last_only:
@@ -1370,7 +1386,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._prefill_logits_buf = torch.empty(st.logits.shape, dtype=torch.float32, device=self.device)
         vp = getattr(self.model, "image_score_predictor", None)
         hooked = vp is not None and (len(vp._forward_hooks) or len(vp._forward_pre_hooks))
-        graphable = self.use_hip_graph and self.debug_records is None and not hooked and not self._instruct_on(indices, B)  # data-dependent shapes
+        graphable = self.use_hip_graph and self.debug_records is None and not hooked  # (the instruct predictor's data-dependent row count stays on the device)
         if graphable:
             key = (lay["sig"], None if images is None else tuple(images.shape), None if image_features is None else tuple(image_features.shape),
                    cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new, repr(self.config.sparse_config))
@@ -1381,6 +1397,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 ent = dict(ids=inputs.contiguous().clone(), images=None if images is None else images.to(self.device).clone(),
                            feats=None if image_features is None else image_features.to(self.device).clone(),
                            plan=self._plan_prefill(lens, indices), indices=copy.deepcopy(indices))
+                ent["plan"]["device_instruct"] = True
                 if dev_layout:
                     ent["didx"] = ops.prompt_layout(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
                     ent["plan"]["img_start"] = ent["didx"]["img_start"]  # written by the layout kernel inside the graph

@@ -217,6 +217,14 @@ int dl_kv_pack_rows(void* k_slab0, void* v_slab0, int64_t layer_stride, int n_la
                     int T_cap, const int32_t* keep, const int32_t* kv_len, int B, int n_kv_heads, int T, int head_dim, int dtype,
                     void* stream);
 
+/* ---- prefill compaction of the instruct predictor (DML:2261-2375: `torch.where` on the keep decisions of the last instruct turn + gather/cat)
+ * without a device->host copy.  ONE packed sequence of `total` rows [total, H]; rows [span0, span0 + n_span) survive where decision[j] != 0,
+ * all other rows always.  h_out [total, H] / pos_out [total] receive the kept rows in order (pos_in NULL: the position is the row index);
+ * cu_out int32[2] = {0, kept}; counts int64[2] = {kept, kept - 1} (device-side index of the last row).  Rows past `kept` are left untouched:
+ * the caller keeps sizing its launches for `total` rows and passes cu_out to the kernels that need the true length. */
+int dl_compact_rows_by_mask(const void* h_in, const int32_t* pos_in, const int32_t* decision, int span0, int n_span, int total, int H, void* h_out,
+                            int32_t* pos_out, int32_t* cu_out, int64_t* counts, int dtype, void* stream);
+
 /* ---- device-side prompt layout (replaces the host logic of ARCH:309-490 -- per row `.item()` on the image position ARCH:330-334, the
  * O(n) `torch.equal` scan for "USER:" ARCH:422-428 -- for the common eval case: every row holds exactly ONE image token (-200) and is not
  * padded).  input_ids int64 [B, W].  Outputs (all on the device, nothing is read back):

@@ -631,6 +631,26 @@ def test_kv_pack_rows(ops, dtype, B, nKV, d, T, n_layers):
                     assert torch.equal(got[l, kv, b], slab[l, kv, b])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("total,span0,n_span,H", [(170, 150, 19, 4096), (60, 0, 60, 256), (33, 10, 0, 128), (700, 640, 59, 512), (41, 40, 1, 64)])
+def test_compact_rows_by_mask(ops, dtype, total, span0, n_span, H):
+    """dl_compact_rows_by_mask == nonzero + index_select of the eager instruct-predictor compaction (DML:2261-2375): rows, positions, the
+    device-side counts; all-kept, all-dropped and empty spans."""
+    g = torch.Generator().manual_seed(total)
+    h = torch.randn(total, H, generator=g).to(dtype).cuda()
+    pos = torch.randperm(2 * total, generator=g)[:total].to(torch.int32).cuda()
+    for case in ("random", "all", "none"):
+        dec = {"random": torch.randint(0, 2, (max(n_span, 1),), generator=g), "all": torch.ones(max(n_span, 1)), "none": torch.zeros(max(n_span, 1))}[case].to(torch.int32)[:n_span].cuda()
+        idx = torch.cat([torch.arange(0, span0), torch.nonzero(dec.cpu()).flatten() + span0, torch.arange(span0 + n_span, total)]).cuda()
+        for use_pos in (True, False):
+            dec_arg = dec if n_span > 0 else torch.zeros(1, dtype=torch.int32, device="cuda")
+            h_out, p_out, cu, counts = ops.compact_rows_by_mask(h, pos if use_pos else None, dec_arg, span0, n_span)
+            n = int(idx.numel())
+            assert counts.tolist() == [n, n - 1] and cu.tolist() == [0, n]
+            assert torch.equal(h_out[:n], h.index_select(0, idx)) and not bool(h_out[n:].any())
+            assert torch.equal(p_out[:n], (pos if use_pos else torch.arange(total, dtype=torch.int32, device="cuda")).index_select(0, idx))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("H,I,NQ", [(4096, 11008, 12288), (5120, 13824, 15360), (512, 1536, 1536), (1024, 2816, 1000)])
 def test_decode_block_bit_identical_to_the_gemv_chain(ops, dtype, H, I, NQ):

@@ -330,6 +330,33 @@ def test_instruct_predictor_generate_equals_reference_golden(golden_dir):
         model.generate(ids.repeat(2, 1), images=images.repeat(2, 1, 1, 1), max_new_tokens=2)
 
 
+@pytest.mark.parametrize("name", ["tiny_fp32_instruct", "tiny_bf16_instruct", "tiny_fp32_userprompt"])
+def test_instruct_prefill_is_captured_and_matches_the_eager_path(name, golden_dir):
+    """the instruct predictor's prefill compaction (DML:2261-2375) keeps its data-dependent row count on the device
+    (dl_compact_rows_by_mask), so generate() captures the whole prefill in a hipGraph: graph replay == eager path (host-side nonzero /
+    index_select, one device->host copy) on tokens and KV lengths, and -- fp32 -- == the oracle's greedy continuation."""
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    res = {}
+    for graph in (False, True, True):
+        model.use_hip_graph = graph
+        out = model.generate(ids, images=images, max_new_tokens=8, eos_token_id=None)
+        lens = model.last_cache[1]
+        res.setdefault(graph, []).append((out.cpu(), int(lens[0][0]), int(lens[-1][0]), model.last_prefill_logits.float().cpu().clone()))
+    assert len(model._prefill_graphs) == 1, "the instruct prefill must have been captured"
+    e, g1, g2 = res[False][0], res[True][0], res[True][1]
+    assert torch.equal(g1[0], g2[0]) and g1[1:3] == g2[1:3] and torch.equal(g1[3], g2[3]), "replays differ"
+    assert g1[1:3] == e[1:3], (g1[1:3], e[1:3])
+    if dtype == torch.float32:
+        assert torch.equal(g1[0], e[0])
+        assert float((g1[3] - e[3]).abs().max()) < 1e-3
+        ref, _ = Oracle(cfg, sd, dtype, clip=clip).greedy(ids.cpu(), images=images.cpu(), max_new_tokens=8, eos_token_id=None)
+        assert g1[0].tolist() == ref.tolist()
+
+
 def test_checkpoint_roundtrip_through_load_pretrained_model(tmp_path):
     """dynamic_llava_builder.load_pretrained_model surface: config.json + safetensors with the reference's key names."""
     from dynamic_llava_amd.builder import load_pretrained_model, save_pretrained
