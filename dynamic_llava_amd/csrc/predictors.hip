@@ -271,7 +271,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void decode_advance_kernel(const void* __restrict__ logits, int64_t row_stride, int V,
                                                                int64_t* __restrict__ next_ids, int64_t* __restrict__ out_ids, int out_cap,
                                                                int32_t* __restrict__ step, int32_t* __restrict__ finished, int eos_id,
-                                                               int pad_id, int32_t* __restrict__ kv_len_full,
+                                                               int eos_id2, int eos_id3, int pad_id, int32_t* __restrict__ kv_len_full,
                                                                int32_t* __restrict__ kv_len_sparse, const int32_t* __restrict__ decision,
                                                                int min_new_tokens) {
   constexpr int VE = Elem<T>::kVec;
@@ -290,7 +290,9 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const void* __rest
   const S* row = reinterpret_cast<const S*>(logits) + (int64_t)b * row_stride;
   const bool vec_ok = (row_stride % VE == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
   // HF MinNewTokensLengthLogitsProcessor: the EOS logit is -inf while fewer than min_new_tokens tokens exist (uniform per row)
-  const int banned = (eos_id >= 0 && min_new_tokens > 0 && (step ? step[b] : 0) < min_new_tokens) ? eos_id : -1;
+  // (all EOS ids of the set: eos_id2 / eos_id3 are -1 when unused, and no vocabulary index is negative)
+  const bool ban = eos_id >= 0 && min_new_tokens > 0 && (step ? step[b] : 0) < min_new_tokens;
+  const int banned = ban ? eos_id : -1, banned2 = ban ? eos_id2 : -1, banned3 = ban ? eos_id3 : -1;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   const int n_chunks = V / VE;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const void* __rest
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             const int v = c * VE + e;
-            if (v == banned) continue;
+            if (v == banned || v == banned2 || v == banned3) continue;
             if (x[u][e] > best || (x[u][e] == best && v < bi)) {
               best = x[u][e];
               bi = v;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const void* __rest
   }
   for (int v = (vec_ok ? n_chunks * VE : 0) + tid; v < V; v += 1024) {  // tail (or the whole row when it is not 16-byte addressable)
     const float xv = load1<T>(logits, (int64_t)b * row_stride + v);
-    if (v == banned) continue;
+    if (v == banned || v == banned2 || v == banned3) continue;
     if (xv > best || (xv == best && v < bi)) {
       best = xv;
       bi = v;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(1024) void decode_advance_kernel(const void* __rest
     int tok = bi;
     if (finished) {
       if (st_fin) tok = pad_id;
-      else if (eos_id >= 0 && tok == eos_id) finished[b] = 1;
+      else if (eos_id >= 0 && (tok == eos_id || tok == eos_id2 || tok == eos_id3)) finished[b] = 1;
     }
     next_ids[b] = tok;
     if (out_ids && step) {
@@ -477,7 +479,7 @@ extern "C" int dl_text_predictor_decide(const void* x, int64_t x_row_stride, int
 }
 
 extern "C" int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_stride, int V, int B, int64_t* next_ids,
-                                 int64_t* out_ids, int out_cap, int32_t* step, int32_t* finished, int eos_id, int pad_id,
+                                 int64_t* out_ids, int out_cap, int32_t* step, int32_t* finished, int eos_id, int eos_id2, int eos_id3, int pad_id,
                                  int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision, int min_new_tokens,
                                  void* stream) {
   DL_REQUIRE(logits && next_ids, "dl_decode_advance: NULL pointer");
@@ -485,7 +487,7 @@ extern "C" int dl_decode_advance(const void* logits, int logits_dtype, int64_t l
   hipStream_t st = as_stream(stream);
   DL_DISPATCH_DTYPE(logits_dtype, T, {
     hipLaunchKernelGGL((decode_advance_kernel<T>), dim3((unsigned)B), dim3(1024), 0, st, logits, logits_row_stride, V, next_ids, out_ids,
-                       out_cap, step, finished, eos_id, pad_id, kv_len_full, kv_len_sparse, decision, min_new_tokens);
+                       out_cap, step, finished, eos_id, eos_id >= 0 ? eos_id2 : -1, eos_id >= 0 ? eos_id3 : -1, pad_id, kv_len_full, kv_len_sparse, decision, min_new_tokens);
   });
   DL_CHECK_LAUNCH("dl_decode_advance");
   return DL_OK;

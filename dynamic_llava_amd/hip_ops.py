@@ -114,7 +114,7 @@ SIGNATURES = {
     "dl_quick_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+        [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     ),
 }
 
@@ -444,13 +444,18 @@ def gemv(w, y, x=None, mode=GEMV_PLAIN, h_in=None, h_out=None, delta=None, norm_
 
 
 def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos_id=-1, pad_id=0, kv_len_full=None, kv_len_sparse=None, decision=None, min_new_tokens=0):
+    """eos_id: -1 (none), one id, or a sequence of up to three ids (the EOS set)."""
     _dev(logits, next_ids)
+    eos = [int(e) for e in eos_id] if isinstance(eos_id, (list, tuple)) else [int(eos_id)]
+    if len(eos) > 3:
+        raise HipOpsError("dl_decode_advance compares at most three eos ids on the device")
+    eos = (eos + [-1, -1, -1])[:3]
     assert logits.dim() == 2 and logits.stride(1) == 1 and next_ids.dtype == torch.int64
     B, V = logits.shape
     out_cap = out_ids.shape[1] if out_ids is not None else 0
     _check(
         lib().dl_decode_advance(
-            _p(logits), dtype_code(logits.dtype), logits.stride(0), V, B, _p(next_ids), _p(out_ids), out_cap, _p(step), _p(finished), int(eos_id), int(pad_id),
+            _p(logits), dtype_code(logits.dtype), logits.stride(0), V, B, _p(next_ids), _p(out_ids), out_cap, _p(step), _p(finished), eos[0], eos[1], eos[2], int(pad_id),
             _p(kv_len_full), _p(kv_len_sparse), _p(decision), int(min_new_tokens), _stream(),
         ),
         "dl_decode_advance",

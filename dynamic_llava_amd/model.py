@@ -1251,8 +1251,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         built instead of silently ignoring it."""
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
-        if kwargs.get("past_key_values") is not None:
-            raise NotImplementedError("generate(past_key_values=...) is not built: drive multi-round dialogue through forward() (BLTM:326-337)")
         if (kwargs.get("num_beams", 1) or 1) != 1:
             raise NotImplementedError("beam search is not built (harness default num_beams=1)")
         max_new = kwargs.get("max_new_tokens")
@@ -1327,6 +1325,55 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return seq
 
     @torch.no_grad()
+    def _generate_on_cache(self, inputs, images, **kwargs):
+        """generate(new_ids, past_key_values=cache): greedy continuation of a dialogue whose earlier turns (image included) are in `cache` (what
+        a previous call returned: `return_dict_in_generate=True`, or forward()).  `inputs` holds ONLY the new turn's token ids [B, T] -- with
+        the image placeholder of the first turn the reference's `input_ids[:, past_length:]` slicing (DML:2831-2853) has no consistent meaning,
+        and its own multi-round harness drives forward() (model_lvis_multi_round_for_ppl.py:108-220).  The new chunk goes through the
+        chunk-on-cache path (DML:2506-2521: the instruct predictor decides which of its K/V rows stay in layers >= sparse_layer), the new
+        tokens through single decode steps; plain loop over forward(), no hipGraph."""
+        if images is not None or kwargs.get("image_features") is not None:
+            raise NotImplementedError("generate(past_key_values=...) continues a dialogue: the image belongs to the first call")
+        cache = kwargs["past_key_values"]
+        if not isinstance(cache, KVSlabCache):
+            cache = KVSlabCache.from_legacy_cache(cache, self.config.sparse_config["sparse_layer"], device=self.device)
+        inputs = inputs.to(self.device)
+        if inputs.shape[0] != cache.batch:
+            raise ValueError(f"{inputs.shape[0]} rows of new tokens for a cache of {cache.batch} rows")
+        max_new, min_new, eos, pad = self._gen_kwargs({k: v for k, v in kwargs.items() if k != "past_key_values"}, [0])
+        eos_set = [] if eos is None else (eos if isinstance(eos, list) else [eos])
+        out = self.forward(inputs, attention_mask=kwargs.get("attention_mask"), past_key_values=cache)
+        cache = out.past_key_values
+        logits = out.logits[:, -1].float()
+        self.last_prefill_logits = logits.clone()
+        finished = torch.zeros(inputs.shape[0], dtype=torch.bool, device=self.device)
+        toks, scores = [], []
+        for step in range(max_new):
+            z = logits.clone()
+            if step < min_new and eos_set:
+                z[:, eos_set] = float("-inf")
+            scores.append(z)
+            nxt = z.argmax(dim=-1)
+            nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
+            toks.append(nxt)
+            for e in eos_set:
+                finished = finished | (nxt == e)
+            if eos_set and bool(finished.all()):
+                break
+            if step + 1 < max_new:
+                out = self.forward(nxt[:, None], past_key_values=cache)
+                cache = out.past_key_values
+                logits = out.logits[:, -1].float()
+        seq = torch.stack(toks, dim=1)
+        self.last_cache = cache
+        if kwargs.get("return_dict_in_generate"):
+            res = {"sequences": seq, "past_key_values": cache}
+            if kwargs.get("output_scores"):
+                res["scores"] = tuple(scores)
+            return res
+        return seq
+
+    @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, **kwargs):
         """dynamic_llava_llama.py:117-152: greedy decoding; returns the NEW tokens only [B, T_new] (HF behaviour when
         generation is driven by inputs_embeds).  Supported kwargs: max_new_tokens / max_length, min_new_tokens (EOS banned from
@@ -1341,6 +1388,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if "inputs_embeds" in kwargs:
                 raise NotImplementedError("`inputs_embeds` is not supported")  # DLL:128-129
             return self._generate_sample(inputs, images, **kwargs)
+        if kwargs.get("past_key_values") is not None:
+            return self._generate_on_cache(inputs, images, **kwargs)
         attention_mask = kwargs.get("attention_mask")
         image_features = kwargs.get("image_features")
         sync_every = int(kwargs.get("sync_every", 16))
@@ -1367,8 +1416,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             lay = self._layout(inputs, attention_mask, None, n_feat)
         lens, indices, B = lay["lens"], lay["indices"], lay["B"]
         max_new, min_new, eos, pad = self._gen_kwargs(kwargs, lens)
-        if isinstance(eos, list):
-            raise NotImplementedError("several eos_token_ids on the greedy device path (one id is compared on the device)")
+        if isinstance(eos, list) and len(eos) > 3:
+            raise NotImplementedError("more than three eos_token_ids on the greedy device path (three ids are compared on the device)")
         cache = self._pooled_cache(B, max(lens) + max_new + 1)
         self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)
@@ -1379,7 +1428,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         st.attn_ws.zero_()
         if st.blk_sync is not None:
             st.blk_sync.zero_()  # same rule for the granules of dl_decode_block
-        self._eos = -1 if eos is None else eos
+        self._eos = -1 if eos is None else (tuple(eos) if isinstance(eos, list) else eos)  # one id or a tuple of up to three (the EOS set)
         self._pad = pad
         self._min_new = min_new
         if getattr(self, "_prefill_logits_buf", None) is None or self._prefill_logits_buf.shape != st.logits.shape:
@@ -1431,10 +1480,12 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.last_prefill_logits = self._prefill_logits_buf
         scores = []
 
+        eos_ids = [] if self._eos == -1 else (list(self._eos) if isinstance(self._eos, tuple) else [self._eos])
+
         def _score(step_idx):  # HF `scores`: the processed logits of that step (EOS at -inf while step < min_new_tokens)
             z = (self._prefill_logits_buf if step_idx == 0 else st.logits).float().clone()
-            if step_idx < min_new and self._eos >= 0:
-                z[:, self._eos] = float("-inf")
+            if step_idx < min_new and eos_ids:
+                z[:, eos_ids] = float("-inf")
             scores.append(z)
 
         if want_scores:
@@ -1447,7 +1498,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             produced += n
             if want_scores:
                 _score(produced - 1)
-            if self._eos >= 0 and produced < max_new and bool(st.finished.min().item()):
+            if eos_ids and produced < max_new and bool(st.finished.min().item()):
                 break
         if B == 1:
             self.check_block_decode()
@@ -1460,8 +1511,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cache.full_len_host = [n + produced - 1 for n in cache.full_len_host]
         cache.seen_tokens += produced - 1
         out = st.out_ids[:, :produced].clone()
-        if self._eos >= 0:  # HF stops as soon as every row has emitted EOS: trim the columns produced after that
-            fin = (out == self._eos).int().cumsum(dim=1).clamp(max=1)
+        if eos_ids:  # HF stops as soon as every row has emitted EOS: trim the columns produced after that
+            hit = out == eos_ids[0]
+            for e_ in eos_ids[1:]:
+                hit = hit | (out == e_)
+            fin = hit.int().cumsum(dim=1).clamp(max=1)
             all_done = fin.min(dim=0).values
             if bool(all_done.any().item()):
                 first = int(torch.argmax(all_done).item())

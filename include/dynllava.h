@@ -273,10 +273,11 @@ int dl_decode_block(const dl_block_phase* phases, int n_phases, void* sync_buf, 
  * out_ids[b, step[b]] = next[b]; ++step[b]; kv_len_full[b] += 1; kv_len_sparse[b] += decision ? decision[b] : 1.
  * logits: [B,V] in `logits_dtype` (DL_F32 or the model dtype).  step/finished: int32[B].  All state lives on
  * the device; out_ids / step / finished / kv_len_* / decision may be NULL to skip that piece of bookkeeping.
- * min_new_tokens > 0: eos_id is excluded from the argmax while step[b] < min_new_tokens (HF MinNewTokensLengthLogitsProcessor). */
+ * eos_id (-1: none), eos_id2, eos_id3 (-1: unused): the EOS set (HF accepts a list of ids).
+ * min_new_tokens > 0: the EOS ids are excluded from the argmax while step[b] < min_new_tokens (HF MinNewTokensLengthLogitsProcessor). */
 int dl_decode_advance(const void* logits, int logits_dtype, int64_t logits_row_stride, int V, int B,
                       int64_t* next_ids, int64_t* out_ids, int out_cap, int32_t* step, int32_t* finished,
-                      int eos_id, int pad_id, int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision,
+                      int eos_id, int eos_id2, int eos_id3, int pad_id, int32_t* kv_len_full, int32_t* kv_len_sparse, const int32_t* decision,
                       int min_new_tokens, void* stream);
 
 /* ---- decode GEMM for 5..32 rows: Y[M,N] = X[M,K] @ W[N,K]^T (nn.Linear without bias: DML:1011-1013, 1127, 328, 2709), M <=

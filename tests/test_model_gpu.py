@@ -448,6 +448,60 @@ def test_multiround_chunks_on_cache_vs_reference_golden(name, golden_dir):
             np.testing.assert_array_equal(model.debug_records["text_decision"].cpu().numpy(), g[f"decision_{j}"])
 
 
+@pytest.mark.parametrize("name", ["tiny_fp32_multiround", "tiny_fp32_chunked"])
+def test_generate_continues_on_a_returned_cache_vs_oracle(name):
+    """generate(new_turn_ids, past_key_values=cache): the second turn of a dialogue on the cache the first generate() returned (the new chunk
+    through the chunk-on-cache path DML:2506-2521, then greedy steps) against the oracle driving the reference's own forward() loop."""
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    model = _build(cfg, sd, clip, dtype)
+    ids = fx.make_prompt(cfg, 5, 9, seed=0)[None]
+    images = fx.make_images(cfg, 1, seed=0).to(dtype)
+    turn2 = torch.randint(3, cfg.vocab_size, (1, 7), generator=torch.Generator().manual_seed(12))
+    r1 = model.generate(ids.cuda(), images=images.cuda(), max_new_tokens=4, eos_token_id=None, return_dict_in_generate=True)
+    out2 = model.generate(turn2.cuda(), past_key_values=r1["past_key_values"], max_new_tokens=5, eos_token_id=None)
+    o = Oracle(cfg, sd, dtype, clip=clip)
+    t1, pkv = o.greedy(ids, images=images, max_new_tokens=4, eos_token_id=None)
+    assert r1["sequences"].cpu().tolist() == t1.tolist()
+    with torch.no_grad():
+        logits, pkv = o.forward(turn2, past_key_values=pkv)
+        ref = []
+        for step in range(5):
+            nxt = logits[:, -1].argmax(-1)
+            ref.append(int(nxt[0]))
+            if step < 4:
+                logits, pkv = o.forward(nxt[:, None], past_key_values=pkv)
+    assert out2.cpu().tolist() == [ref]
+    lens = model.last_cache[1]
+    assert int(lens[0][0]) == int(pkv[1][0][0]) and int(lens[-1][0]) == int(pkv[1][-1][0])
+    with pytest.raises(NotImplementedError):
+        model.generate(turn2.cuda(), images=images.cuda(), past_key_values=model.last_cache, max_new_tokens=2)
+
+
+def test_generate_with_a_set_of_eos_ids(golden_dir):
+    """HF accepts a list of eos_token_ids: the greedy device path compares up to three ids (dl_decode_advance), bans all of them while
+    fewer than min_new_tokens tokens exist, and stops / trims at the first hit of any."""
+    name = "tiny_fp32_b1_greedy"
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    gold = [int(t) for t in g["ids"][:, 0]]
+    n = len(gold)
+    never = max(gold) + 1 if max(gold) + 1 < cfg.vocab_size else 0
+    assert never not in gold
+    for graph in (False, True):
+        model.use_hip_graph = graph
+        out = model.generate(ids, images=images, max_new_tokens=n, eos_token_id=[never, gold[3], gold[5]])
+        first = min(gold.index(gold[3]), gold.index(gold[5]))
+        assert out.cpu().tolist()[0] == gold[: first + 1], graph
+        # min_new_tokens bans the whole set: the run must go past position `first`
+        out = model.generate(ids, images=images, max_new_tokens=n, min_new_tokens=first + 2, eos_token_id=[gold[3], gold[5]])
+        assert out.shape[1] > first + 1 and gold[3] not in out.cpu().tolist()[0][: first + 2] and gold[5] not in out.cpu().tolist()[0][: first + 2]
+    with pytest.raises(NotImplementedError):
+        model.generate(ids, images=images, max_new_tokens=2, eos_token_id=[1, 2, 3, 4])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_clip_tower_packed_path_matches_eager_module(dtype):
     """the CLIP ViT-L/14-336 tower on the packed HIP path (dl_layernorm / dl_add_layernorm / dl_attn_prefill /
