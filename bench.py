@@ -403,8 +403,12 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
         ids_r, lg_r = all_ids[r * per:(r + 1) * per], all_lg[r * per:(r + 1) * per]
         ok = bool(torch.equal(ids_r, o2) and torch.equal(lg_r, l2))
         detail = {"rows_with_different_ids": int((ids_r != o2).any(dim=1).sum()), "max_abs_prefill_logit_diff": float((lg_r - l2).abs().max())}
-        if detail["rows_with_different_ids"]:
-            raise SystemExit(f"configs[3]: rank {r}'s gathered rows differ from rank 0's re-run of the same chunk: {detail}")
+        if detail["rows_with_different_ids"] and detail["max_abs_prefill_logit_diff"] == 0.0:
+            # identical prefill (every K/V row of every layer feeds those logits) but different tokens: the DECODE diverged between two devices
+            # running the same kernels on the same data -- a bug (round 3's packed-fp32 anomaly looked exactly like this), never a rounding matter
+            raise SystemExit(f"configs[3]: rank {r}'s gathered rows differ from rank 0's re-run of the same chunk after a bit-identical prefill: {detail}")
+        # a last-bit difference of the prefill logits (another device's library GEMM picked another kernel) can legitimately flip a near-tied
+        # argmax later: reported in rerun_detail, not fatal
     n_tok_all = sum(35 + 576 + q for q in n_q) + n_req * new_tokens
     return {"workload": f"BASELINE configs[3]: {n_req} ragged requests ({per} per rank, question lengths ~U[8,64]), {new_tokens} new tokens each, one all-gather",
             "tokens_per_s": round(n_tok_all / el, 1), "seconds": round(el, 4), "gathered_rows": int(all_ids.shape[0]), "dp_equals_rerun_of_last_rank": ok,
