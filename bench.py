@@ -128,7 +128,7 @@ def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim):
     def launch():
         i = it[0] = (it[0] + 1) % n_buf
         tagc[0] = (tagc[0] + 1) % 251  # as in the decode step: consecutive launches sharing the workspace carry different call tags
-        ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, ws, n_splits, n_heads, n_heads, head_dim, call_tag=tagc[0])
+        ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, ws, n_splits, n_heads, n_heads, head_dim, chunk_keys=KVSlabCache.spec_chunk(n_splits), call_tag=tagc[0])
 
     ms = graph_time_ms(launch)
     nbytes = sum(2 * t * H * 2 + 2 * H * 2 for t in T_list)

@@ -169,8 +169,25 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
   for (int i = 0; i < V; ++i) o[i] = 0.f;
 
   // keys of this workgroup are dealt round-robin: key = base + (u * NW + wid) * KPW + g
+  // the rows of trip i + 1 are requested before trip i is consumed (U <= 4: the registers are there): a row of T keys is a chain of
+  // T / (NG U) trips, and without this every trip paid a full memory round trip (the longest row of a ragged batch sets the launch time)
+  constexpr bool kPrefetch = U <= 4;
+  uint4 kpre[kPrefetch ? U : 1], vpre[kPrefetch ? U : 1];
+  bool okpre[kPrefetch ? U : 1];
   for (int base = s.k0; base < s.k1; base += NG * U) {
-    if (base != s.k0) {
+    if constexpr (kPrefetch) {
+      const int nbase = base + NG * U;
+      if (nbase < s.k1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int key = nbase + (u * NW + wid) * KPW + g;
+          okpre[u] = key < s.k1;
+          const int64_t off = (int64_t)(okpre[u] ? key : s.k0) * D;
+          kpre[u] = *reinterpret_cast<const uint4*>(s.kb + off);
+          vpre[u] = *reinterpret_cast<const uint4*>(s.vb + off);
+        }
+      }
+    } else if (base != s.k0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int key = base + (u * NW + wid) * KPW + g;
@@ -209,6 +226,16 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
         for (int i = 0; i < V; ++i) o[i] += s.ok[u] ? p * vx[i] : 0.f;  // a speculatively read slot past the length may hold NaN bits
       }
       m = mn;
+    }
+    if constexpr (kPrefetch) {
+      if (base + NG * U < s.k1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          s.kraw[u] = kpre[u];
+          s.vraw[u] = vpre[u];
+          s.ok[u] = okpre[u];
+        }
+      }
     }
   }
 
