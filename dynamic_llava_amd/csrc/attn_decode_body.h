@@ -35,6 +35,13 @@ __device__ __forceinline__ float lpk_sum(float a) {
   }
 }
 
+// K/V rows are read once per decode step: non-temporal (the weight streams' policy), so that they do not displace what the step re-reads
+__device__ __forceinline__ uint4 kv_ld16(const void* p) {
+  typedef uint32_t kv_u32x4_t __attribute__((ext_vector_type(4)));
+  const kv_u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const kv_u32x4_t*>(p));
+  return make_uint4(r.x, r.y, r.z, r.w);
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack_kv(const uint4& r, float (&f)[Elem<T>::kVec]) {
   if constexpr (Elem<T>::kVec == 4) {
@@ -97,8 +104,8 @@ __device__ __forceinline__ void attn_split_issue(AttnSplitState<T, D, NW, U>& s,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int key = min(s.k0 + (u * NW + s.wid) * KPW + s.g, T_cap - 1);
-      s.kraw[u] = *reinterpret_cast<const uint4*>(s.kb + (int64_t)key * D);
-      s.vraw[u] = *reinterpret_cast<const uint4*>(s.vb + (int64_t)key * D);
+      s.kraw[u] = kv_ld16(s.kb + (int64_t)key * D);
+      s.vraw[u] = kv_ld16(s.vb + (int64_t)key * D);
     }
   }
   s.Tn = T_old + (FUSED ? 1 : extra);
@@ -116,8 +123,8 @@ __device__ __forceinline__ void attn_split_issue(AttnSplitState<T, D, NW, U>& s,
     s.ok[u] = key < s.k1;
     if (!s.spec) {
       const int64_t off = (int64_t)(s.ok[u] ? key : (s.k0 < s.k1 ? s.k0 : 0)) * D;
-      s.kraw[u] = *reinterpret_cast<const uint4*>(s.kb + off);
-      s.vraw[u] = *reinterpret_cast<const uint4*>(s.vb + off);
+      s.kraw[u] = kv_ld16(s.kb + off);
+      s.vraw[u] = kv_ld16(s.vb + off);
     }
   }
 }
@@ -183,8 +190,8 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
           const int key = nbase + (u * NW + wid) * KPW + g;
           okpre[u] = key < s.k1;
           const int64_t off = (int64_t)(okpre[u] ? key : s.k0) * D;
-          kpre[u] = *reinterpret_cast<const uint4*>(s.kb + off);
-          vpre[u] = *reinterpret_cast<const uint4*>(s.vb + off);
+          kpre[u] = kv_ld16(s.kb + off);
+          vpre[u] = kv_ld16(s.vb + off);
         }
       }
     } else if (base != s.k0) {
@@ -193,8 +200,8 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
         const int key = base + (u * NW + wid) * KPW + g;
         s.ok[u] = key < s.k1;
         const int64_t off = (int64_t)(s.ok[u] ? key : s.k0) * D;
-        s.kraw[u] = *reinterpret_cast<const uint4*>(s.kb + off);
-        s.vraw[u] = *reinterpret_cast<const uint4*>(s.vb + off);
+        s.kraw[u] = kv_ld16(s.kb + off);
+        s.vraw[u] = kv_ld16(s.vb + off);
       }
     }
     float sc[U];
