@@ -25,6 +25,13 @@ __device__ __forceinline__ f32x4_t mfma16_lin<f16_t>(const uint4& a, const uint4
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+// weights of the split-K kernels are read once, by one workgroup: non-temporal like every other weight stream here
+__device__ __forceinline__ uint4 lin_ldg_nt(const void* p) {
+  typedef uint32_t lin_u32x4_t __attribute__((ext_vector_type(4)));
+  const lin_u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const lin_u32x4_t*>(p));
+  return make_uint4(r.x, r.y, r.z, r.w);
+}
+
 constexpr int kTM = 64, kTN = 64;
 
 template <typename T>
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256) void linear_splitk_wide_kernel(const void* __r
       const int idx = it * 256 + tid;
       const int r = idx / CPR, ch = (idx % CPR) * 8;
       w4[it] = make_uint4(0, 0, 0, 0);
-      if (n0 + r < N && k0 + ch < K) w4[it] = *reinterpret_cast<const uint4*>(W + (int64_t)(n0 + r) * K + k0 + ch);
+      if (n0 + r < N && k0 + ch < K) w4[it] = lin_ldg_nt(W + (int64_t)(n0 + r) * K + k0 + ch);
     }
   };
   if (s0 < s1) fetch(s0 * kTK);

@@ -439,6 +439,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # 4.24 ms per step at B = 4 / 8 / 16 against 5.1-5.3 on the library; a wash at 20-24 (4.64 / 4.80 vs 4.66 / 4.75) where the hand-written
         # path is kept for being deterministic and batch-invariant; 4 % behind at 32 (5.09 vs 4.89)
         self.smallm_max_decode_batch = 24
+        # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
+        # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
+        self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
         if os.environ.get("DL_SMALLM_MAX_B"):  # tuning experiments only
             self.smallm_max_decode_batch = int(os.environ["DL_SMALLM_MAX_B"])
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
@@ -822,8 +825,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
             attn = torch.empty((total, nH * d), dtype=dt, device=dev)
             ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : (nH + nKV) * d], qkv[:, (nH + nKV) * d :], attn, cu, max_len, nH, nKV, d, True)
-            o = F.linear(attn, layer.self_attn.o_proj.weight)
-            x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
+            if self.splitk_o_proj and dt in (torch.bfloat16, torch.float16) and attn.shape[0] <= 192 and attn.shape[1] >= 1024 and attn.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
+                x = ops.add_rmsnorm_parts(h, ops.linear_splitk(attn, layer.self_attn.o_proj.weight, self._splitk_ws(h.shape[1]), 8), layer.post_attention_layernorm.weight, eps)
+            else:
+                o = F.linear(attn, layer.self_attn.o_proj.weight)
+                x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
             act = ops.silu_mul(F.linear(x, layer.w_gu))
             nw_next = self.model.norm.weight if i + 1 == L else (None if i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"])  # residual add only: layer SL's norm runs after compaction
                                                                else self.model.layers[i + 1].input_layernorm.weight)
