@@ -115,7 +115,7 @@ def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim):
     out = torch.empty((B, H), device=dev, dtype=dt)
     lens = torch.tensor([t - 1 for t in T_list], dtype=torch.int32, device=dev)
     cos, sin = model._rope_tables(T_cap + 1)
-    n_splits = max(1, min(32, max(1, 256 // (B * n_heads)), -(-T_cap // 64)))  # same rule as KVSlabCache.n_splits
+    n_splits = 1 if T_cap <= 256 else max(1, min(32, max(1, 256 // (B * n_heads)), -(-T_cap // 64)))  # same rule as KVSlabCache.n_splits
     ws = ops.attn_decode_workspace(B, n_heads, head_dim, 32, dev)
     # rotate over several slabs so that, as in the real decode step (13 GB of weights streamed in between), K/V come from HBM
     n_buf = 8 if k.numel() * 4 < 200e6 else 1
