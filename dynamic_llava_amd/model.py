@@ -956,7 +956,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
             # only when the row is long enough to need more than one workgroup per head)
             ns = cache.n_splits(i, st.B * nH)
-            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, chunk_keys=cache.spec_chunk(ns),
+            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
                                  call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
             if block:
                 # o_proj -> gate|up -> down -> next layer's q|k|v (lm_head after the last layer) in one launch; the residual stream goes
@@ -1002,7 +1002,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             lens = cache.len_of_layer(i)
             qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws) if sm else F.linear(st.x, layer.w_qkv)
             ns = cache.n_splits(i, st.B * nH)
-            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, chunk_keys=cache.spec_chunk(ns),
+            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
                                  call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             if sm:

@@ -99,8 +99,9 @@ int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k_slab, cons
  * slot kv_len[b] (CU:109-268) and the ragged attention over keys [0, kv_len[b]] (DML:1061-1122).
  * qkv: [B, qkv_row_stride] UN-rotated projection output (q heads | k heads | v heads), not modified.
  * pos_base[b]: RoPE position of the new token.  Same split-KV scheme as dl_attn_decode.
- * keys_in_flight = 64 or 256: K/V rows a workgroup requests per loop trip (256 = one HBM round trip for a 256-key split:
- * the batch-1 decode step is latency-bound).  chunk_keys > 0: split s owns keys [s*chunk_keys, (s+1)*chunk_keys) (the last
+ * keys_in_flight = 64, 128 or 256: K/V rows a workgroup requests per loop trip (64 / 256: four waves x 4 / 16 rows per lane group; 128: eight
+ * waves x 4 -- the form small single-split launches use; the batch-1 decode step is latency-bound).  The rows of trip i + 1 are requested
+ * before trip i is consumed; K/V rows are loaded non-temporal.  chunk_keys > 0: split s owns keys [s*chunk_keys, (s+1)*chunk_keys) (the last
  * split also takes any remainder), so the K/V rows are requested before kv_len[b] has been read; 0: the kernel balances
  * ceil((kv_len[b]+1) / n_splits) keys per split itself.  Results are identical either way up to the merge order.
  * call_tag >= 0 (with keys_in_flight = 64, chunk_keys = 0, n_splits > 1 and a grid of <= 1024 workgroups): the splits are merged

@@ -47,11 +47,11 @@ for B, Ts in [(1, [226]), (1, [695]), (1, [2048]), (4, [226] * 4), (32, [200 + (
             ops.rope_kv_write(qkv, cos, sin, cu, None, lens, lens, ks[i], vs[i], nH, nH, d)
             ops.attn_decode(qkv[:, :H], ks[i], vs[i], lens, 1, out, ws, ns, nH, nH, d)
         res.append(("rope+attn4", ns, timed(unfused)))
-        for kif, chunk in ((64, 0), (64, 256), (256, 256)):
+        for kif, chunk in ((64, 0), (64, 256), (128, 256), (256, 256)):
             def fused():
                 i = it[0] = (it[0] + 1) % n_buf
                 ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, ws, ns, nH, nH, d, keys_in_flight=kif, chunk_keys=chunk)
             res.append((f"fused{kif}/{chunk}", ns, timed(fused)))
     print(f"B={B} T={Ts[0]}.. bytes={nbytes/1e6:.1f}MB")
-    for name in ("rope+attn4", "fused64/0", "fused64/256", "fused256/256"):
+    for name in ("rope+attn4", "fused64/0", "fused64/256", "fused128/256", "fused256/256"):
         print(f"   {name:13s} " + "  ".join(f"ns={ns}:{us:6.2f}us" for n, ns, us in res if n == name))
