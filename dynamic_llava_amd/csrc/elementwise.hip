@@ -6,7 +6,8 @@
 namespace dl {
 
 constexpr int kThreads = 256;
-constexpr int kMaxVecPerThread = 8;  // H <= 256 * 8 * kVec  (16384 for 2-byte types, 8192 for fp32)
+constexpr int kMaxVecPerThread = 8;
+constexpr int kPartsBatch = 8;  // split-K slices whose loads are in flight together in the consumers of fp32 partials  // H <= 256 * 8 * kVec  (16384 for 2-byte types, 8192 for fp32)
 
 // ---- RMSNorm: DML:134-139.  ADD: h = cast(h + delta) first (DML:1289/1295), written back. ----
 // ADD = 2: delta = cast(sum_s parts[s, row, :]) -- the fp32 split-K partials of dl_gemm_smallm(defer_reduce), summed in slice order.
@@ -40,15 +41,26 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_
         float d[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) d[j] = 0.f;
-        for (int s = 0; s < n_slices; ++s) {
+        // all slices of a batch are requested before the first is added (a rolled load -> add loop paid one memory round trip per slice:
+        // 10 us per launch at 8 slices); the additions stay in slice order
+        for (int s0 = 0; s0 < n_slices; s0 += kPartsBatch) {
+          float4 pv[kPartsBatch][V / 4];
 #pragma unroll
-          for (int q = 0; q < V / 4; ++q) {
-            const float4 p = *reinterpret_cast<const float4*>(parts + s * slice_stride + v * V + q * 4);
-            d[q * 4] += p.x;
-            d[q * 4 + 1] += p.y;
-            d[q * 4 + 2] += p.z;
-            d[q * 4 + 3] += p.w;
-          }
+          for (int s = 0; s < kPartsBatch; ++s)
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q)
+              pv[s][q] = *reinterpret_cast<const float4*>(parts + (s0 + s < n_slices ? s0 + s : s0) * slice_stride + v * V + q * 4);
+#pragma unroll
+          for (int s = 0; s < kPartsBatch; ++s)
+            if (s0 + s < n_slices) {
+#pragma unroll
+              for (int q = 0; q < V / 4; ++q) {
+                d[q * 4] += pv[s][q].x;
+                d[q * 4 + 1] += pv[s][q].y;
+                d[q * 4 + 2] += pv[s][q].z;
+                d[q * 4 + 3] += pv[s][q].w;
+              }
+            }
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + Elem<T>::round(d[j]));
@@ -198,11 +210,20 @@ __global__ __launch_bounds__(kThreads) void silu_mul_parts_kernel(const float* _
     const int64_t r = idx / q_per_row;
     const int c = (int)(idx - r * q_per_row) * 4;
     float g[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n_slices; ++s) {
-      const float4 pg = *reinterpret_cast<const float4*>(parts + s * slice_stride + r * 2 * I + c);
-      const float4 pu = *reinterpret_cast<const float4*>(parts + s * slice_stride + r * 2 * I + I + c);
-      g[0] += pg.x; g[1] += pg.y; g[2] += pg.z; g[3] += pg.w;
-      u[0] += pu.x; u[1] += pu.y; u[2] += pu.z; u[3] += pu.w;
+    for (int s0 = 0; s0 < n_slices; s0 += kPartsBatch) {  // loads of a batch of slices first, additions in slice order
+      float4 pg[kPartsBatch], pu[kPartsBatch];
+#pragma unroll
+      for (int s = 0; s < kPartsBatch; ++s) {
+        const int64_t so = (int64_t)(s0 + s < n_slices ? s0 + s : s0) * slice_stride;
+        pg[s] = *reinterpret_cast<const float4*>(parts + so + r * 2 * I + c);
+        pu[s] = *reinterpret_cast<const float4*>(parts + so + r * 2 * I + I + c);
+      }
+#pragma unroll
+      for (int s = 0; s < kPartsBatch; ++s)
+        if (s0 + s < n_slices) {
+          g[0] += pg[s].x; g[1] += pg[s].y; g[2] += pg[s].z; g[3] += pg[s].w;
+          u[0] += pu[s].x; u[1] += pu[s].y; u[2] += pu[s].z; u[3] += pu[s].w;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
