@@ -257,12 +257,18 @@ __global__ __launch_bounds__(256) void gemm_smallm_reduce_kernel(const float* __
     const int64_t m = idx / (N / 4);
     const int n = (int)(idx - m * (N / 4)) * 4;
     float4 s = *reinterpret_cast<const float4*>(part + m * N + n);
-    for (int k = 1; k < n_slices; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)k * M + m) * N + n);
-      s.x += v.x;
-      s.y += v.y;
-      s.z += v.z;
-      s.w += v.w;
+    for (int k0 = 1; k0 < n_slices; k0 += 8) {  // the loads of up to eight slices are in flight together; the additions stay in slice order
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(part + ((int64_t)(k0 + j < n_slices ? k0 + j : k0) * M + m) * N + n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < n_slices) {
+          s.x += v[j].x;
+          s.y += v[j].y;
+          s.z += v[j].z;
+          s.w += v[j].w;
+        }
     }
     store1<T>(Y_, m * ldy + n, s.x);
     store1<T>(Y_, m * ldy + n + 1, s.y);
