@@ -134,11 +134,19 @@ __device__ __forceinline__ void attn_split_issue(AttnSplitState<T, D, NW, U>& s,
 // `write_kv`: this workgroup stores the new token's rotated key / value at slab slot T_old (one writer per kv head).
 // Contains ONE __syncthreads(): every wave of the real workgroup must call it.  Result for threads vtid < D: M, L (same for all)
 // and O = un-normalised output of head dim vtid.
-template <typename T, int D, int NW, bool FUSED, int U>
+// `before_new` (default: nothing): called by EVERY thread right before the new token's key / value rows are read -- a caller whose k / v rows
+// arrive late (dl_gemv_qkv_attn: they are the last outputs of the projection running in the same launch) waits for them there, after the
+// scores / softmax / P.V over the slab keys, which need q only.  With a waiter the k / v loads and the key's RoPE move behind the call; the
+// arithmetic and its order are the same.
+struct AttnNoWait {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <typename T, int D, int NW, bool FUSED, int U, typename BeforeNew = AttnNoWait>
 __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s, int vtid, const void* qrow_, const void* krow_,
                                                   const void* vrow_, const void* cos_, const void* sin_, int n_pos, int pos, float scale,
                                                   bool write_kv, int T_cap, float* sm_m, float* sm_l, float* sm_o, float& M_out, float& L_out,
-                                                  float& O_out) {
+                                                  float& O_out, BeforeNew before_new = BeforeNew()) {
+  constexpr bool LATE = !__is_same(BeforeNew, AttnNoWait);
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
   constexpr int V = St::V, LPK = St::LPK, KPW = St::KPW, NG = St::NG;
@@ -157,14 +165,14 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
     load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
     load16<T>(qrow + c, own);
     load16<T>(qrow + cpar, par);
-    if (owns_new) {
+    if (owns_new && !LATE) {
       const S* krow = reinterpret_cast<const S*>(krow_);
       load16<T>(krow + c, kown);
       load16<T>(krow + cpar, kpar);
       load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
     }
     if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
-    if (owns_new) {
+    if (owns_new && !LATE) {
       if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
     }
   } else {
@@ -246,6 +254,17 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
     }
   }
 
+  if constexpr (FUSED && LATE) {
+    before_new();
+    if (owns_new) {
+      float kown[V], kpar[V];
+      const S* krow = reinterpret_cast<const S*>(krow_);
+      load16<T>(krow + c, kown);
+      load16<T>(krow + cpar, kpar);
+      load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
+      if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
+    }
+  }
   if constexpr (FUSED) {
     // the new token (key index T_old): owned by lane group (wave 0, g 0) of the split whose range contains it
     if (owns_new) {

@@ -14,6 +14,8 @@
 #include <mutex>
 
 #include "gemv_dot.h"
+#include "granule.h"
+#include "attn_decode_body.h"
 
 namespace dl {
 
@@ -35,11 +37,20 @@ constexpr int kGemvMaxB = 8;
 // MODE: prologue (0 plain, 1 add+rmsnorm, 2 silu*up).  PAIR: the wave's R=2 neurons are (n, n + N/2) and the output is
 // cast(cast(silu(y_n)) * y_{n+N/2}) -> y [B, N/2]  (gate|up fused weight: DML:328 computed in the epilogue).
 // R neurons per wave per pass, U 16-byte chunks per neuron in flight  =>  R*U independent loads per lane.
+// the stored value's bit pattern (what store1<T> writes), for the in-launch granules
+template <typename T>
+__device__ __forceinline__ uint32_t gemv_bits(float f) {
+  if constexpr (Elem<T>::kBytes == 4) return __float_as_uint(f);
+  else return (uint32_t)Elem<T>::from_f(f);
+}
+
+// The body is a device function so that dl_gemv_qkv_attn can run it as part of a wider grid: `bid` / `nblk` are this workgroup's index and the
+// number of workgroups that share the rows.  gran != nullptr: every output is ALSO published as an 8-byte {gtag, value bits} granule
+// (granule.h) for consumers inside the same launch.
 template <typename T, int B, int MODE, bool PAIR, int R, int U>
-__global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restrict__ W_, int N, int K, const void* x_, int64_t x_rs,
-                                                            const void* __restrict__ h_, void* __restrict__ h_out_,
-                                                            const void* __restrict__ delta_, const void* __restrict__ nw_,
-                                                            float eps, void* __restrict__ y_, int64_t y_rs) {
+__device__ __forceinline__ void gemv_body(const void* __restrict__ W_, int N, int K, const void* x_, int64_t x_rs, const void* __restrict__ h_,
+                                          void* __restrict__ h_out_, const void* __restrict__ delta_, const void* __restrict__ nw_, float eps,
+                                          void* __restrict__ y_, int64_t y_rs, const int bid, const int nblk, u64_t* gran, uint32_t gtag) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -56,9 +67,9 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
   constexpr int RW = PAIR ? 1 : R;                    // wave-owned output neurons per pass (PAIR: one act = two rows)
   const int groups = (n_out + 4 * RW - 1) / (4 * RW);
   uint4 pre[R][U];
-  const bool have_pre = (int)blockIdx.x < groups && lane + 64 * (U - 1) < nvec;
+  const bool have_pre = bid < groups && lane + 64 * (U - 1) < nvec;
   if (have_pre) {
-    const int n0 = blockIdx.x * 4 * RW + wid * RW;
+    const int n0 = bid * 4 * RW + wid * RW;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int n = PAIR ? (n0 + r * n_out) : (n0 + r);
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
 #pragma unroll
               for (int e = 0; e < V; ++e) a[c][e] = Elem<T>::round(a[c][e] + d[e]);
               // updated residual stream: written once, to a DIFFERENT buffer (other workgroups are still reading h_in)
-              if (blockIdx.x == 0) store16<T>(h_out + (int64_t)b * K + v * V, a[c]);
+              if (bid == 0) store16<T>(h_out + (int64_t)b * K + v * V, a[c]);
             }
 #pragma unroll
             for (int e = 0; e < V; ++e) ss += a[c][e] * a[c][e];
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
             load16<T>(dl_ + (int64_t)b * K + v * V, d);
 #pragma unroll
             for (int e = 0; e < V; ++e) a[e] = Elem<T>::round(a[e] + d[e]);
-            if (blockIdx.x == 0) store16<T>(h_out + (int64_t)b * K + v * V, a);
+            if (bid == 0) store16<T>(h_out + (int64_t)b * K + v * V, a);
           }
 #pragma unroll
           for (int e = 0; e < V; ++e) ss += a[e] * a[e];
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
 
   // ---- stream the weights ----
   bool first = have_pre;
-  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+  for (int grp = bid; grp < groups; grp += nblk) {
     const int n0 = grp * 4 * RW + wid * RW;
     float acc[R][B];
     const S* wp[R];
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
         for (int r = 0; r < R; ++r) acc[r][b] = dot16<T>(raw[r], xv, acc[r][b]);
       }
     }
-    if (grp == (int)blockIdx.x) DL_GSTAMP(2);  // first neuron group streamed
+    if (grp == bid) DL_GSTAMP(2);  // first neuron group streamed
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -249,11 +260,22 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restri
         for (int r = 0; r < R; ++r)
 #pragma unroll
           for (int b = 0; b < B; ++b)
-            if (n0 + r < N) store1<T>(y_, (int64_t)b * y_rs + n0 + r, acc[r][b]);
+            if (n0 + r < N) {
+              store1<T>(y_, (int64_t)b * y_rs + n0 + r, acc[r][b]);
+              if (gran) gr_store(gran + (int64_t)b * N + n0 + r, gtag, gemv_bits<T>(acc[r][b]));
+            }
       }
     }
   }
   DL_GSTAMP(3);
+}
+
+template <typename T, int B, int MODE, bool PAIR, int R, int U>
+__global__ __launch_bounds__(kGemvThreads) void gemv_kernel(const void* __restrict__ W_, int N, int K, const void* x_, int64_t x_rs,
+                                                            const void* __restrict__ h_, void* __restrict__ h_out_,
+                                                            const void* __restrict__ delta_, const void* __restrict__ nw_,
+                                                            float eps, void* __restrict__ y_, int64_t y_rs) {
+  gemv_body<T, B, MODE, PAIR, R, U>(W_, N, K, x_, x_rs, h_, h_out_, delta_, nw_, eps, y_, y_rs, (int)blockIdx.x, (int)gridDim.x, nullptr, 0u);
 }
 
 // ---- batch 1, plain prologue (o_proj, down_proj): x lives in REGISTERS ----
@@ -364,9 +386,130 @@ static int gemv_launch(int mode, const void* W, int N, int K, const void* x, int
   return gemv_variant<T, B, 0>(pair, W, N, K, x, x_rs, h, h_out, delta, nw, eps, y, y_rs, grid_cap, st);
 }
 
+// ---- dl_gemv_qkv_attn: the q|k|v projection of a batch-1 decode layer and the attention that consumes it, in ONE launch ----
+// The decode attention at batch 1 is a 9 us latency chain (launch, first K/V bytes, softmax trips, merge) that moves 3 MB: 11 % of the step.
+// Here its workgroups (one per head) request their K/V rows as soon as they start -- those do not depend on the projection -- wait for
+// THEIR head_dim q outputs (the projection's first third; the streaming workgroups publish every output as a granule next to the ordinary
+// store), run scores / softmax / P.V over the slab keys while the weights still stream, and only then wait for the new token's k / v (the
+// projection's last outputs): after the stream ends the attention has one key and the merge left.  25.4 vs 26.5 us per layer, decode 2.617 ->
+// 2.564 ms/token.
+// No producer ever waits, so the launch cannot deadlock; the consumers' wait is bounded and poisons the output (NaN + error word) on give-up.
+// Both halves are the shared bodies (gemv_body, attn_decode_body.h): the results are bit-identical to dl_gemv + dl_attn_decode_rope.
+struct QkvAttnArgs {
+  // projection
+  const void* W; const void* h; void* h_out; const void* delta; const void* nw; void* y;
+  int N, K; float eps;
+  // attention
+  const void* cos_tab; const void* sin_tab; const int32_t* pos_base; const int32_t* kv_len; void* k_slab; void* v_slab; void* out;
+  int64_t stride_b, stride_h;
+  int n_pos, T_cap, n_heads, n_kv_heads, call_tag;
+  u64_t* gran; int32_t* err;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs a) {
+  using S = typename Elem<T>::storage;
+  const uint32_t tag = ((((uint32_t)a.pos_base[0] & 0x7fffffu) << 8) | ((uint32_t)a.call_tag & 0xffu)) + 1u;
+  // the attention workgroups are the LAST blocks of the grid (and the grid stays within what the device holds at once): as first blocks they
+  // displaced 32 streaming workgroups into a late second round (26.9 vs 25.4 us per launch)
+  const int n_gemv = (int)gridDim.x - a.n_heads;
+  if ((int)blockIdx.x < n_gemv) {
+    gemv_body<T, 1, 1, false, 2, 4>(a.W, a.N, a.K, nullptr, 0, a.h, a.h_out, a.delta, a.nw, a.eps, a.y, a.N, (int)blockIdx.x, n_gemv, a.gran, tag);
+    return;
+  }
+  constexpr int NW = 4, U = 4;
+  using St = AttnSplitState<T, D, NW, U>;
+  constexpr int NG = St::NG;
+  __shared__ float sm_m[NG], sm_l[NG];
+  __shared__ float sm_o[NG * D];
+  __shared__ __attribute__((aligned(16))) S rows[3 * D];
+  const int h = (int)blockIdx.x - n_gemv, tid = threadIdx.x;
+  const int n_rep = a.n_heads / a.n_kv_heads, kvh = h / n_rep;
+  const int T_old = a.kv_len[0];
+  St st;
+  attn_split_issue<T, D, NW, true, U>(st, tid, a.k_slab, a.v_slab, a.stride_b, a.stride_h, T_old, 1, 0, kvh, 0, 1, a.T_cap, 256);
+  // q first (the projection's first third): the slab keys need nothing else; k / v of the new token (its last third) only before the end
+  bool bad = false;
+  auto fetch = [&](int i0, int i1, int last, bool gate) {  // rows[i0, i1) <- granules; gate: one lane watches `last` (produced last) with long naps first
+    if (gate && tid == 0) {
+      for (int spins = 0;; ++spins) {
+        if ((uint32_t)(gr_load(a.gran + last) >> 32) == tag) break;
+        if (spins > (1 << 20)) {
+          bad = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __syncthreads();
+    for (int i = i0 + tid; i < i1; i += kGemvThreads) {
+      const int n = i < D ? h * D + i : (i < 2 * D ? (a.n_heads + kvh) * D + (i - D) : (a.n_heads + a.n_kv_heads + kvh) * D + (i - 2 * D));
+      u64_t v = 0;
+      for (int spins = 0;; ++spins) {
+        v = gr_load(a.gran + n);
+        if ((uint32_t)(v >> 32) == tag) break;
+        if (spins > (1 << 20)) {
+          bad = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if constexpr (Elem<T>::kBytes == 4) rows[i] = __uint_as_float((uint32_t)v);
+      else rows[i] = (S)(uint32_t)v;
+    }
+    __syncthreads();
+  };
+  fetch(0, D, h * D + D - 1, true);
+  float M, L, O;
+  attn_split_finish<T, D, NW, true, U>(st, tid, rows, rows + D, rows + 2 * D, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], 1.0f / sqrtf((float)D),
+                                       h % n_rep == 0, a.T_cap, sm_m, sm_l, sm_o, M, L, O,
+                                       [&]() { fetch(D, 3 * D, (a.n_heads + a.n_kv_heads + kvh) * D + D - 1, false); });
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : (L > 0.f ? O / L : 0.f));
+  if (any_bad && tid == 0 && a.err) atomicOr(a.err, 1);
+}
+
 }  // namespace dl
 
 using namespace dl;
+
+extern "C" int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads, int head_dim) {
+  return (int64_t)(n_heads + 2 * n_kv_heads) * head_dim * (int64_t)sizeof(u64_t);
+}
+
+extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* qkv,
+                                const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base, const int32_t* kv_len, void* k_slab,
+                                void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
+                                int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream) {
+  DL_REQUIRE(W && h_in && norm_w && qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && out && granules, "dl_gemv_qkv_attn: NULL pointer");
+  DL_REQUIRE(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && (head_dim == 128 || head_dim == 64) && K > 0 && n_pos > 0 && T_cap > 0,
+             "dl_gemv_qkv_attn: bad shape");
+  DL_REQUIRE(!delta || (h_out && h_out != h_in), "dl_gemv_qkv_attn: h_out must be a distinct buffer when delta is given");
+  DL_REQUIRE(call_tag >= 0 && grid_cap >= 0, "dl_gemv_qkv_attn: call_tag / grid_cap must be >= 0");
+  if (grid_cap == 0) grid_cap = kGemvGridCap;
+  const int N = (n_heads + 2 * n_kv_heads) * head_dim;
+  hipStream_t st = as_stream(stream);
+  int rc = DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(K % Elem<T>::kVec == 0 && (size_t)K * Elem<T>::kBytes <= 48 * 1024, "dl_gemv_qkv_attn: K=%d unsupported", K);
+    QkvAttnArgs a;
+    a.W = W; a.h = h_in; a.h_out = h_out; a.delta = delta; a.nw = norm_w; a.y = qkv; a.N = N; a.K = K; a.eps = eps;
+    a.cos_tab = cos_tab; a.sin_tab = sin_tab; a.pos_base = pos_base; a.kv_len = kv_len; a.k_slab = k_slab; a.v_slab = v_slab; a.out = out;
+    a.stride_b = slab_stride_b; a.stride_h = slab_stride_h; a.n_pos = n_pos; a.T_cap = T_cap; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads;
+    a.call_tag = call_tag; a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag;
+
+    const int groups = (N + 7) / 8;
+    if (grid_cap > 2 * n_heads) grid_cap -= n_heads;  // projection + attention workgroups together stay within what is resident at once
+    const int grid = (groups < grid_cap ? groups : grid_cap) + n_heads;
+    const size_t smem = (size_t)K * Elem<T>::kBytes;
+    if (head_dim == 128) hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 128>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+    else hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 64>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+  });
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_gemv_qkv_attn");
+  return DL_OK;
+}
+
 
 extern "C" int dl_gemv_max_batch(int K, int dtype) {
   const int es = dtype == DL_F32 ? 4 : 2;

@@ -409,6 +409,8 @@ class _DecodeState:
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
         # dl_decode_block (opt-in): granule workspace + error word of the in-launch GEMV chain
         self.blk_sync = None
+        # dl_gemv_qkv_attn's granules (batch 1, 16-bit dtypes at the decoder widths the kernel takes)
+        self.qa_gran = ops.gemv_qkv_attn_workspace(nH, nKV, d, device) if (B == 1 and dtype in (torch.bfloat16, torch.float16) and d in (64, 128) and H * 2 <= 48 * 1024) else None
         self.blk_err = torch.zeros(1, dtype=torch.int32, device=device)
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
 
@@ -439,6 +441,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # 4.24 ms per step at B = 4 / 8 / 16 against 5.1-5.3 on the library; a wash at 20-24 (4.64 / 4.80 vs 4.66 / 4.75) where the hand-written
         # path is kept for being deterministic and batch-invariant; 4 % behind at 32 (5.09 vs 4.89)
         self.smallm_max_decode_batch = 24
+        self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
         # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
@@ -938,7 +941,17 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if block and st.blk_sync is None:
             st.blk_sync = ops.decode_block_sync(max(cfg.hidden_size, cfg.intermediate_size), self.device)
         for i, layer in enumerate(self.model.layers):
-            if not (block and i > 0):  # with dl_decode_block the previous layer's launch already produced this layer's q|k|v
+            lens = cache.len_of_layer(i)
+            ns = cache.n_splits(i, st.B * nH)
+            # q|k|v projection + single-split attention of a batch-1 layer in ONE launch (dl_gemv_qkv_attn: the attention workgroups fetch their
+            # K/V rows while the weights stream and receive the projection as granules): bit-identical to the two launches below
+            fused_attn = self.fuse_qkv_attn and not block and st.B == 1 and ns == 1 and st.qa_gran is not None
+            if fused_attn:
+                ops.gemv_qkv_attn(layer.w_qkv, st.qkv, h_cur, h_alt, delta, layer.input_layernorm.weight, eps, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i],
+                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
+                if delta is not None:
+                    h_cur, h_alt = h_alt, h_cur
+            elif not (block and i > 0):  # with dl_decode_block the previous layer's launch already produced this layer's q|k|v
                 ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
@@ -952,12 +965,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                         self.model.output_text_score_predictor.decide(st.tp_x, st.tp_ws, st.tp_logits, st.decision)
                 else:
                     self.model.output_text_score_predictor.decide(h_cur, st.tp_ws, st.tp_logits, st.decision)
-            lens = cache.len_of_layer(i)
             # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
             # only when the row is long enough to need more than one workgroup per head)
-            ns = cache.n_splits(i, st.B * nH)
-            ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
-                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
+            if not fused_attn:
+                ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
+                                     call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
             if block:
                 # o_proj -> gate|up -> down -> next layer's q|k|v (lm_head after the last layer) in one launch; the residual stream goes
                 # h_cur -> (in LDS) -> h_alt exactly as the two add+norm prologues of the launch path update it
@@ -1066,7 +1078,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
         key = (self.use_block_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
-               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch)
+               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)
@@ -1122,6 +1134,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
+            if st.qa_gran is not None:
+                st.qa_gran.zero_()
             if st.blk_sync is not None:
                 st.blk_sync.zero_()
             self._decode_step_kernels(st, cache, False)
@@ -1434,6 +1448,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # request positions only grow, so a slot left by an earlier step never matches -- but a slot left by an EARLIER REQUEST at the same
         # position would.  Tag 0 is never expected: one clear per request makes every older granule unmatchable.
         st.attn_ws.zero_()
+        if st.qa_gran is not None:
+            st.qa_gran.zero_()  # and of dl_gemv_qkv_attn
         if st.blk_sync is not None:
             st.blk_sync.zero_()  # same rule for the granules of dl_decode_block
         self._eos = -1 if eos is None else (tuple(eos) if isinstance(eos, list) else eos)  # one id or a tuple of up to three (the EOS set)

@@ -338,6 +338,20 @@ int dl_gumbel_hard_keep_bwd(const void* d_keep, const void* prev_decision, const
  * bf16 / f16; N % 4 == 0, K % 8 == 0.  parts: n_slices * M * N floats. */
 int dl_linear_splitk(const void* A, int64_t lda, const void* W, float* parts, int M, int N, int K, int n_slices, int dtype, void* stream);
 
+/* ---- a batch-1 decode layer's q|k|v projection (DML:1011-1013, with the residual add + input RMSNorm prologue of dl_gemv's ADDNORM mode)
+ * AND the attention that consumes it (dl_attn_decode_rope with one split: RoPE DML:260-285, KV append CU:109-268, ragged attention
+ * DML:1061-1122) in ONE launch.  The attention workgroups (one per head) are the first blocks of the grid: they request their K/V rows at once
+ * and then wait for their 3 x head_dim projection outputs, which the weight-streaming workgroups publish as 8-byte {tag, value} granules
+ * beside the ordinary stores to `qkv`.  Bit-identical to dl_gemv(ADDNORM) + dl_attn_decode_rope(n_splits = 1).  B = 1 only.
+ * W: [(n_heads + 2 n_kv_heads) head_dim, K].  granules: dl_gemv_qkv_attn_workspace_bytes() bytes, zeroed once per request (tags are made of
+ * pos_base[0] and call_tag, 0..255: distinct for every (step, layer) of a request).  err_flag (may be NULL): bit 0 is set, and the output poisoned
+ * with NaN, if a consumer gave up waiting.  out: [n_heads * head_dim]. */
+int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads, int head_dim);
+int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* qkv,
+                     const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base, const int32_t* kv_len, void* k_slab,
+                     void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
+                     int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -713,3 +713,43 @@ def test_linear_splitk(ops, dtype, M, N, K, s):
     x2 = ops.add_rmsnorm(h2, ref.to(dtype), nw, 1e-5)
     assert torch.equal(h1, h2) or float((h1.float() - h2.float()).abs().max()) <= 2 * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * float(h2.float().abs().max())
     _close_ulp(x1, x2, dtype, 2.0, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nH,nKV,d,H,T_old,with_delta", [(32, 32, 128, 4096, 199, True), (40, 40, 128, 5120, 0, True), (32, 32, 128, 4096, 255, False), (8, 4, 64, 1024, 37, True), (32, 32, 128, 4096, 700, True)])
+def test_gemv_qkv_attn_bit_identical_to_the_two_launches(ops, dtype, nH, nKV, d, H, T_old, with_delta):
+    """dl_gemv_qkv_attn (q|k|v projection with the add+RMSNorm prologue AND the single-split decode attention in one launch, the projection's
+    outputs handed to the attention workgroups as granules) against dl_gemv(ADDNORM) + dl_attn_decode_rope(n_splits=1): projection row,
+    residual stream, attention output and the appended K/V row, bit for bit; repeated over steps / call tags on the same granule buffer (no
+    stale granule may be consumed), empty cache, GQA, head_dim 64, rows longer than one trip."""
+    from oracle.ref_cpu import rope_table
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *shape, s=0.02: (torch.randn(*shape, device="cuda", generator=g) * s).to(dtype)
+    N = (nH + 2 * nKV) * d
+    W, nw = rnd(N, H), 1 + rnd(H, s=0.1)
+    T_cap = T_old + 40
+    cos, sin = (t.cuda() for t in rope_table(d, T_cap + 8, 10000.0, dtype))
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gran = ops.gemv_qkv_attn_workspace(nH, nKV, d, "cuda")
+    k0, v0 = rnd(1, nKV, T_cap, d, s=1.0), rnd(1, nKV, T_cap, d, s=1.0)
+    eps = 1e-5
+    for step in range(6):
+        h0, delta = rnd(1, H, s=1.0), (rnd(1, H, s=1.0) if with_delta else None)
+        lens = torch.tensor([T_old + step], dtype=torch.int32, device="cuda")
+        pos = torch.tensor([T_old + step + 3], dtype=torch.int32, device="cuda")
+        # reference: two launches
+        k_r, v_r = k0.clone(), v0.clone()
+        qkv_r, ho_r, out_r = torch.zeros(1, N, dtype=dtype, device="cuda"), torch.zeros(1, H, dtype=dtype, device="cuda"), torch.zeros(1, nH * d, dtype=dtype, device="cuda")
+        ops.gemv(W, qkv_r, mode=ops.GEMV_ADDNORM, h_in=h0, h_out=ho_r, delta=delta, norm_w=nw, eps=eps)
+        ops.attn_decode_rope(qkv_r, cos, sin, pos, lens, k_r, v_r, out_r, None, 1, nH, nKV, d, chunk_keys=256)
+        for tag in (step & 0xff, 200 + step):  # the same step under another call tag as well
+            k_f, v_f = k0.clone(), v0.clone()
+            qkv_f, ho_f, out_f = torch.zeros_like(qkv_r), torch.zeros_like(ho_r), torch.zeros_like(out_r)
+            ops.gemv_qkv_attn(W, qkv_f, h0, ho_f, delta, nw, eps, cos, sin, pos, lens, k_f, v_f, out_f, gran, tag, nH, nKV, d, err=err)
+            assert torch.equal(qkv_f, qkv_r) and torch.equal(out_f, out_r), (step, tag, float((out_f.float() - out_r.float()).abs().max()))
+            assert torch.equal(k_f, k_r) and torch.equal(v_f, v_r)
+            if with_delta:
+                assert torch.equal(ho_f, ho_r)
+        k0, v0 = k_r, v_r  # the appended row stays for the next step
+    assert int(err.item()) == 0
