@@ -16,6 +16,8 @@
 #include "gemv_dot.h"
 #include "granule.h"
 #include "attn_decode_body.h"
+#include "tp_body.h"
+#include "../../include/dynllava.h"
 
 namespace dl {
 
@@ -469,9 +471,119 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
   if (any_bad && tid == 0 && a.err) atomicOr(a.err, 1);
 }
 
+// ---- dl_gemv_gu_tp: the gate|up projection of layer `sparse_layer` and the text predictor, in ONE launch ----
+// The predictor (three small latency-bound launches, 22 us of the batch-1 step: LN + Linear(H -> d), Linear(d -> d/2), the d/2 -> d/4 -> 2 tail)
+// reads the residual stream entering the layer -- the h_in of this very launch -- and only the end-of-step length advance needs its decision.
+// Its stages run as the FIRST workgroups of the grid (resident from the start, gone after a few microseconds; stage k+1 receives stage k's
+// outputs as granules), the projection streams next to them.  Shared stage bodies (tp_body.h): bit-identical to dl_text_predictor_decide.
+struct GuTpArgs {
+  const void* W; const void* h; void* h_out; const void* delta; const void* nw; void* y;
+  int N, K; float eps;
+  dl_tp_weights w;
+  float* tp_ws; float* logits; int32_t* decision;
+  const int32_t* pos_base;
+  u64_t* gran; int32_t* err;
+  int D, call_tag;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kGemvThreads) void gemv_gu_tp_kernel(GuTpArgs a) {
+  const int D = a.D, n1 = (D + 7) / 8, n2 = (D / 2 + 7) / 8, side = n1 + n2 + 1;
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  if (bid >= side) {
+    gemv_body<T, 1, 1, true, 2, 4>(a.W, a.N, a.K, nullptr, 0, a.h, a.h_out, a.delta, a.nw, a.eps, a.y, a.N / 2, bid - side, (int)gridDim.x - side, nullptr, 0u);
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) float gt_dyn[];  // >= max(H, 2 D) floats (host)
+  const uint32_t tag = ((((uint32_t)a.pos_base[0] & 0x7fffffu) << 8) | ((uint32_t)a.call_tag & 0xffu)) + 1u;
+  float* h1 = a.tp_ws;
+  float* a1 = h1 + D;
+  u64_t* g1 = a.gran;
+  u64_t* g2 = a.gran + D;
+  if (bid < n1) {  // stage 1: needs nothing from this launch
+    tp_stage1_body<T>(a.h, a.K, a.w.ln_w, a.w.ln_b, a.w.l1_w, a.w.l1_b, h1, a.K, D, bid, 0, g1, tag);
+    return;
+  }
+  bool bad = false;
+  auto fetch = [&](const u64_t* g, int n, float* dst) {  // dst[0, n) <- granules of the previous stage (produced almost together: watch the last one first)
+    if (tid == 0) {
+      for (int spins = 0;; ++spins) {
+        if ((uint32_t)(gr_load(g + n - 1) >> 32) == tag) break;
+        if (spins > (1 << 20)) {
+          bad = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kGemvThreads) {
+      u64_t v = 0;
+      for (int spins = 0;; ++spins) {
+        v = gr_load(g + i);
+        if ((uint32_t)(v >> 32) == tag) break;
+        if (spins > (1 << 20)) {
+          bad = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      dst[i] = __uint_as_float((uint32_t)v);
+    }
+  };
+  if (bid < n1 + n2) {  // stage 2a
+    fetch(g1, D, gt_dyn);
+    if (__syncthreads_or(bad ? 1 : 0)) {
+      if (tid == 0 && a.err) atomicOr(a.err, 2);
+      return;  // its granules never appear: stage 2b gives up too and reports
+    }
+    tp_stage2a_body<T>(gt_dyn, a.w.l3_w, a.w.l3_b, a1, D, bid - n1, 0, g2, tag);
+    return;
+  }
+  fetch(g2, D / 2, gt_dyn);  // stage 2b
+  if (__syncthreads_or(bad ? 1 : 0)) {
+    if (tid == 0) {
+      if (a.err) atomicOr(a.err, 2);
+      a.decision[0] = 1;  // keep the token: the conservative outcome
+    }
+    return;
+  }
+  tp_stage2b_body<T>(gt_dyn, a.w.l5_w, a.w.l5_b, a.w.l7_w, a.w.l7_b, a.logits, a.decision, D, 0, gt_dyn + D / 2);
+}
+
 }  // namespace dl
 
 using namespace dl;
+
+extern "C" int64_t dl_gemv_gu_tp_workspace_bytes(int d_model) { return d_model > 0 ? (int64_t)(d_model + d_model / 2) * (int64_t)sizeof(u64_t) : 0; }
+
+extern "C" int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* y,
+                             const dl_tp_weights* tp, int d_model, void* tp_workspace, float* logits_out, int32_t* decision, const int32_t* pos_base,
+                             void* granules, int call_tag, int32_t* err_flag, int dtype, int grid_cap, void* stream) {
+  DL_REQUIRE(W && h_in && norm_w && y && tp && tp_workspace && decision && pos_base && granules, "dl_gemv_gu_tp: NULL pointer");
+  DL_REQUIRE(N > 0 && N % 2 == 0 && K > 0 && d_model > 0 && d_model % 32 == 0 && K % 8 == 0 && K <= 5120, "dl_gemv_gu_tp: bad shape N=%d K=%d d_model=%d", N, K, d_model);
+  DL_REQUIRE(!delta || (h_out && h_out != h_in), "dl_gemv_gu_tp: h_out must be a distinct buffer when delta is given");
+  DL_REQUIRE(call_tag >= 0 && grid_cap >= 0, "dl_gemv_gu_tp: call_tag / grid_cap must be >= 0");
+  if (grid_cap == 0) grid_cap = kGemvGridCap;
+  hipStream_t st = as_stream(stream);
+  int rc = DL_OK;
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(K % Elem<T>::kVec == 0, "dl_gemv_gu_tp: K must be a multiple of %d", Elem<T>::kVec);
+    GuTpArgs a;
+    a.W = W; a.h = h_in; a.h_out = h_out; a.delta = delta; a.nw = norm_w; a.y = y; a.N = N; a.K = K; a.eps = eps;
+    a.w = *tp; a.tp_ws = reinterpret_cast<float*>(tp_workspace); a.logits = logits_out; a.decision = decision; a.pos_base = pos_base;
+    a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag; a.D = d_model; a.call_tag = call_tag;
+    const int side = (d_model + 7) / 8 + (d_model / 2 + 7) / 8 + 1;
+    const int groups = (N / 2 + 3) / 4;
+    const int grid = (groups < grid_cap ? groups : grid_cap) + side;
+    size_t smem = (size_t)K * sizeof(float);  // stage 1 stages the row in fp32; the projection needs K elements of the model dtype
+    if (smem < (size_t)2 * d_model * sizeof(float)) smem = (size_t)2 * d_model * sizeof(float);
+    hipLaunchKernelGGL((gemv_gu_tp_kernel<T>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+  });
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_gemv_gu_tp");
+  return DL_OK;
+}
 
 extern "C" int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads, int head_dim) {
   return (int64_t)(n_heads + 2 * n_kv_heads) * head_dim * (int64_t)sizeof(u64_t);

@@ -93,6 +93,9 @@ SIGNATURES = {
     "dl_gemv": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "dl_linear_splitk": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_gemv_qkv_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dl_gemv_gu_tp_workspace_bytes": (c_int64, [c_int]),
+    "dl_gemv_gu_tp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, POINTER(TpWeights), c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dl_gemv_qkv_attn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_attn_policy_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
@@ -471,6 +474,27 @@ def gemv_qkv_attn(w, qkv, h_in, h_out, delta, norm_w, eps, cos, sin, pos_base, k
         "dl_gemv_qkv_attn",
     )
     return out
+
+
+def gemv_gu_tp_workspace(d_model, device):
+    """Granule buffer of gemv_gu_tp (zeroed: no tag is 0); zero it again at the start of every request."""
+    return torch.zeros(int(lib().dl_gemv_gu_tp_workspace_bytes(int(d_model))) // 8, dtype=torch.int64, device=device)
+
+
+def gemv_gu_tp(w, y, h_in, h_out, delta, norm_w, eps, tp_weights: TpWeights, d_model, tp_workspace, logits_out, decision, pos_base, granules, call_tag, err=None, grid_cap=0):
+    """One launch = gemv(w, y, mode=GEMV_ADDNORM | GEMV_OUT_SILU_PAIR, ...) + text_predictor_decide(h_in, ...) for ONE row (see include/dynllava.h)."""
+    _dev(w, y, h_in, h_out, delta, norm_w, tp_workspace, logits_out, decision, pos_base, granules, err)
+    N, K = w.shape
+    assert w.is_contiguous() and y.shape == (1, N // 2) and y.is_contiguous() and h_in.is_contiguous() and h_in.shape == (1, K)
+    assert delta is None or (delta.is_contiguous() and h_out.is_contiguous())
+    assert decision.dtype == torch.int32 and pos_base.dtype == torch.int32 and tp_workspace.dtype == torch.float32
+    assert tp_workspace.numel() * 4 >= lib().dl_text_predictor_workspace_bytes(1, d_model) and granules.numel() * granules.element_size() >= lib().dl_gemv_gu_tp_workspace_bytes(d_model)
+    _check(
+        lib().dl_gemv_gu_tp(_p(w), N, K, _p(h_in), _p(h_out), _p(delta), _p(norm_w), eps, _p(y), ctypes.byref(tp_weights), int(d_model), _p(tp_workspace), _p(logits_out),
+                            _p(decision), _p(pos_base), _p(granules), int(call_tag), _p(err), dtype_code(w.dtype), int(grid_cap), _stream()),
+        "dl_gemv_gu_tp",
+    )
+    return y
 
 
 def decode_advance(logits, next_ids, out_ids=None, step=None, finished=None, eos_id=-1, pad_id=0, kv_len_full=None, kv_len_sparse=None, decision=None, min_new_tokens=0):

@@ -409,6 +409,9 @@ class _DecodeState:
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
         # dl_decode_block (opt-in): granule workspace + error word of the in-launch GEMV chain
         self.blk_sync = None
+        # dl_gemv_gu_tp's granules (batch 1; the predictor's stage 1 stages the row in LDS: H <= 5120)
+        tpm = getattr(model.model, "output_text_score_predictor", None)
+        self.tp_gran = ops.gemv_gu_tp_workspace(tpm.d_model, device) if (B == 1 and tpm is not None and dtype in (torch.bfloat16, torch.float16) and H <= 5120 and H % 8 == 0 and tpm.d_model % 32 == 0) else None
         # dl_gemv_qkv_attn's granules (batch 1, 16-bit dtypes at the decoder widths the kernel takes)
         self.qa_gran = ops.gemv_qkv_attn_workspace(nH, nKV, d, device) if (B == 1 and dtype in (torch.bfloat16, torch.float16) and d in (64, 128) and H * 2 <= 48 * 1024) else None
         self.blk_err = torch.zeros(1, dtype=torch.int32, device=device)
@@ -442,6 +445,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # path is kept for being deterministic and batch-invariant; 4 % behind at 32 (5.09 vs 4.89)
         self.smallm_max_decode_batch = 24
         self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
+        self.fuse_gu_tp = os.environ.get("DL_FUSE_GU_TP", "1") == "1"
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
         # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
@@ -955,7 +959,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
-            if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
+            # the predictor as extra workgroups of this layer's gate|up launch (dl_gemv_gu_tp): its input is that launch's h_in
+            fused_tp = i == SL and use_tp and self.fuse_gu_tp and not block and not self.tp_side_stream and st.B == 1 and st.tp_gran is not None
+            if i == SL and use_tp and not fused_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 # only the end-of-step length advance consumes the decision: run the predictor on a side stream (a parallel
                 # branch of the captured graph) on a snapshot of the residual stream, off the layer chain's critical path
                 if self.tp_side_stream:
@@ -986,7 +992,12 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 h_cur, h_alt = h_alt, h_cur
                 continue
             ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
-            ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
+            if fused_tp:
+                tp = self.model.output_text_score_predictor
+                ops.gemv_gu_tp(layer.w_gu, st.gu, h_cur, h_alt, st.o, layer.post_attention_layernorm.weight, eps, tp._weights(), tp.d_model, st.tp_ws, st.tp_logits,
+                               st.decision, cache.len_full, st.tp_gran, i & 0xff, err=st.blk_err)
+            else:
+                ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
             h_cur, h_alt = h_alt, h_cur
             ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
             delta = st.dn
@@ -1078,7 +1089,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
         key = (self.use_block_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
-               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn)
+               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)
@@ -1136,6 +1147,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
             if st.qa_gran is not None:
                 st.qa_gran.zero_()
+            if st.tp_gran is not None:
+                st.tp_gran.zero_()
             if st.blk_sync is not None:
                 st.blk_sync.zero_()
             self._decode_step_kernels(st, cache, False)
@@ -1450,6 +1463,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         st.attn_ws.zero_()
         if st.qa_gran is not None:
             st.qa_gran.zero_()  # and of dl_gemv_qkv_attn
+        if st.tp_gran is not None:
+            st.tp_gran.zero_()  # and of dl_gemv_gu_tp
         if st.blk_sync is not None:
             st.blk_sync.zero_()  # same rule for the granules of dl_decode_block
         self._eos = -1 if eos is None else (tuple(eos) if isinstance(eos, list) else eos)  # one id or a tuple of up to three (the EOS set)

@@ -352,6 +352,17 @@ int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const 
                      void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
                      int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
 
+/* ---- the gate|up projection of layer `sparse_layer` at decode batch 1 (dl_gemv ADDNORM | OUT_SILU_PAIR: DML:1289 + DML:134-139 + DML:328) AND the
+ * text predictor (dl_text_predictor_decide: DML:1385-1387, 2388-2391) on the residual stream entering that layer -- the h_in of this launch --
+ * in ONE launch: the predictor's three stages are the first workgroups of the grid and hand their outputs on as granules; nothing in the
+ * layer chain waits for them.  Bit-identical to the separate calls.  tp_workspace: dl_text_predictor_workspace_bytes(1, d_model);
+ * granules: dl_gemv_gu_tp_workspace_bytes(d_model), zeroed once per request (tag = pos_base[0], call_tag); err_flag (may be NULL): bit 1 is
+ * set (and decision[0] = 1, keep) if a stage gave up waiting. */
+int64_t dl_gemv_gu_tp_workspace_bytes(int d_model);
+int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* y,
+                  const dl_tp_weights* tp, int d_model, void* tp_workspace, float* logits_out, int32_t* decision, const int32_t* pos_base,
+                  void* granules, int call_tag, int32_t* err_flag, int dtype, int grid_cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -753,3 +753,37 @@ def test_gemv_qkv_attn_bit_identical_to_the_two_launches(ops, dtype, nH, nKV, d,
                 assert torch.equal(ho_f, ho_r)
         k0, v0 = k_r, v_r  # the appended row stays for the next step
     assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,I,D", [(4096, 11008, 1024), (5120, 13824, 1024), (1024, 2816, 256), (512, 1536, 64)])
+def test_gemv_gu_tp_bit_identical_to_the_separate_launches(ops, dtype, H, I, D):
+    """dl_gemv_gu_tp (gate|up projection with add+RMSNorm prologue and SiLU*up epilogue AND the text predictor's three stages as extra workgroups of
+    the same launch, handing h1 / a1 on as granules) against dl_gemv + dl_text_predictor_decide: activation row, residual stream, predictor
+    logits and decision bit for bit, repeated over steps / call tags on the same granule buffer."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *shape, s=0.02: (torch.randn(*shape, device="cuda", generator=g) * s).to(dtype)
+    Wgu, nw = rnd(2 * I, H), 1 + rnd(H, s=0.1)
+    w = ops.TpWeights()
+    keep = [1 + rnd(H, s=0.1), rnd(H, s=0.1), rnd(D, H, s=0.05), rnd(D, s=0.1), rnd(D // 2, D, s=0.1), rnd(D // 2, s=0.1), rnd(D // 4, D // 2, s=0.2), rnd(D // 4, s=0.1),
+            rnd(2, D // 4, s=0.5), rnd(2, s=0.1)]
+    (w.ln_w, w.ln_b, w.l1_w, w.l1_b, w.l3_w, w.l3_b, w.l5_w, w.l5_b, w.l7_w, w.l7_b) = [t.data_ptr() for t in keep]
+    eps = 1e-5
+    gran = ops.gemv_gu_tp_workspace(D, "cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws_r, ws_f = ops.text_predictor_workspace(1, D, "cuda"), ops.text_predictor_workspace(1, D, "cuda")
+    decs = []
+    for step in range(8):
+        h0, delta = rnd(1, H, s=1.0), rnd(1, H, s=1.0)
+        pos = torch.tensor([50 + step // 2], dtype=torch.int32, device="cuda")
+        y_r, ho_r = torch.zeros(1, I, dtype=dtype, device="cuda"), torch.zeros(1, H, dtype=dtype, device="cuda")
+        lg_r, dec_r = torch.zeros(1, 2, dtype=torch.float32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.gemv(Wgu, y_r, mode=ops.GEMV_ADDNORM | ops.GEMV_OUT_SILU_PAIR, h_in=h0, h_out=ho_r, delta=delta, norm_w=nw, eps=eps)
+        ops.text_predictor_decide(h0, w, D, ws_r, lg_r, dec_r)
+        y_f, ho_f = torch.zeros_like(y_r), torch.zeros_like(ho_r)
+        lg_f, dec_f = torch.full_like(lg_r, 7.0), torch.full_like(dec_r, 5)
+        ops.gemv_gu_tp(Wgu, y_f, h0, ho_f, delta, nw, eps, w, D, ws_f, lg_f, dec_f, pos, gran, step & 1, err=err)
+        assert torch.equal(y_f, y_r) and torch.equal(ho_f, ho_r), step
+        assert torch.equal(lg_f, lg_r) and torch.equal(dec_f, dec_r) and torch.equal(ws_f, ws_r), (step, lg_f, lg_r)
+        decs.append(int(dec_r))
+    assert int(err.item()) == 0
