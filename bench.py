@@ -531,7 +531,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": roof_main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_main["frac"], "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": roof_main["kernel"], "launches_per_step": roof_main["launches_per_step"], "bytes_per_launch": roof_main["bytes"], "us_per_launch": roof_main["us"],
                      "bytes_per_step": roof_main["bytes_per_step"], "us_per_step": roof_main["us_per_step"],
-                     "note": "averaged over the 129 dl_gemv launches of one decode step replayed as one hipGraph between HIP events on the launch stream (includes inter-kernel gaps); the north_star's sparse-attention kernel is the first entry of roofline_kernels"},
+                     "note": "averaged over the 129 dl_gemv launches of one decode step replayed as one hipGraph between HIP events on the launch stream (includes inter-kernel gaps); the north_star's sparse-attention kernel is the first entry of roofline_kernels; in the product step the q|k|v launches of the single-split layers also carry that layer's attention workgroups (dl_gemv_qkv_attn) and one gate|up launch the text predictor (dl_gemv_gu_tp): same streaming body, same bytes"},
         "roofline_kernels": extra,
     }
     if c3 is not None:
