@@ -455,6 +455,7 @@ def main():
     torch.cuda.synchronize()
     dd.barrier()
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
+    model.check_device_errors()  # a launch with in-kernel hand-offs that gave up would have poisoned its output: never report such a run
     end_lens = model.last_cache.lens.cpu().tolist()  # KV lengths at the end of a full step (before the pooled slab is reset)
     dp_consistent = None
     c3 = None

@@ -94,12 +94,14 @@ class KVSlabCache:
         boundaries would move, so those launches keep the length-derived ranges."""
         return 256 if n_splits == 1 else 0
 
+    eight_wave_single_split = True  # tests switch it off to compare the stand-alone attention with dl_gemv_qkv_attn (four waves) bit for bit
+
     @staticmethod
     def keys_in_flight(n_splits: int, rows_times_heads: int) -> int:
         """`keys_in_flight` of dl_attn_decode_rope: single-split launches of few (row, head) pairs (decode batches <= 4) run eight waves per
         workgroup -- 128 keys per trip, two trips in flight: 8.9 vs 9.7 us at 226 keys; with more rows the four-wave form keeps more
         workgroups resident per CU (B=32 ragged: 22.6 vs 28.5 us)."""
-        return 128 if n_splits == 1 and rows_times_heads <= 128 else 64
+        return 128 if n_splits == 1 and rows_times_heads <= 128 and KVSlabCache.eight_wave_single_split else 64
 
     # ---- which length vector a layer uses ----
     def group(self, layer_idx: int) -> int:

@@ -908,14 +908,22 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return (self.use_block_decode and st.B == 1 and st.use_gemv and self.dtype in (torch.bfloat16, torch.float16) and H % 512 == 0 and I % 8 == 0
                 and H <= 8192 and cfg.num_attention_heads * cfg.head_dim == H)
 
-    def check_block_decode(self):
-        """Raises if a dl_decode_block launch gave up on an in-kernel wait (costs one device->host copy)."""
+    def check_device_errors(self):
+        """Raises if a launch with in-kernel hand-offs (dl_gemv_qkv_attn, dl_gemv_gu_tp, dl_decode_block) gave up on a wait since the last check
+        (such a launch poisons its output instead of hanging).  Costs one device->host copy: call it where a sync is acceptable."""
         st = self._dstate
-        if st is not None and self.use_block_decode:
+        if st is not None:
             code = int(st.blk_err.item())
             if code != 0:
                 st.blk_err.zero_()
-                raise ops.HipOpsError(f"dl_decode_block aborted (code {code:#x}): a workgroup was not resident or a producer never published")
+                what = [n for bit, n in ((1, "dl_gemv_qkv_attn (attention never received its projection outputs)"), (2, "dl_gemv_gu_tp (a predictor stage never received its inputs)")) if code & bit]
+                if code & ~3:
+                    what.append(f"dl_decode_block (code {code & ~3:#x}: a workgroup was not resident or a producer never published)")
+                raise ops.HipOpsError("in-kernel hand-off aborted: " + "; ".join(what))
+
+    def check_block_decode(self):
+        """Kept for callers of the opt-in dl_decode_block path: same as check_device_errors()."""
+        self.check_device_errors()
 
     def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
         if st.use_gemv:
@@ -1089,7 +1097,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
         key = (self.use_block_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
-               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp)
+               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)

@@ -97,3 +97,48 @@ def test_block_decode_generate_graph_replay_equals_launch_path():
         assert outs[k + ("lens",)] == outs[False, False, "lens"]
     kept = outs[True, True, "lens"][1] - (35 + 115 + 20)
     assert 0 <= kept <= 39
+
+
+def test_fused_decode_launches_equal_the_separate_launches_in_generate():
+    """generate() with dl_gemv_qkv_attn / dl_gemv_gu_tp (the defaults at batch 1) against the same step built from separate launches: tokens, KV
+    lengths and the K/V rows of every layer bit for bit, graph replay and eager; the in-kernel hand-offs must not have given up."""
+    dtype = torch.bfloat16
+    cfg = fx.llava7b_config(num_hidden_layers=4)
+    cfg.vocab_size = 4096
+    sd = fx.make_state_dict(cfg, seed=29, predictor_gain=50.0)
+    model = _build(cfg, sd, dtype)
+    g = torch.Generator().manual_seed(3)
+    ids = fx.make_prompt(cfg, 35, 20, seed=8)[None]
+    feats = torch.randn(1, 576, cfg.hidden_size, generator=g).to(dtype)
+    from dynamic_llava_amd.cache import KVSlabCache
+
+    res = {}
+    # the fused launch runs the attention body with four waves per workgroup; the stand-alone launch would pick eight for these rows (another
+    # key -> lane-group dealing, last-bit differences): compare like with like
+    KVSlabCache.eight_wave_single_split = False
+    try:
+        _run_fused_matrix(model, cfg, ids, feats, res)
+    finally:
+        KVSlabCache.eight_wave_single_split = True
+    ref = res[False, False]
+    for key in ((False, True), (True, False), (True, True)):
+        out, lens, kv = res[key]
+        assert torch.equal(out, ref[0]) and lens == ref[1], key
+        for i in range(len(kv)):
+            assert torch.equal(kv[i][0], ref[2][i][0]) and torch.equal(kv[i][1], ref[2][i][1]), (key, i)
+    assert 0 <= ref[1][1] - (35 + 115 + 20) <= 47
+
+
+def _run_fused_matrix(model, cfg, ids, feats, res):
+    for fused in (False, True):
+        for graph in (False, True):
+            model.fuse_qkv_attn = model.fuse_gu_tp = fused
+            model.use_hip_graph = graph
+            out = model.generate(ids.cuda(), image_features=feats.cuda(), max_new_tokens=48, eos_token_id=None).cpu()
+            model.check_device_errors()
+            lens = model.last_cache[1]
+            n0, n1 = int(lens[0][0]), int(lens[-1][0])
+            c = model.last_cache
+            L, SL = cfg.num_hidden_layers, cfg.sparse_config["sparse_layer"]
+            kv = [(c.k[i][0, :, : (n0 if i < SL else n1)].clone(), c.v[i][0, :, : (n0 if i < SL else n1)].clone()) for i in range(L)]
+            res[fused, graph] = (out, (n0, n1), kv)
