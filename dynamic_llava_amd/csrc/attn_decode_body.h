@@ -75,6 +75,10 @@ struct AttnSplitState {
   bool spec;
   bool ok[U];
   uint4 kraw[U], vraw[U];
+  // second trip, requested ahead of the first one's consumption (attn_split_prefetch2: callers that have to wait for q anyway)
+  bool pre2;
+  bool ok2[U <= 4 ? U : 1];
+  uint4 kraw2[U <= 4 ? U : 1], vraw2[U <= 4 ? U : 1];
 };
 
 // Part 1.  `vtid`: thread index inside the (virtual) workgroup of NW waves.  Every load that does not depend on another load is
@@ -95,6 +99,7 @@ __device__ __forceinline__ void attn_split_issue(AttnSplitState<T, D, NW, U>& s,
   s.kb = reinterpret_cast<const S*>(k_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + s.c;
   s.vb = reinterpret_cast<const S*>(v_slab_) + (int64_t)b * stride_b + (int64_t)kvh * stride_h + s.c;
   s.T_old = T_old;
+  s.pre2 = false;
   s.spec = chunk_keys > 0 && T_cap > 0;
   s.chunk = 0;
   s.k0 = 0;
@@ -125,6 +130,28 @@ __device__ __forceinline__ void attn_split_issue(AttnSplitState<T, D, NW, U>& s,
       const int64_t off = (int64_t)(s.ok[u] ? key : (s.k0 < s.k1 ? s.k0 : 0)) * D;
       s.kraw[u] = kv_ld16(s.kb + off);
       s.vraw[u] = kv_ld16(s.vb + off);
+    }
+  }
+}
+
+// Optional, between the two parts: request the SECOND trip's rows too (U <= 4).  attn_split_finish requests trip i + 1 when it starts on trip i;
+// a caller that cannot start yet (dl_gemv_qkv_attn waits for q) puts two trips in flight meanwhile.  Loads only: results unchanged.
+template <typename T, int D, int NW, int U>
+__device__ __forceinline__ void attn_split_prefetch2(AttnSplitState<T, D, NW, U>& s) {
+  using St = AttnSplitState<T, D, NW, U>;
+  constexpr int KPW = St::KPW, NG = St::NG;
+  if constexpr (U <= 4) {
+    const int nbase = s.k0 + NG * U;
+    if (nbase < s.k1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int key = nbase + (u * NW + s.wid) * KPW + s.g;
+        s.ok2[u] = key < s.k1;
+        const int64_t off = (int64_t)(s.ok2[u] ? key : s.k0) * D;
+        s.kraw2[u] = kv_ld16(s.kb + off);
+        s.vraw2[u] = kv_ld16(s.vb + off);
+      }
+      s.pre2 = true;
     }
   }
 }
@@ -193,13 +220,22 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
     if constexpr (kPrefetch) {
       const int nbase = base + NG * U;
       if (nbase < s.k1) {
+        if (base == s.k0 && s.pre2) {  // already in flight (attn_split_prefetch2)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int key = nbase + (u * NW + wid) * KPW + g;
-          okpre[u] = key < s.k1;
-          const int64_t off = (int64_t)(okpre[u] ? key : s.k0) * D;
-          kpre[u] = kv_ld16(s.kb + off);
-          vpre[u] = kv_ld16(s.vb + off);
+          for (int u = 0; u < U; ++u) {
+            okpre[u] = s.ok2[u];
+            kpre[u] = s.kraw2[u];
+            vpre[u] = s.vraw2[u];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int key = nbase + (u * NW + wid) * KPW + g;
+            okpre[u] = key < s.k1;
+            const int64_t off = (int64_t)(okpre[u] ? key : s.k0) * D;
+            kpre[u] = kv_ld16(s.kb + off);
+            vpre[u] = kv_ld16(s.vb + off);
+          }
         }
       }
     } else if (base != s.k0) {
