@@ -519,18 +519,31 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_gu_tp_kernel(GuTpArgs a) {
       }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += kGemvThreads) {
-      u64_t v = 0;
+    // a thread's granules are requested TOGETHER and re-requested until all carry the tag (one at a time, each poll was a ~2 us round trip
+    // beside the weight stream: 6 us from the last stage-1 store to stage 2a's first instruction)
+    constexpr int GB = 4;
+    for (int i0 = tid; i0 < n; i0 += GB * kGemvThreads) {
+      u64_t v[GB];
       for (int spins = 0;; ++spins) {
-        v = gr_load(g + i);
-        if ((uint32_t)(v >> 32) == tag) break;
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+          const int i = i0 + j * kGemvThreads;
+          v[j] = gr_load(g + (i < n ? i : i0));
+          all = all && (uint32_t)(v[j] >> 32) == tag;
+        }
+        if (all) break;
         if (spins > (1 << 20)) {
           bad = true;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      dst[i] = __uint_as_float((uint32_t)v);
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        const int i = i0 + j * kGemvThreads;
+        if (i < n) dst[i] = __uint_as_float((uint32_t)v[j]);
+      }
     }
   };
   if (bid < n1 + n2) {  // stage 2a
@@ -542,15 +555,14 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_gu_tp_kernel(GuTpArgs a) {
     tp_stage2a_body<T>(gt_dyn, a.w.l3_w, a.w.l3_b, a1, D, bid - n1, 0, g2, tag);
     return;
   }
-  fetch(g2, D / 2, gt_dyn);  // stage 2b
-  if (__syncthreads_or(bad ? 1 : 0)) {
-    if (tid == 0) {
-      if (a.err) atomicOr(a.err, 2);
-      a.decision[0] = 1;  // keep the token: the conservative outcome
-    }
-    return;
-  }
-  tp_stage2b_body<T>(gt_dyn, a.w.l5_w, a.w.l5_b, a.w.l7_w, a.w.l7_b, a.logits, a.decision, D, 0, gt_dyn + D / 2);
+  // stage 2b: its weights are requested first, then it waits for stage 2a's outputs (inside the body)
+  float* a1s = gt_dyn + D;  // granule values; the body copies them into its own LDS area at gt_dyn
+  tp_stage2b_body<T>(a1s, a.w.l5_w, a.w.l5_b, a.w.l7_w, a.w.l7_b, a.logits, a.decision, D, 0, gt_dyn, [&]() {
+    fetch(g2, D / 2, a1s);
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;  // give-up: a1s holds whatever arrived; flag it, the decision below is then overwritten
+    if (bad && tid == 0 && a.err) atomicOr(a.err, 2);
+  });
+  if (bad && tid == 0) a.decision[0] = 1;  // keep the token: the conservative outcome
 }
 
 }  // namespace dl

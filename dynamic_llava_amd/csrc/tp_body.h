@@ -183,17 +183,72 @@ __device__ __forceinline__ void tp_stage2a_body(const float* __restrict__ h1, co
 }
 
 // ---- text predictor, stage 2b: D/2 -> D/4 -> 2 and the keep/evict decision.  grid (B) ----
-template <typename T>
+// `wait_input` (default: nothing) is called by every thread after the weights have been requested and before the input row is read: inside
+// dl_gemv_gu_tp the stage waits there for stage 2a's granules.  When a lane's share of the D/2 -> D/4 layer fits (<= 8 passes of 4 neurons per
+// wave, one 16-byte chunk per row) ALL its weight rows and biases are requested up front instead of pass by pass: beside a weight stream
+// every dependent round trip costs ~2 us (8 passes: 13 us, which pushed the fused launch 9 us past the end of its projection).  Same chunk ->
+// lane dealing, same accumulation order as tp_dense: same bits.
+struct TpNoWait {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <typename T, typename WaitInput = TpNoWait>
 __device__ __forceinline__ void tp_stage2b_body(const float* __restrict__ a1g, const void* w5, const void* b5, const void* w7, const void* b7,
-                                                float* __restrict__ logits, int32_t* __restrict__ decision, int D, const int bx, float* sm) {
+                                                float* __restrict__ logits, int32_t* __restrict__ decision, int D, const int bx, float* sm,
+                                                WaitInput wait_input = WaitInput()) {
   // sm: [D/2] + [D/4] + [2] floats of LDS
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
   float* a1 = sm;
   float* a2 = a1 + D / 2;
   float* a3 = a2 + D / 4;
   const int b = bx;
+  const int K5 = D / 2, N5 = D / 4;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int passes = (N5 + nw * 4 - 1) / (nw * 4);
+  const bool pre = K5 % V == 0 && K5 / V <= 64 && passes <= 8;
+  uint4 wq[8][4];
+  float bq[8][4];
+  if (pre) {
+    const S* W = reinterpret_cast<const S*>(w5);
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int n = wid * 4 + ps * nw * 4 + j;
+        n = n < N5 ? n : N5 - 1;
+        if (lane < K5 / V) wq[ps][j] = *reinterpret_cast<const uint4*>(W + (int64_t)n * K5 + lane * V);
+        bq[ps][j] = load1<T>(b5, n);
+      }
+  }
+  wait_input();
   for (int i = threadIdx.x; i < D / 2; i += blockDim.x) a1[i] = a1g[(int64_t)b * (D / 2) + i];
   __syncthreads();
-  tp_dense<T>(a1, a2, w5, b5, D / 2, D / 4, true);
+  if (pre) {
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int n0 = wid * 4 + ps * nw * 4;
+      if (n0 < N5) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < K5 / V) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float wf[V];
+            tp_unpack<T>(wq[ps][j], wf);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[j] = fmaf(wf[e], a1[lane * V + e], acc[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = wave_sum(acc[j]);
+          if (lane == 0 && n0 + j < N5) a2[n0 + j] = Elem<T>::round(gelu_erf(Elem<T>::round(a + bq[ps][j])));
+        }
+      }
+    }
+    __syncthreads();
+  } else {
+    tp_dense<T>(a1, a2, w5, b5, D / 2, D / 4, true);
+  }
   tp_dense<T>(a2, a3, w7, b7, D / 4, 2, false);
   if (threadIdx.x == 0) {
     if (logits) {
