@@ -488,7 +488,9 @@ struct GuTpArgs {
   int D, call_tag;
 };
 
-template <typename T>
+// MAXC: 16-byte chunks per lane of a stage-1 weight row held in registers (8: H <= 4096, 10: H <= 5120).  With 8 and two passes of stage 2b
+// in flight the kernel needs 121 VGPRs -- four workgroups per CU like the plain projection (135 / 237 VGPRs held three / two).
+template <typename T, int MAXC>
 __global__ __launch_bounds__(kGemvThreads) void gemv_gu_tp_kernel(GuTpArgs a) {
   const int D = a.D, n1 = (D + 7) / 8, n2 = (D / 2 + 7) / 8, side = n1 + n2 + 1;
   const int bid = blockIdx.x, tid = threadIdx.x;
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_gu_tp_kernel(GuTpArgs a) {
   u64_t* g1 = a.gran;
   u64_t* g2 = a.gran + D;
   if (bid < n1) {  // stage 1: needs nothing from this launch
-    tp_stage1_body<T>(a.h, a.K, a.w.ln_w, a.w.ln_b, a.w.l1_w, a.w.l1_b, h1, a.K, D, bid, 0, g1, tag);
+    tp_stage1_body<T, MAXC>(a.h, a.K, a.w.ln_w, a.w.ln_b, a.w.l1_w, a.w.l1_b, h1, a.K, D, bid, 0, g1, tag);
     return;
   }
   bool bad = false;
@@ -592,7 +594,8 @@ extern "C" int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void
     const int grid = (groups < grid_cap ? groups : grid_cap) + side;
     size_t smem = (size_t)K * sizeof(float);  // stage 1 stages the row in fp32; the projection needs K elements of the model dtype
     if (smem < (size_t)2 * d_model * sizeof(float)) smem = (size_t)2 * d_model * sizeof(float);
-    hipLaunchKernelGGL((gemv_gu_tp_kernel<T>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+    if (K / Elem<T>::kVec <= 64 * 8) hipLaunchKernelGGL((gemv_gu_tp_kernel<T, 8>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+    else hipLaunchKernelGGL((gemv_gu_tp_kernel<T, 10>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
   });
   if (rc != DL_OK) return rc;
   DL_CHECK_LAUNCH("dl_gemv_gu_tp");

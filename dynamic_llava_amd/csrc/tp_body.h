@@ -27,11 +27,11 @@ __device__ __forceinline__ void tp_unpack(const uint4& r, float (&f)[Elem<T>::kV
 // ---- text predictor, stage 1: LN(H) + Linear(H -> D) + GELU.  grid (ceil(D/8), B): a wave owns 2 neurons ----
 // Single-instance latency kernel on the decode step's critical path: the weight rows (cold HBM) are requested before the
 // LayerNorm chain starts, x / ln_w / ln_b are 16-byte loads issued together -- one HBM round trip instead of ~5.
-constexpr int kTp1MaxChunks = 10;  // 16-byte chunks per lane per weight row: H <= 64 * 8 * 10 = 5120
+constexpr int kTp1MaxChunks = 10;   // 16-byte chunks per lane per weight row: H <= 64 * 8 * 10 = 5120
 // The stages are device functions (bx / by = the block coordinates of the stand-alone grids) so that dl_gemv_gu_tp can run them as extra
 // workgroups of a projection launch; `gran` != nullptr: every output is also published as a granule {gtag, float bits} for a consumer in
 // the same launch.
-template <typename T>
+template <typename T, int MAXC = kTp1MaxChunks>
 __device__ __forceinline__ void tp_stage1_body(const void* __restrict__ x_, int64_t x_rs, const void* __restrict__ ln_w,
                                                const void* __restrict__ ln_b, const void* __restrict__ w1, const void* __restrict__ b1,
                                                float* __restrict__ h1, int H, int D, const int bx, const int by, u64_t* gran, uint32_t gtag) {
@@ -44,14 +44,14 @@ __device__ __forceinline__ void tp_stage1_body(const void* __restrict__ x_, int6
   const int nvec = H / V;
   const S* W = reinterpret_cast<const S*>(w1);
   const int nb = bx * 8 + wid * 2;  // this wave's 2 neurons
-  uint4 wv[2][kTp1MaxChunks];
-  const bool pre = nvec <= 64 * kTp1MaxChunks;  // else (fp32 at full width): plain streaming loop below
+  uint4 wv[2][MAXC];
+  const bool pre = nvec <= 64 * MAXC;  // else (fp32 at full width): plain streaming loop below
   if (pre) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = nb + j < D ? nb + j : D - 1;
 #pragma unroll
-      for (int c = 0; c < kTp1MaxChunks; ++c)
+      for (int c = 0; c < MAXC; ++c)
         if (lane + 64 * c < nvec) wv[j][c] = *reinterpret_cast<const uint4*>(W + (int64_t)n * H + (lane + 64 * c) * V);
     }
   }
@@ -96,7 +96,7 @@ __device__ __forceinline__ void tp_stage1_body(const void* __restrict__ x_, int6
       }
   }
 #pragma unroll
-  for (int c = 0; c < kTp1MaxChunks; ++c)
+  for (int c = 0; c < MAXC; ++c)
     if (pre && lane + 64 * c < nvec) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -206,42 +206,47 @@ __device__ __forceinline__ void tp_stage2b_body(const float* __restrict__ a1g, c
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int passes = (N5 + nw * 4 - 1) / (nw * 4);
   const bool pre = K5 % V == 0 && K5 / V <= 64 && passes <= 8;
-  uint4 wq[8][4];
-  float bq[8][4];
-  if (pre) {
+  constexpr int PB = 2;  // passes whose weight rows are in flight together: 32 VGPRs (eight at once made dl_gemv_gu_tp a 237-VGPR kernel: two workgroups per CU)
+  uint4 wq[PB][4];
+  float bq[PB][4];
+  auto request = [&](int p0) {
     const S* W = reinterpret_cast<const S*>(w5);
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps)
+    for (int ps = 0; ps < PB; ++ps)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int n = wid * 4 + ps * nw * 4 + j;
+        int n = wid * 4 + (p0 + ps) * nw * 4 + j;
         n = n < N5 ? n : N5 - 1;
         if (lane < K5 / V) wq[ps][j] = *reinterpret_cast<const uint4*>(W + (int64_t)n * K5 + lane * V);
         bq[ps][j] = load1<T>(b5, n);
       }
-  }
+  };
+  if (pre) request(0);
   wait_input();
   for (int i = threadIdx.x; i < D / 2; i += blockDim.x) a1[i] = a1g[(int64_t)b * (D / 2) + i];
   __syncthreads();
   if (pre) {
+    for (int p0 = 0; p0 < passes; p0 += PB) {
+      if (p0 > 0) request(p0);
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int n0 = wid * 4 + ps * nw * 4;
-      if (n0 < N5) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane < K5 / V) {
+      for (int ps = 0; ps < PB; ++ps) {
+        const int n0 = wid * 4 + (p0 + ps) * nw * 4;
+        if (n0 < N5) {
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
+          if (lane < K5 / V) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float wf[V];
+              tp_unpack<T>(wq[ps][j], wf);
+#pragma unroll
+              for (int e = 0; e < V; ++e) acc[j] = fmaf(wf[e], a1[lane * V + e], acc[j]);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float wf[V];
-            tp_unpack<T>(wq[ps][j], wf);
-#pragma unroll
-            for (int e = 0; e < V; ++e) acc[j] = fmaf(wf[e], a1[lane * V + e], acc[j]);
+            const float a = wave_sum(acc[j]);
+            if (lane == 0 && n0 + j < N5) a2[n0 + j] = Elem<T>::round(gelu_erf(Elem<T>::round(a + bq[ps][j])));
           }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a = wave_sum(acc[j]);
-          if (lane == 0 && n0 + j < N5) a2[n0 + j] = Elem<T>::round(gelu_erf(Elem<T>::round(a + bq[ps][j])));
         }
       }
     }
