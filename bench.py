@@ -11,8 +11,10 @@ LLaVA-1.5-7B, bf16, B=1, one synthetic 336x336 image, prompt = 35 system tokens 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: weak scaling, one identical request per rank (weights replicated), one RCCL all-gather of the last-token
-logits + generated ids per step, no collective in the decode loop.  The ranks' results must be identical (FATAL otherwise).
+    python bench.py --gpus N ...        (no launcher: bench.py starts the N ranks itself through torch.distributed.run)
+
+N > 1: weak scaling, one identical request per rank (weights replicated), one RCCL all-gather (a single
+all_gather_into_tensor carrying the last-token logits + generated ids + their shapes) per step, no collective in the decode loop.  The ranks' results must be identical (FATAL otherwise).
 After the timed region an N > 1 run also executes BASELINE configs[3] once (32 ragged requests per rank, one all-gather) and checks
 the gathered rows against a re-run of another rank's chunk.  Rank 0 prints ONE JSON line.
 
@@ -389,8 +391,7 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out, lg = run(ids, am, imgs)
-    all_ids = dd.all_gather_rows(out)
-    all_lg = dd.all_gather_rows(lg)
+    all_lg, all_ids = dd.gather_results(lg, out, max_rows=per, max_new_tokens=new_tokens)  # one all_gather_into_tensor: logits + ids + shapes
     torch.cuda.synchronize()
     dd.barrier()
     el = dd.max_over_ranks(time.perf_counter() - t0, device)
@@ -421,9 +422,13 @@ def main():
     from dynamic_llava_amd.builder import build_random_model
     from dynamic_llava_amd.config import DynamicLlavaConfig
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (the reference forks one process per GPU from a shell loop,
+        # run/dynamic_eval/eval_for_vqav2.sh:11-21); rank 0 of the child job prints the JSON line on the inherited stdout
+        raise SystemExit(dd.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank, world, local = dd.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dtype = torch.bfloat16
@@ -440,9 +445,8 @@ def main():
 
     def step():
         out = model.generate(prompt, images=images, max_new_tokens=T_new, do_sample=False, num_beams=1, use_cache=True, eos_token_id=None)
-        if world > 1:  # DP result = concatenation over ranks (logits of the prefill's last token + generated ids)
-            gathered["logits"] = dd.all_gather_rows(model.last_prefill_logits)
-            gathered["ids"] = dd.all_gather_rows(out)
+        if world > 1:  # DP result = concatenation over ranks (logits of the prefill's last token + generated ids): ONE collective
+            gathered["logits"], gathered["ids"] = dd.gather_results(model.last_prefill_logits, out, max_rows=1, max_new_tokens=T_new)
         return out
 
     for _ in range(args.warmup):

@@ -33,10 +33,15 @@ def _worker(rank, world, port, items, q):
     logits = torch.stack([o[1] for o in outs]) if outs else torch.zeros(0, 16)
     all_ids = dd.all_gather_rows(ids, pad_value=-1)
     all_logits = dd.all_gather_rows(logits)
+    # the product's per-batch collective: logits + ids + true shapes in ONE message, sized by host-known bounds (chunk rule, max_new_tokens)
+    per = -(-len(items) // w)
+    one_lg, one_ids = dd.gather_results(logits, ids, max_rows=per, max_new_tokens=5, pad_token_id=-1)
+    bounded = dd.all_gather_rows(ids, pad_value=-1, max_shape=(per, 5))
     t = dd.max_over_ranks(float(rank + 1), "cpu")
     dd.barrier()
     if rank == 0:
-        q.put((all_ids, all_logits, t))
+        q.put((all_ids.numpy(), all_logits.numpy(), t, bool(  # by value: a shared-memory tensor handle dies with this process
+            torch.equal(one_lg, all_logits) and torch.equal(one_ids, all_ids) and torch.equal(bounded, all_ids))))
     torch.distributed.destroy_process_group()
 
 
@@ -51,7 +56,8 @@ def test_dp_equals_single_process(n_items):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, items, q)) for r in range(2)]
     for p in procs:
         p.start()
-    all_ids, all_logits, t = q.get(timeout=120)
+    all_ids, all_logits, t, one_message_same = q.get(timeout=120)
+    all_ids, all_logits = torch.from_numpy(all_ids), torch.from_numpy(all_logits)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -62,6 +68,59 @@ def test_dp_equals_single_process(n_items):
         assert (all_ids[i, tok.numel() :] == -1).all()
         assert torch.equal(all_logits[i], lg)
     assert t == 2.0
+    assert one_message_same, "gather_results / bounded all_gather_rows (one collective) must equal the two-collective gather"
+
+
+def _count_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from dynamic_llava_amd import dist as dd
+
+    dd.init_distributed("gloo")
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    lg, ids = dd.gather_results(torch.randn(3, 8), torch.arange(6).view(3, 2) + 10 * rank, max_rows=3, max_new_tokens=4)
+    if rank == 0:
+        q.put((len(calls), tuple(lg.shape), ids.tolist()))
+    dd.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_results_is_one_collective():
+    """one all-gather per request batch -- logits, ids and their true shapes travel in a single all_gather_into_tensor."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_count_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_calls, shape, ids = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n_calls == 1 and shape == (6, 8)
+    assert ids == [[0, 1], [2, 3], [4, 5], [10, 11], [12, 13], [14, 15]]
+
+
+def test_forced_world_size_one_collective_runs():
+    """`force=True` really issues the collective at world size 1 (the GPU suite uses it to push a device tensor through RCCL on a 1-GPU box)."""
+    import subprocess
+
+    code = ("import sys; sys.path.insert(0, %r); import torch; from dynamic_llava_amd import dist as dd; import torch.distributed as dist\n"
+            "dd.init_distributed('gloo', force=True); assert dist.is_initialized() and dist.get_world_size() == 1\n"
+            "n = []; real = dist.all_gather_into_tensor; dist.all_gather_into_tensor = lambda *a, **k: (n.append(1), real(*a, **k))[1]\n"
+            "lg, ids = dd.gather_results(torch.randn(2, 4), torch.arange(6).view(2, 3), 2, 5, force=True)\n"
+            "assert len(n) == 1 and lg.shape == (2, 4) and ids.tolist() == [[0, 1, 2], [3, 4, 5]]\n"
+            "x = torch.randn(2, 4); assert dd.all_gather_rows(x) is x  # no force, world 1: no collective\n"
+            "dist.destroy_process_group(); print('ok')" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_get_chunk_matches_reference_rule():

@@ -66,8 +66,7 @@ def _worker(rank, world, port, q):
     ids, logits, lens = _run_chunk(model, prompts, feats, mine)
     torch.cuda.synchronize()
     dd.barrier()
-    all_ids = dd.all_gather_rows(ids)
-    all_logits = dd.all_gather_rows(logits)
+    all_logits, all_ids = dd.gather_results(logits, ids, max_rows=PER_RANK, max_new_tokens=STEPS)  # the product's ONE collective per batch
     all_lens = dd.all_gather_rows(lens)
     # bench.py's builder: every rank must hold identical random-init weights (seeded device generator)
     rm = build_random_model(DynamicLlavaConfig(num_hidden_layers=1, vocab_size=512), dtype=dtype, device="cuda", seed=0, predictor_gain=50.0)
@@ -105,3 +104,63 @@ def test_dp2_real_model_equals_single_process_bit_exact():
     assert res["weights"], "build_random_model must give every rank identical weights"
     assert res["ids"] and res["logits"] and res["lens"], res
     assert res["evicted_some"], "the per-row eviction must be exercised both ways"
+
+
+_NCCL_WS1 = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from dynamic_llava_amd import dist as dd
+for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DL_FORCE_DEVICE", "DL_DIST_BACKEND"):
+    os.environ.pop(k, None)
+rank, world, local = dd.init_distributed("nccl", force=True)   # RCCL process group of ONE rank on cuda:0
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", local)
+n = []
+real = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda *a, **k: (n.append(1), real(*a, **k))[1]
+g = torch.Generator().manual_seed(0)
+logits = torch.randn(32, 32000, generator=g).to(dev)              # configs[3]'s per-rank payload: 32 x 32000 fp32 = 4.1 MB
+ids = torch.randint(0, 32000, (32, 17), generator=g).to(dev)
+lg, tk = dd.gather_results(logits, ids, max_rows=32, max_new_tokens=32, force=True)
+torch.cuda.synchronize()
+assert len(n) == 1, n                                             # one collective carried both tensors
+assert lg.is_cuda and torch.equal(lg, logits) and torch.equal(tk, ids)
+x = torch.arange(12, device=dev, dtype=torch.float32).view(3, 4)
+assert torch.equal(dd.all_gather_rows(x, force=True), x)          # shape exchange + payload, device tensors
+assert dd.max_over_ranks(1.5, dev) == 1.5
+t = torch.tensor([2.0], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 2.0
+dist.barrier(); dist.destroy_process_group()
+print("nccl-ws1-ok")
+"""
+
+
+def test_nccl_backend_world_size_one_pushes_device_tensors_through_rccl():
+    """`backend="nccl"` (RCCL) had never executed.  A 1-GPU box cannot host two RCCL ranks, but a process group of ONE
+    rank loads librccl, creates the communicator on cuda:0 and runs the very collective of the DP path (`gather_results`: one
+    all_gather_into_tensor of logits + ids + shapes) and the timing all-reduce on DEVICE tensors."""
+    import subprocess
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_WS1 % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "nccl-ws1-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_self_launches_two_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no launcher (VERDICT r3 missing #2): bench.py starts its ranks itself.  On this 1-GPU box the two ranks
+    share the device through the DL_FORCE_DEVICE hook (gloo); on the 8-GPU node the same call runs one rank per GPU over RCCL.  A shallow
+    model keeps it short: the JSON line is marked INVALID by bench.py itself, which is fine -- this test checks the launch and the DP legs."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, DL_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "4", "--new-tokens", "8",
+                        "--no-cpu-baseline", "--no-ref-gpu"], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
+    assert res["config"]["dp_rows_identical"] is True
+    assert res["configs3"]["gathered_rows"] == 64 and res["configs3"]["dp_equals_rerun_of_last_rank"] is True
