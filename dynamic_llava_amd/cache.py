@@ -50,7 +50,7 @@ class _LayerViews:
 
 # rows of at most this many keys run as ONE workgroup per (row, head): four prefetched trips of 64 keys with the speculative first request beat
 # four splits + the in-kernel merge (two fabric round trips) -- 9.6 vs 9.9-10.5 us per launch, decode 2.648 -> 2.633 ms/token (A/B on one box)
-_SINGLE_SPLIT_MAX_KEYS = 256
+_SINGLE_SPLIT_MAX_KEYS = int(os.environ.get("DL_SINGLE_SPLIT_MAX_KEYS", "256"))
 
 
 class KVSlabCache:
@@ -76,15 +76,34 @@ class KVSlabCache:
         # shapes the computation (split-KV factor) is derived from the logical capacity, so results do not depend on pooling history
         self.logical_cap = self.t_cap
         self.sparse_cap = self.t_cap  # host-known upper bound of lens[1] (set by the prefill: logical_cap minus the dropped image tokens)
+        # Round 4: what the decode attention is SCHEDULED for (split-KV factor, and with it the fused q|k|v + attention launch) is the number of
+        # keys the steps about to be enqueued can actually attend, not the capacity the request reserved: `full_bound` is exact on the host
+        # (every row grows by one per token), `sparse_bound` = the evicted group's lengths as last OBSERVED on the device (generate(): a
+        # non-blocking copy per chunk of steps, read one chunk late so the queue never drains) + the steps enqueued since.  Reference
+        # semantics being served: the cache only grows where `cache_decision` says so (DML:2377-2391, cache_utils.py:153-164) -- BASELINE
+        # configs[4] reserves 1588 slots in layers >= 2 and fills 259.  None = no tighter bound known (capacities apply).
+        self.full_bound = None
+        self.sparse_bound = None
 
     def n_splits(self, layer_idx: int, rows_times_heads: int, max_splits: int = 32) -> int:
         """Split-KV factor of the decode attention (tools/bench_attn_decode.py sweep): enough workgroups to cover the 256 CUs
         (rows x heads x splits >= 256), never fewer than ~64 keys per workgroup, judged on the host-known length bound."""
-        cap = self.logical_cap if self.group(layer_idx) == 0 else min(self.sparse_cap, self.logical_cap)
+        cap = self.key_bound(self.group(layer_idx))
         want = max(1, 256 // max(1, rows_times_heads))
         if cap <= _SINGLE_SPLIT_MAX_KEYS:
             return 1
         return max(1, min(max_splits, want, -(-cap // 64)))
+
+    def key_bound(self, group: int) -> int:
+        """Host-known upper bound of the keys a decode step enqueued now attends in this length group (new token included)."""
+        if group == 0:
+            return self.logical_cap if self.full_bound is None else min(self.logical_cap, self.full_bound)
+        cap = min(self.sparse_cap, self.logical_cap)
+        return cap if self.sparse_bound is None else min(cap, self.sparse_bound)
+
+    def set_bounds(self, full_bound, sparse_bound):
+        self.full_bound = None if full_bound is None else int(full_bound)
+        self.sparse_bound = None if sparse_bound is None else int(sparse_bound)
 
     @staticmethod
     def spec_chunk(n_splits: int) -> int:
@@ -129,6 +148,7 @@ class KVSlabCache:
         self.slab = new
         self.sparse_cap += new_cap - self.t_cap
         self.logical_cap += new_cap - self.t_cap
+        self.full_bound = self.sparse_bound = None
         self.t_cap = new_cap
         self.k = [self.slab[i, 0] for i in range(self.n_layers)]
         self.v = [self.slab[i, 1] for i in range(self.n_layers)]

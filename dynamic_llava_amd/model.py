@@ -415,6 +415,10 @@ class _DecodeState:
         # dl_gemv_qkv_attn's granules (batch 1, 16-bit dtypes at the decoder widths the kernel takes)
         self.qa_gran = ops.gemv_qkv_attn_workspace(nH, nKV, d, device) if (B == 1 and dtype in (torch.bfloat16, torch.float16) and d in (64, 128) and H * 2 <= 48 * 1024) else None
         self.blk_err = torch.zeros(1, dtype=torch.int32, device=device)
+        # generate(): ring of pinned host words [lens (2 x B) | finished (B)] + events -- the decode loop observes the evicted lengths and the
+        # EOS flags with non-blocking copies and reads them one chunk of steps late (the launch queue never drains)
+        self.obs_host = torch.empty((4, 3 * B), dtype=torch.int32).pin_memory()
+        self.obs_ev = [torch.cuda.Event() for _ in range(4)]
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
 
 
@@ -871,6 +875,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cache.full_len_host = list(p["lens"])
         cache.seen_tokens = max(p["lens"])
         cache.sparse_cap = cache.logical_cap - (max(p["lens"]) - max(p["lens2"])) - p["instruct_drop"]  # host-known upper bound of the evicted group's lengths
+        cache.prefill_sparse_max = max(p["lens2"]) - p["instruct_drop"]  # longest row of layers >= sparse_layer after the prefill (upper bound when the instruct compaction stayed on the device)
+        cache.set_bounds(None, None)
         if p["instruct_drop"]:  # DML:2365-2375
             for ix in indices:
                 ix["instruct"][1] -= p["instruct_drop"]
@@ -1066,6 +1072,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         c.seen_tokens = 0
         c.logical_cap = int(t_need)  # a pooled (possibly larger) slab must compute exactly like a fresh one of the requested size
         c.sparse_cap = c.logical_cap
+        c.set_bounds(None, None)
         return c
 
     def _get_dstate(self, B, out_cap):
@@ -1112,7 +1119,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
             g, _ = self._capture(lambda: self._decode_step_kernels(st, cache, True), warm)
             st.cur_ids.copy_(snap[0]); st.out_ids.copy_(snap[1]); st.step.copy_(snap[2]); st.finished.copy_(snap[3]); cache.lens.copy_(snap[4]); st.decision.copy_(snap[5])
-            if len(st.graphs) >= 6:
+            if len(st.graphs) >= 12:  # a long generation walks through a few split factors as its rows grow (one capture each)
                 st.graphs.pop(next(iter(st.graphs)))
             st.graphs[key] = g
         for _ in range(n_steps):
@@ -1152,6 +1159,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._rope_tables(max(cache.full_len_host) + 2)
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
+            # schedule: the un-evicted group's length is exact on the host; the evicted group's would need a device->host copy per call, so this
+            # eager path keeps its capacity bound (generate() observes the device lengths chunk by chunk instead)
+            cache.set_bounds(max(cache.full_len_host) + 1, None)
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
             if st.qa_gran is not None:
                 st.qa_gran.zero_()
@@ -1538,15 +1548,44 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if want_scores:
             _score(0)
             sync_every = 1
-        produced = 1
-        while produced < max_new:
-            n = min(sync_every, max_new - produced)
+        # ---- decode loop: chunks of captured steps, scheduled from the lengths the predictor actually leaves (DML:2377-2391, CU:153-164) ----
+        # Before a chunk the host knows: the un-evicted group's length exactly, and the evicted group's as OBSERVED after an earlier chunk
+        # (non-blocking copy into pinned memory, consumed one chunk late so that the host never waits for steps it has just enqueued) plus
+        # the steps enqueued since.  Those bounds pick the split-KV factor / the fused q|k|v+attention launch (cache.n_splits), i.e. which
+        # captured graph is replayed; the values are data, never timing, so the schedule is deterministic for a given request.
+        produced, chunks = 1, 0
+        full0 = max(cache.full_len_host)
+        sparse_obs, obs_at = getattr(cache, "prefill_sparse_max", None), 1
+        if sparse_obs is None:
+            sparse_obs = full0
+        pending = []  # (ring slot, produced-when-copied)
+        all_done = False
+        while produced < max_new and not all_done:
+            n = min(sync_every if chunks >= 2 else min(sync_every, 4), max_new - produced)  # short first chunks: an early EOS is seen early
+            # EOS of a short answer (VQA: a few tokens) must not cost two chunks of wasted steps: the first chunks are observed blocking
+            # (one ~50 us queue drain each), later ones one chunk late
+            keep_newest = 0 if (eos_ids and chunks <= 2) else 1
+            while len(pending) > keep_newest:
+                slot, at = pending.pop(0)
+                st.obs_ev[slot].synchronize()
+                row = st.obs_host[slot]
+                sparse_obs, obs_at = int(row[B : 2 * B].max()), at
+                if eos_ids and int(row[2 * B :].min()) != 0:
+                    all_done = True
+            if all_done:
+                break
+            cache.set_bounds(full0 + produced - 1 + n, sparse_obs + (produced - obs_at) + n)
             self._run_decode_steps(st, cache, n)
             produced += n
+            chunks += 1
             if want_scores:
                 _score(produced - 1)
-            if eos_ids and produced < max_new and bool(st.finished.min().item()):
-                break
+            if produced < max_new:
+                slot = chunks % 4
+                st.obs_host[slot, : 2 * B].copy_(cache.lens.view(-1), non_blocking=True)
+                st.obs_host[slot, 2 * B :].copy_(st.finished, non_blocking=True)
+                st.obs_ev[slot].record()
+                pending.append((slot, produced))
         if B == 1:
             self.check_block_decode()
         if dev_layout and int(ent["didx"]["err"].item()) != 0:
