@@ -84,15 +84,19 @@ class KVSlabCache:
         # configs[4] reserves 1588 slots in layers >= 2 and fills 259.  None = no tighter bound known (capacities apply).
         self.full_bound = None
         self.sparse_bound = None
+        # rows of at most this many keys run ONE workgroup per (row, head).  The model raises it for batch-1 decoding on the fused
+        # q|k|v + attention launch, where the slab part of the attention hides under the weight stream (tools/bench_qkv_attn.py)
+        self.single_split_max_keys = _SINGLE_SPLIT_MAX_KEYS
+        self.min_keys_per_split = 64  # a split workgroup is given at least this many keys (tests lower it to force split launches on tiny rows)
 
     def n_splits(self, layer_idx: int, rows_times_heads: int, max_splits: int = 32) -> int:
         """Split-KV factor of the decode attention (tools/bench_attn_decode.py sweep): enough workgroups to cover the 256 CUs
         (rows x heads x splits >= 256), never fewer than ~64 keys per workgroup, judged on the host-known length bound."""
         cap = self.key_bound(self.group(layer_idx))
         want = max(1, 256 // max(1, rows_times_heads))
-        if cap <= _SINGLE_SPLIT_MAX_KEYS:
+        if cap <= self.single_split_max_keys:
             return 1
-        return max(1, min(max_splits, want, -(-cap // 64)))
+        return max(1, min(max_splits, want, -(-cap // self.min_keys_per_split)))
 
     def key_bound(self, group: int) -> int:
         """Host-known upper bound of the keys a decode step enqueued now attends in this length group (new token included)."""

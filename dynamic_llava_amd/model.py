@@ -435,6 +435,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self._rope = None
         self._dstate = None
         self._prefill_graphs = {}
+        self._prefill_pool = None
+        # captured prefill shapes kept (LRU).  288 GB of HBM: the graphs share one memory pool, an entry costs its static inputs (~0.7 MB of
+        # pixels) and the graph object
+        self.max_prefill_graphs = 64
         self.use_hip_graph = True
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
@@ -455,6 +459,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
         if os.environ.get("DL_SMALLM_MAX_B"):  # tuning experiments only
             self.smallm_max_decode_batch = int(os.environ["DL_SMALLM_MAX_B"])
+        self.record_timing = False  # generate(): HIP events around the prefill / decode parts -> self.last_timing (tools/bench_varlen_stream.py)
+        self.last_timing = None
+        self.single_split_keys_override = None  # tests only: see _single_split_max_keys
+        self.min_keys_per_split = 64  # tests only: KVSlabCache.min_keys_per_split of the caches this model schedules
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
         self.eval()
 
@@ -1075,6 +1083,28 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         c.set_bounds(None, None)
         return c
 
+    def _single_split_max_keys(self, st) -> int:
+        """Largest row (keys) that runs as ONE attention workgroup per head.  Stand-alone launch: 256 (cache.py).  Inside dl_gemv_qkv_attn the
+        slab part of the attention runs while the q|k|v weights still stream, so the break-even against `dl_gemv` + a split launch moves out with
+        the stream's length (tools/bench_qkv_attn.py, 1x MI355X: 7B -- 100.7 MB, 17.6 us -- one launch 26.9 vs 27.5 us at 350 keys, 27.6 vs 27.3 at
+        400; 13B -- 157 MB, 28.1 us -- 36.2 vs 37.7 at 512, 37.7 vs 38.9 at 640): 384 keys per 100 MB of q|k|v weights, in steps of 64."""
+        from .cache import _SINGLE_SPLIT_MAX_KEYS
+        if self.single_split_keys_override is not None:  # tests: force the schedule to change inside a short generation
+            return int(self.single_split_keys_override)
+        if not (self.fuse_qkv_attn and st.B == 1 and st.use_gemv and st.qa_gran is not None and not self._block_ok(st)):
+            return _SINGLE_SPLIT_MAX_KEYS
+        w = self.model.layers[0].w_qkv
+        keys = int(384 * (w.numel() * w.element_size()) / 100.7e6) // 64 * 64
+        return max(_SINGLE_SPLIT_MAX_KEYS, min(768, keys))
+
+    def _evict_prefill_entries(self):
+        """Bound the prefill-shape cache: at most `max_prefill_graphs` captured graphs and as many seen-once entries (oldest first)."""
+        cap = self.max_prefill_graphs
+        graphs = [k for k, e in self._prefill_graphs.items() if e["graph"] is not None]
+        seen = [k for k, e in self._prefill_graphs.items() if e["graph"] is None]
+        for k in graphs[: max(0, len(graphs) - cap + 1)] + seen[: max(0, len(seen) - cap + 1)]:
+            self._prefill_graphs.pop(k)
+
     def _get_dstate(self, B, out_cap):
         st = self._dstate
         if st is None or st.B != B or st.out_ids.shape[1] < out_cap:
@@ -1155,6 +1185,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 return self._forward_chunk(input_ids, attention_mask, cache)
             B = input_ids.shape[0]
             st = self._get_dstate(B, 0)
+            cache.single_split_max_keys, cache.min_keys_per_split = self._single_split_max_keys(st), self.min_keys_per_split
             cache.ensure_capacity(2)
             self._rope_tables(max(cache.full_len_host) + 2)
             st.cur_ids.copy_(input_ids[:, 0])
@@ -1445,10 +1476,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             return self._generate_on_cache(inputs, images, **kwargs)
         attention_mask = kwargs.get("attention_mask")
         image_features = kwargs.get("image_features")
-        sync_every = int(kwargs.get("sync_every", 16))
+        sync_every = int(kwargs.get("sync_every", os.environ.get("DL_SYNC_EVERY", 8)))  # decode steps enqueued between two observations of the device state
         want_dict = bool(kwargs.get("return_dict_in_generate"))
         want_scores = want_dict and bool(kwargs.get("output_scores"))
         inputs = inputs.to(self.device)
+        tm = None
+        if self.record_timing:
+            tm = {"ev": [torch.cuda.Event(enable_timing=True) for _ in range(3)], "path": None}
+            tm["ev"][0].record()
         n_feat = self._n_feat(images, image_features)
         sc_ = self.config.sparse_config
         vp_ = getattr(self.model, "image_score_predictor", None)
@@ -1474,6 +1509,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cache = self._pooled_cache(B, max(lens) + max_new + 1)
         self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)
+        cache.single_split_max_keys, cache.min_keys_per_split = self._single_split_max_keys(st), self.min_keys_per_split
         st.step.zero_(); st.finished.zero_(); st.decision.fill_(1)
         # the in-kernel split merge of the decode attention validates its granules by tag = (position of the new token, layer): within one
         # request positions only grow, so a slot left by an earlier step never matches -- but a slot left by an EARLIER REQUEST at the same
@@ -1493,16 +1529,21 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         vp = getattr(self.model, "image_score_predictor", None)
         hooked = vp is not None and (len(vp._forward_hooks) or len(vp._forward_pre_hooks))
         graphable = self.use_hip_graph and self.debug_records is None and not hooked  # (the instruct predictor's data-dependent row count stays on the device)
+        prefill_path = "eager"
         if graphable:
+            # the instruct predictor's compaction span is baked into the captured plan, and `sig` ignores token values: two
+            # equally long multi-turn prompts whose last "USER:" sits elsewhere must not share a graph
+            li_key = tuple(tuple(ix["last_instruct"]) for ix in indices) if self._instruct_on(indices, B) else None
             key = (lay["sig"], None if images is None else tuple(images.shape), None if image_features is None else tuple(image_features.shape),
-                   cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new, repr(self.config.sparse_config))
+                   cache.slab.data_ptr(), cache.t_cap, self._rope[0].data_ptr(), self._eos, self._pad, min_new, repr(self.config.sparse_config), li_key)
             ent = self._prefill_graphs.get(key)
             if ent is None:
-                if len(self._prefill_graphs) >= 8:
-                    self._prefill_graphs.pop(next(iter(self._prefill_graphs)))
+                # first sighting of a prompt shape: run it eagerly ONCE, through the same closure a capture would record (a request stream
+                # such as the VQA loader's, VQAL:123-196, presents many widths; capturing each on sight cost two prefills + a capture per miss)
+                self._evict_prefill_entries()
                 ent = dict(ids=inputs.contiguous().clone(), images=None if images is None else images.to(self.device).clone(),
                            feats=None if image_features is None else image_features.to(self.device).clone(),
-                           plan=self._plan_prefill(lens, indices), indices=copy.deepcopy(indices))
+                           plan=self._plan_prefill(lens, indices), indices=copy.deepcopy(indices), graph=None)
                 ent["plan"]["device_instruct"] = True
                 if dev_layout:
                     ent["didx"] = ops.prompt_layout(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
@@ -1510,7 +1551,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 else:
                     ent["didx"] = self._dev_idx(lay)
 
-                def run():
+                def run(ent=ent, lay=lay, dev_layout=dev_layout, n_feat=n_feat, min_new=min_new, cache=cache, st=st):
                     if dev_layout:
                         ops.prompt_layout_into(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS, ent["didx"])
                     f = ent["feats"] if ent["feats"] is not None else (self.encode_images(ent["images"]) if ent["images"] is not None else None)
@@ -1518,16 +1559,33 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     x = self._prefill_run(ent["plan"], emb, cache, copy.deepcopy(ent["indices"]), True)
                     self._first_token(st, x, min_new)
 
-                ent["graph"], _ = self._capture(run, run)
+                ent["run"] = run
                 self._prefill_graphs[key] = ent
+                st.step.zero_(); st.finished.zero_()
+                run()
             else:
+                self._prefill_graphs[key] = self._prefill_graphs.pop(key)  # most recently used last
                 ent["ids"].copy_(inputs)
                 if images is not None:
                     ent["images"].copy_(images)
                 if image_features is not None:
                     ent["feats"].copy_(image_features)
-            st.step.zero_(); st.finished.zero_()
-            ent["graph"].replay()
+                if ent["graph"] is None:
+                    # second sighting: capture (the eager run of the first sighting was the warm-up: library heuristics, allocator); all
+                    # prefill graphs record into ONE memory pool -- they never run concurrently and leave nothing behind in it (logits, ids
+                    # and K/V land in persistent buffers), so a hundred cached shapes cost one shape's activations
+                    prefill_path = "graph-capture"
+                    if self._prefill_pool is None:
+                        self._prefill_pool = torch.cuda.graph_pool_handle()
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_, pool=self._prefill_pool):
+                        ent["run"]()
+                    ent["graph"] = g_
+                    ent["run"] = None
+                else:
+                    prefill_path = "graph-replay"
+                st.step.zero_(); st.finished.zero_()
+                ent["graph"].replay()
             self._prefill_host_update(ent["plan"], cache, indices)
         else:
             f = image_features if image_features is not None else (self.encode_images(images) if images is not None else None)
@@ -1535,6 +1593,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             x, cache, _, _ = self._prefill(embeds, lens, indices, cache, reserve=max_new + 1, last_only=True)
             self._first_token(st, x, min_new)
         self.last_prefill_logits = self._prefill_logits_buf
+        if tm is not None:
+            tm["ev"][1].record()
+            tm["path"] = prefill_path
         scores = []
 
         eos_ids = [] if self._eos == -1 else (list(self._eos) if isinstance(self._eos, tuple) else [self._eos])
@@ -1583,7 +1644,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if produced < max_new:
                 slot = chunks % 4
                 st.obs_host[slot, : 2 * B].copy_(cache.lens.view(-1), non_blocking=True)
-                st.obs_host[slot, 2 * B :].copy_(st.finished, non_blocking=True)
+                if eos_ids:
+                    st.obs_host[slot, 2 * B :].copy_(st.finished, non_blocking=True)
                 st.obs_ev[slot].record()
                 pending.append((slot, produced))
         if B == 1:
@@ -1608,6 +1670,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 out = out[:, : first + 1]
                 scores = scores[: first + 1]
         self.last_cache = cache
+        if tm is not None:
+            tm["ev"][2].record()
+            tm["new_tokens"] = int(out.shape[1])
+            self.last_timing = tm
         if want_dict:
             # the caller keeps this cache (the reference returns an independent one per call): detach it from the pool, the next
             # generate() allocates a fresh slab instead of overwriting this one

@@ -161,6 +161,35 @@ def test_generate_greedy_matches_reference_golden(golden_dir):
     np.testing.assert_array_equal(out3.cpu().numpy()[0], g["ids"][: first + 1, 0])
 
 
+def test_generate_schedule_follows_observed_lengths_and_matches_reference_golden(golden_dir):
+    """Round 4: the decode attention is scheduled from the lengths the predictor actually leaves (observed on the device chunk by chunk), not
+    from the reserved capacity -- so ONE generate() call replays several captured graphs (single-workgroup rows first, split-KV + in-kernel
+    merge once the evicted group's bound passes the threshold).  Thresholds are lowered so that the switch happens inside the golden's
+    16 tokens; tokens and KV lengths must still equal the reference's (DML:2377-2391, cache_utils.py:153-164)."""
+    name = "tiny_fp32_b1_greedy"
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    n = g["ids"].shape[0]
+    n_sparse0 = int(g["len_last"][0][0])  # layers >= sparse_layer after the prefill
+    model.single_split_keys_override = n_sparse0 + 6
+    model.min_keys_per_split = 8
+    for sync_every in (8, 3):
+        model._dstate = None
+        out = model.generate(ids, images=images, max_new_tokens=n, do_sample=False, num_beams=1, use_cache=True, eos_token_id=None, sync_every=sync_every)
+        np.testing.assert_array_equal(out.cpu().numpy()[0], g["ids"][:, 0])
+        np.testing.assert_array_equal(model.last_cache[1][-1].numpy(), g["len_last"][n - 1])
+        np.testing.assert_array_equal(model.last_cache[1][0].numpy(), g["len_first"][n - 1])
+        splits = sorted({k[3] for k in model._dstate.graphs})  # (layers < sparse_layer, layer sparse_layer, last layer) split factors of each captured step
+        assert any(s[2] == 1 for s in splits) and any(s[2] > 1 for s in splits), f"one call must have replayed both schedules: {splits}"
+        print(f"sync_every={sync_every}: captured decode graphs by split factors {splits}")
+    # the same request again: same observations -> same schedule -> bit-identical
+    out2 = model.generate(ids, images=images, max_new_tokens=n, eos_token_id=None, sync_every=3)
+    assert torch.equal(out, out2)
+
+
 def test_batched_ragged_rows_equal_their_b1_runs():
     """SURVEY finding 2: the reference's B>1 decode attends zero-padded slots; parity for batches is defined per
     row against the B=1 reference.  Ragged prompts + per-row eviction, packed varlen, vs three oracle B=1 runs."""
@@ -330,6 +359,37 @@ def test_instruct_predictor_generate_equals_reference_golden(golden_dir):
         model.generate(ids.repeat(2, 1), images=images.repeat(2, 1, 1, 1), max_new_tokens=2)
 
 
+def test_instruct_prefill_graph_is_not_shared_between_prompts_with_different_last_user_offsets():
+    """the instruct predictor compacts the LAST instruct span (from the last "USER:" match, ARCH:418-454, DML:2261-2375); the
+    span is part of the captured plan while the graph key ignored token values.  Two equally long prompts whose last "USER:" sits at different
+    offsets must each equal the oracle, in either order, through first sighting, capture and replay."""
+    from dynamic_llava_amd.model import USER_IDS
+
+    c, dtype, cfg, sd, clip = _golden_setup("tiny_fp32_userprompt")
+    model = _build(cfg, sd, clip, dtype)
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    base = fx.make_prompt(cfg, 5, 26, seed=4)
+    img_pos = int((base == -200).nonzero()[0])
+    prompts = []
+    for off in (3, 15):
+        p_ = base.clone()
+        p_[img_pos + 1 + off], p_[img_pos + 2 + off] = USER_IDS[0], USER_IDS[1]
+        prompts.append(p_[None])
+    o = Oracle(cfg, sd, dtype, clip=clip)
+    refs = []
+    for p_ in prompts:
+        ref, _ = o.greedy(p_, images=images.cpu(), max_new_tokens=6, eos_token_id=None)
+        refs.append((ref.tolist(), None))
+    kept = []
+    for rnd in range(3):  # first sighting, capture, replay -- alternating the two prompts
+        for p_, (ref, _) in zip(prompts, refs):
+            out = model.generate(p_.cuda(), images=images, max_new_tokens=6, eos_token_id=None)
+            assert out.cpu().tolist() == ref, f"round {rnd}: a prompt ran on the other prompt's instruct span"
+            kept.append(int(model.last_cache[1][-1][0]))
+    assert len({k for k in model._prefill_graphs}) == 2, "one cached prefill per last-instruct span"
+    print("kept KV lengths (layers >= sparse_layer) per call:", kept)
+
+
 @pytest.mark.parametrize("name", ["tiny_fp32_instruct", "tiny_bf16_instruct", "tiny_fp32_userprompt"])
 def test_instruct_prefill_is_captured_and_matches_the_eager_path(name, golden_dir):
     """the instruct predictor's prefill compaction (DML:2261-2375) keeps its data-dependent row count on the device
@@ -341,14 +401,19 @@ def test_instruct_prefill_is_captured_and_matches_the_eager_path(name, golden_di
     ids = torch.from_numpy(g["input_ids"]).cuda()
     images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
     res = {}
-    for graph in (False, True, True):
+    model.record_timing = True
+    paths = []
+    for graph in (False, True, True, True):  # host-side eager path; then first sighting (run once eagerly, on the device-side plan), capture, replay
         model.use_hip_graph = graph
         out = model.generate(ids, images=images, max_new_tokens=8, eos_token_id=None)
         lens = model.last_cache[1]
+        paths.append(model.last_timing["path"])
         res.setdefault(graph, []).append((out.cpu(), int(lens[0][0]), int(lens[-1][0]), model.last_prefill_logits.float().cpu().clone()))
-    assert len(model._prefill_graphs) == 1, "the instruct prefill must have been captured"
-    e, g1, g2 = res[False][0], res[True][0], res[True][1]
-    assert torch.equal(g1[0], g2[0]) and g1[1:3] == g2[1:3] and torch.equal(g1[3], g2[3]), "replays differ"
+    assert paths == ["eager", "eager", "graph-capture", "graph-replay"], paths
+    assert len(model._prefill_graphs) == 1 and next(iter(model._prefill_graphs.values()))["graph"] is not None, "the instruct prefill must have been captured"
+    e, g1, g2, g3 = res[False][0], res[True][0], res[True][1], res[True][2]
+    for gx in (g2, g3):
+        assert torch.equal(g1[0], gx[0]) and g1[1:3] == gx[1:3] and torch.equal(g1[3], gx[3]), "first sighting / capture / replay differ"
     assert g1[1:3] == e[1:3], (g1[1:3], e[1:3])
     if dtype == torch.float32:
         assert torch.equal(g1[0], e[0])

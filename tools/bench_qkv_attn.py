@@ -8,7 +8,8 @@ from dynamic_llava_amd import hip_ops as ops
 from oracle.ref_cpu import rope_table
 
 dev, dt = "cuda", torch.bfloat16
-nH, d, H = 32, 128, 4096
+nH, d, H = (40, 128, 5120) if "--13b" in sys.argv else (32, 128, 4096)
+sys.argv = [a for a in sys.argv if a != "--13b"]
 N = 3 * H
 NB = 8
 
@@ -40,6 +41,7 @@ for T in ([int(a) for a in sys.argv[1:]] or [200, 250, 60]):
     lens = torch.tensor([T - 1], dtype=torch.int32, device=dev)
     gran = ops.gemv_qkv_attn_workspace(nH, nH, d, dev)
     it = [0]
+    tagc = [0]
 
     def two(kif):
         def f():
@@ -48,15 +50,23 @@ for T in ([int(a) for a in sys.argv[1:]] or [200, 250, 60]):
             ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, None, 1, nH, nH, d, keys_in_flight=kif, chunk_keys=256)
         return f
 
+    aws = ops.attn_decode_workspace(1, nH, d, 32, dev)
+
+    def two_split(ns):
+        def f():
+            i = it[0] = (it[0] + 1) % NB
+            tagc[0] = (tagc[0] + 1) % 251
+            ops.gemv(ws[i], qkv, mode=ops.GEMV_ADDNORM, h_in=h0, h_out=ho, delta=delta, norm_w=nw, eps=1e-5)
+            ops.attn_decode_rope(qkv, cos, sin, lens, lens, ks[i], vs[i], out, aws, ns, nH, nH, d, keys_in_flight=64, chunk_keys=0, call_tag=tagc[0])
+        return f
+
     def gemv_only():
         i = it[0] = (it[0] + 1) % NB
         ops.gemv(ws[i], qkv, mode=ops.GEMV_ADDNORM, h_in=h0, h_out=ho, delta=delta, norm_w=nw, eps=1e-5)
-
-    tagc = [0]
 
     def fused():
         i = it[0] = (it[0] + 1) % NB
         tagc[0] = (tagc[0] + 1) % 251
         ops.gemv_qkv_attn(ws[i], qkv, h0, ho, delta, nw, 1e-5, cos, sin, lens, lens, ks[i], vs[i], out, gran, tagc[0], nH, nH, d)
 
-    print(f"T={T}: q|k|v gemv alone {timed(gemv_only):6.2f} us | + attention (4 waves) {timed(two(64)):6.2f} us | + attention (8 waves) {timed(two(128)):6.2f} us | one launch {timed(fused):6.2f} us", flush=True)
+    print(f"T={T}: q|k|v gemv alone {timed(gemv_only):6.2f} us | + attention (4 waves) {timed(two(64)):6.2f} us | + attention (8 waves) {timed(two(128)):6.2f} us | one launch {timed(fused):6.2f} us | + split attention (n_splits = min(256 // nH, ceil(T / 64)) = {max(1, min(256 // nH, -(-T // 64)))}, in-kernel merge) {timed(two_split(max(1, min(256 // nH, -(-T // 64))))):6.2f} us", flush=True)
