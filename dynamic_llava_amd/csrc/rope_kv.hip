@@ -15,9 +15,10 @@ __global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
     int64_t stride_h, int T_cap, int B, int nH, int nKV, int d) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
-  __shared__ int sh[3];
+  __shared__ int sh[4];
   const int t = blockIdx.x;
   if (threadIdx.x == 0) {
+    sh[3] = t < cu[B];  // a launch sized for a width bucket: rows past the last sequence are padding (nothing to rotate or append)
     int lo = 0, hi = B;  // find b with cu[b] <= t < cu[b+1]
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
     sh[2] = kv_base[lo] + j;
   }
   __syncthreads();
+  if (!sh[3]) return;
   const int b = sh[0], p = sh[1], slot = sh[2];
   const int row_w = (nH + 2 * nKV) * d;
   S* row = reinterpret_cast<S*>(qkv_) + (int64_t)t * row_w;

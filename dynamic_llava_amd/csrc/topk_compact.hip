@@ -292,54 +292,79 @@ namespace dl {
 __global__ __launch_bounds__(256) void prompt_layout_kernel(const int64_t* __restrict__ ids, int W, int n_feat, int image_token, int u0, int u1,
                                                              int32_t* __restrict__ seg, int64_t* __restrict__ text_src,
                                                              int64_t* __restrict__ text_dst, int64_t* __restrict__ img_dst,
-                                                             int32_t* __restrict__ img_start, int32_t* __restrict__ err) {
+                                                             int32_t* __restrict__ img_start, int32_t* __restrict__ err,
+                                                             const int32_t* __restrict__ w_true, int n_drop, int32_t* __restrict__ cu,
+                                                             int32_t* __restrict__ cu2, int32_t* __restrict__ lens, int64_t* __restrict__ last_rows) {
   __shared__ int s_pos, s_cnt, s_user;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
   const int64_t* row = ids + (int64_t)b * W;
+  // `w_true` (device scalar): only the first Wt of the W columns are the prompt (the buffer is a width BUCKET shared by prompts of several
+  // widths: one captured prefill graph serves them all).  The sequences are packed at their TRUE lengths; the (W - Wt) columns of padding are
+  // sent to the unused rows at the end of the packed matrix.
+  int Wt = w_true ? w_true[0] : W;
+  Wt = Wt < 1 ? 1 : (Wt > W ? W : Wt);
   if (tid == 0) {
-    s_pos = W;
+    s_pos = Wt;
     s_cnt = 0;
     s_user = -1;
   }
   __syncthreads();
-  for (int c = tid; c < W; c += 256)
+  for (int c = tid; c < Wt; c += 256)
     if (row[c] == (int64_t)image_token) {
       atomicMin(&s_pos, c);
       atomicAdd(&s_cnt, 1);
     }
   __syncthreads();
-  const int p = s_pos < W ? s_pos : 0;
-  // last "USER:" pair inside the instruct span (columns p+1 .. W-1), as an offset from its start (ARCH:418-454 with no labels: the
+  const int p = s_pos < Wt ? s_pos : 0;
+  // last "USER:" pair inside the instruct span (columns p+1 .. Wt-1), as an offset from its start (ARCH:418-454 with no labels: the
   // span runs to the end of the row)
-  for (int c = p + 1 + tid; c + 1 < W; c += 256)
+  for (int c = p + 1 + tid; c + 1 < Wt; c += 256)
     if (row[c] == (int64_t)u0 && row[c + 1] == (int64_t)u1) atomicMax(&s_user, c - (p + 1));
   __syncthreads();
-  const int n_row = W - 1 + n_feat;  // packed rows of this sequence
+  const int n_row = Wt - 1 + n_feat;  // packed rows of this sequence
   const int64_t base = (int64_t)b * n_row;
+  const int64_t trash = (int64_t)B * n_row + (int64_t)b * (W - Wt);  // first unused packed row given to this sequence's padding columns
   for (int c = tid; c < W; c += 256) {
     if (c == p) continue;
-    const int j = c < p ? c : c - 1;  // index among the text tokens
-    text_src[(int64_t)b * (W - 1) + j] = (int64_t)b * W + c;
-    text_dst[(int64_t)b * (W - 1) + j] = base + (c < p ? c : c - 1 + n_feat);
+    const int j = c < p ? c : c - 1;  // index among the W - 1 non-image columns
+    const bool pad = c >= Wt;
+    text_src[(int64_t)b * (W - 1) + j] = (int64_t)b * W + (pad ? 0 : c);  // padding gathers column 0's (valid) token
+    text_dst[(int64_t)b * (W - 1) + j] = pad ? trash + (c - Wt) : base + (c < p ? c : c - 1 + n_feat);
   }
   for (int i = tid; i < n_feat; i += 256) img_dst[(int64_t)b * n_feat + i] = base + p + i;
   if (tid == 0) {
     seg[b * 8 + 0] = p;
     seg[b * 8 + 1] = s_user < 0 ? 0 : s_user;
     seg[b * 8 + 2] = s_cnt;
-    seg[b * 8 + 3] = W;
+    seg[b * 8 + 3] = Wt;
     img_start[b] = p;
     if (s_cnt != 1) atomicMax(err, 1 + b);
+    // the prefill plan's device-side metadata at the TRUE lengths (the captured launches are sized for the bucket and read these)
+    const int n2 = n_row - n_drop;  // rows per sequence in layers >= sparse_layer
+    if (cu) {
+      cu[b] = b * n_row;
+      if (b == B - 1) cu[B] = B * n_row;
+    }
+    if (cu2) {
+      cu2[b] = b * n2;
+      if (b == B - 1) cu2[B] = B * n2;
+    }
+    if (lens) {
+      lens[b] = n_row;
+      lens[B + b] = n2;
+    }
+    if (last_rows) last_rows[b] = (int64_t)(b + 1) * n2 - 1;
   }
 }
 }  // namespace dl
 
 extern "C" int dl_prompt_layout(const int64_t* input_ids, int B, int W, int n_feat, int image_token, int user_id0, int user_id1, int32_t* seg,
-                                int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, void* stream) {
+                                int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, const int32_t* w_true,
+                                int n_drop, int32_t* cu_seqlens, int32_t* cu_seqlens_sparse, int32_t* lens, int64_t* last_rows, void* stream) {
   DL_REQUIRE(input_ids && seg && text_src && text_dst && img_dst && img_start && err, "dl_prompt_layout: NULL pointer");
-  DL_REQUIRE(B > 0 && W > 0 && n_feat >= 0, "dl_prompt_layout: bad shape");
+  DL_REQUIRE(B > 0 && W > 0 && n_feat >= 0 && n_drop >= 0 && n_drop <= n_feat, "dl_prompt_layout: bad shape");
   hipLaunchKernelGGL(dl::prompt_layout_kernel, dim3((unsigned)B), dim3(256), 0, dl::as_stream(stream), input_ids, W, n_feat, image_token, user_id0,
-                     user_id1, seg, text_src, text_dst, img_dst, img_start, err);
+                     user_id1, seg, text_src, text_dst, img_dst, img_start, err, w_true, n_drop, cu_seqlens, cu_seqlens_sparse, lens, last_rows);
   DL_CHECK_LAUNCH("dl_prompt_layout");
   return DL_OK;
 }

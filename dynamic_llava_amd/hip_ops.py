@@ -106,7 +106,7 @@ SIGNATURES = {
     "dl_gumbel_hard_keep_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
     "dl_gumbel_hard_keep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p]),
     "dl_kv_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dl_compact_rows_by_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dl_decode_block_sync_bytes": (c_int64, [c_int]),
     "dl_decode_block": (c_int, [POINTER(BlockPhase), c_int, c_void_p, c_int64, c_void_p, c_int, ctypes.c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -709,10 +709,16 @@ def prompt_layout(input_ids, n_feat, image_token, user_ids):
     return out
 
 
-def prompt_layout_into(input_ids, n_feat, image_token, user_ids, out):
+def prompt_layout_into(input_ids, n_feat, image_token, user_ids, out, w_true=None, n_drop=0, cu=None, cu2=None, lens=None, last_rows=None):
+    """`w_true` (int32 device scalar): the row buffer is a width bucket, only its first w_true columns are the prompt; `cu` / `cu2` int32 [B+1],
+    `lens` int32 [2, B], `last_rows` int64 [B]: the prefill plan's device metadata, written at the true lengths (include/dynllava.h)."""
     B, W = input_ids.shape
+    for t, dt, n in ((w_true, torch.int32, 1), (cu, torch.int32, B + 1), (cu2, torch.int32, B + 1), (lens, torch.int32, 2 * B), (last_rows, torch.int64, B)):
+        if t is not None:
+            _dev(t)
+            assert t.dtype == dt and t.is_contiguous() and t.numel() == n, (t.dtype, t.shape, dt, n)
     _check(
         lib().dl_prompt_layout(_p(input_ids), B, W, int(n_feat), int(image_token), int(user_ids[0]), int(user_ids[1]), _p(out["seg"]), _p(out["text_src"]), _p(out["text_dst"]),
-                               _p(out["img_dst"]), _p(out["img_start"]), _p(out["err"]), _stream()),
+                               _p(out["img_dst"]), _p(out["img_start"]), _p(out["err"]), _p(w_true), int(n_drop), _p(cu), _p(cu2), _p(lens), _p(last_rows), _stream()),
         "dl_prompt_layout",
     )

@@ -439,6 +439,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # captured prefill shapes kept (LRU).  288 GB of HBM: the graphs share one memory pool, an entry costs its static inputs (~0.7 MB of
         # pixels) and the graph object
         self.max_prefill_graphs = 64
+        self.prefill_width_bucket = int(os.environ.get("DL_WIDTH_BUCKET", "16"))  # see _width_bucket
         self.use_hip_graph = True
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
@@ -1073,8 +1074,17 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cfg = self.config
         c = getattr(self, "_cache_pool", None)
         if c is None or c.batch != B or c.t_cap < t_need or c.dtype != self.dtype or c.sparse_layer != cfg.sparse_config["sparse_layer"]:
-            c = KVSlabCache(cfg.num_hidden_layers, cfg.sparse_config["sparse_layer"], B, cfg.num_key_value_heads, cfg.head_dim, t_need, self.dtype, self.device)
+            # slots are allocated in steps of 128: a stream of requests of slightly different lengths (VQAL:123-196) keeps ONE slab -- and with it
+            # every captured graph that holds pointers into it -- instead of re-allocating whenever a prompt is a few tokens longer than any before
+            old_ptr = None if c is None else c.slab.data_ptr()
+            c = None
+            self._cache_pool = None
+            c = KVSlabCache(cfg.num_hidden_layers, cfg.sparse_config["sparse_layer"], B, cfg.num_key_value_heads, cfg.head_dim, -(-int(t_need) // 128) * 128, self.dtype, self.device)
             self._cache_pool = c
+            if old_ptr is not None:  # graphs captured on the slab that has just been freed can never be replayed again
+                self._prefill_graphs = {k: v for k, v in self._prefill_graphs.items() if old_ptr not in k}
+                if self._dstate is not None:
+                    self._dstate.graphs = {k: v for k, v in self._dstate.graphs.items() if old_ptr not in k}
         c.lens.zero_()
         c.full_len_host = [0] * B
         c.seen_tokens = 0
@@ -1096,6 +1106,18 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         w = self.model.layers[0].w_qkv
         keys = int(384 * (w.numel() * w.element_size()) / 100.7e6) // 64 * 64
         return max(_SINGLE_SPLIT_MAX_KEYS, min(768, keys))
+
+    def _width_bucket(self, W: int, n_feat: int) -> int:
+        """Prompt-width bucket of the device-layout prefill: the smallest width >= W whose COMPACTED row count (W - 1 + kept image tokens: the
+        M of 30 of the 32 layers' GEMMs) is a multiple of `prefill_width_bucket` -- 16 by default, one MFMA tile of rows, so a bucket never
+        adds a row tile to those GEMMs that the true width would not have needed.  0 / 1 disables bucketing."""
+        g = int(self.prefill_width_bucket or 0)
+        if g <= 1:
+            return W
+        sc = self.config.sparse_config
+        kept = int(n_feat * sc["vision_keep_rate"]) if (sc["use_vision_predictor"] and sc["sparse_layer"] < self.config.num_hidden_layers) else n_feat
+        rows = W - 1 + kept
+        return W + (-rows) % g
 
     def _evict_prefill_entries(self):
         """Bound the prefill-shape cache: at most `max_prefill_graphs` captured graphs and as many seen-once entries (oldest first)."""
@@ -1495,11 +1517,15 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             # ARCH:309-490 on the device.  Every row is assumed to hold exactly one image token (checked by the kernel; a
             # violation is seen at the final synchronisation and the call is repeated with the host layout): all shapes then follow
             # from (B, W), and where the image sits is the kernel's business, inside the captured graph.
+            # Round 4: W is rounded up to a WIDTH BUCKET -- the captured launches are sized for the bucket, the true width travels as a device
+            # scalar and the layout kernel packs the sequences at their true lengths (cu_seqlens, KV lengths, last rows: device memory the
+            # launches already read).  A request stream with a new width on every call (VQAL:123-196) then replays a handful of graphs.
             Bq, Wq = inputs.shape
-            n_row = Wq - 1 + n_feat
-            fake = [{"system": [0, 0], "image": [0, n_feat], "instruct": [n_feat, n_row], "answer": [n_row, n_row], "last_instruct": [n_feat, n_row]} for _ in range(Bq)]
-            lay = dict(sig=("dev", Bq, Wq, n_feat), B=Bq, lens=[n_row] * Bq, indices=fake, text_src=[0], text_dst=[0], img_dst=[0], img_rows=list(range(Bq)),
-                       total=Bq * n_row, n_feat=n_feat)
+            Wb = self._width_bucket(Wq, n_feat)
+            n_row, n_row_b = Wq - 1 + n_feat, Wb - 1 + n_feat
+            fake = [{"system": [0, 0], "image": [0, n_feat], "instruct": [n_feat, n_row_b], "answer": [n_row_b, n_row_b], "last_instruct": [n_feat, n_row_b]} for _ in range(Bq)]
+            lay = dict(sig=("dev", Bq, Wb, n_feat), B=Bq, lens=[n_row] * Bq, lens_bucket=[n_row_b] * Bq, indices=fake, text_src=[0], text_dst=[0], img_dst=[0], img_rows=list(range(Bq)),
+                       total=Bq * n_row_b, n_feat=n_feat, width=Wq, bucket=Wb)
         else:
             lay = self._layout(inputs, attention_mask, None, n_feat)
         lens, indices, B = lay["lens"], lay["indices"], lay["B"]
@@ -1541,11 +1567,15 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 # first sighting of a prompt shape: run it eagerly ONCE, through the same closure a capture would record (a request stream
                 # such as the VQA loader's, VQAL:123-196, presents many widths; capturing each on sight cost two prefills + a capture per miss)
                 self._evict_prefill_entries()
-                ent = dict(ids=inputs.contiguous().clone(), images=None if images is None else images.to(self.device).clone(),
+                ids0 = inputs.contiguous().clone()
+                if dev_layout and lay["bucket"] != lay["width"]:
+                    ids0 = torch.zeros((B, lay["bucket"]), dtype=inputs.dtype, device=self.device)
+                ent = dict(ids=ids0, images=None if images is None else images.to(self.device).clone(),
                            feats=None if image_features is None else image_features.to(self.device).clone(),
-                           plan=self._plan_prefill(lens, indices), indices=copy.deepcopy(indices), graph=None)
+                           plan=self._plan_prefill(lay.get("lens_bucket", lens), indices), indices=copy.deepcopy(indices), graph=None)
                 ent["plan"]["device_instruct"] = True
                 if dev_layout:
+                    ent["w_true"] = torch.zeros(1, dtype=torch.int32, device=self.device)
                     ent["didx"] = ops.prompt_layout(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
                     ent["plan"]["img_start"] = ent["didx"]["img_start"]  # written by the layout kernel inside the graph
                 else:
@@ -1553,7 +1583,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
                 def run(ent=ent, lay=lay, dev_layout=dev_layout, n_feat=n_feat, min_new=min_new, cache=cache, st=st):
                     if dev_layout:
-                        ops.prompt_layout_into(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS, ent["didx"])
+                        p_ = ent["plan"]  # the plan's shapes are the bucket's; its device metadata is (re)written here at the true width
+                        ops.prompt_layout_into(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS, ent["didx"], w_true=ent["w_true"], n_drop=(p_["n_img"] - p_["k"]) if p_["vision_on"] else 0,
+                                               cu=p_["cu"], cu2=p_["cu2"], lens=p_["lens_dev"], last_rows=p_["last_rows"])
                     f = ent["feats"] if ent["feats"] is not None else (self.encode_images(ent["images"]) if ent["images"] is not None else None)
                     emb = self._assemble(lay, ent["didx"], ent["ids"], f)
                     x = self._prefill_run(ent["plan"], emb, cache, copy.deepcopy(ent["indices"]), True)
@@ -1561,11 +1593,16 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
                 ent["run"] = run
                 self._prefill_graphs[key] = ent
+                if dev_layout:
+                    ent["ids"][:, : inputs.shape[1]].copy_(inputs)
+                    ent["w_true"].fill_(inputs.shape[1])
                 st.step.zero_(); st.finished.zero_()
                 run()
             else:
                 self._prefill_graphs[key] = self._prefill_graphs.pop(key)  # most recently used last
-                ent["ids"].copy_(inputs)
+                ent["ids"][:, : inputs.shape[1]].copy_(inputs)
+                if dev_layout:
+                    ent["w_true"].fill_(inputs.shape[1])
                 if images is not None:
                     ent["images"].copy_(images)
                 if image_features is not None:
@@ -1586,7 +1623,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     prefill_path = "graph-replay"
                 st.step.zero_(); st.finished.zero_()
                 ent["graph"].replay()
-            self._prefill_host_update(ent["plan"], cache, indices)
+            p_host = ent["plan"]
+            if dev_layout and lay["bucket"] != lay["width"]:  # host mirrors follow the true lengths, not the bucket's
+                drop_ = (p_host["n_img"] - p_host["k"]) if p_host["vision_on"] else 0
+                p_host = dict(p_host, lens=list(lens), lens2=[n - drop_ for n in lens] if self.config.sparse_config["sparse_layer"] < self.config.num_hidden_layers else list(lens))
+            self._prefill_host_update(p_host, cache, indices)
         else:
             f = image_features if image_features is not None else (self.encode_images(images) if images is not None else None)
             embeds = self._assemble(lay, self._dev_idx(lay), inputs, f)

@@ -235,9 +235,19 @@ int dl_compact_rows_by_mask(const void* h_in, const int32_t* pos_in, const int32
  *   text_dst int64 [B*(W-1)]: their rows in the packed [B*(W-1+n_feat), H] embedding matrix
  *   img_dst  int64 [B*n_feat]: packed rows of the image features
  *   img_start int32 [B]     : = img_pos
- *   err      int32 [1]      : set to 1 + row when a row does not hold exactly one image token (checked by the caller at its next sync) */
+ *   err      int32 [1]      : set to 1 + row when a row does not hold exactly one image token (checked by the caller at its next sync)
+ * Round 4 -- width buckets (the eval loop of model_vqa_loader.py:123-196 presents a new prompt width nearly every call; one captured prefill
+ * graph per WIDTH BUCKET serves them all):
+ *   w_true   int32 [1] device scalar or NULL: only the first w_true[0] <= W columns of every row are the prompt; the sequences are packed at
+ *            their true length n = w_true - 1 + n_feat, the padding columns gather column 0's token into the unused rows
+ *            [B*n, B*(W-1+n_feat)) at the end of the packed matrix (nobody reads them).  NULL: w_true = W.
+ *   n_drop   rows every sequence loses at layer `sparse_layer` (n_img - k of DML:1899-1901; 0 when nothing is compacted)
+ *   cu_seqlens, cu_seqlens_sparse int32 [B+1], lens int32 [2, B], last_rows int64 [B] (each may be NULL): the prefill's device-side metadata
+ *            at the TRUE lengths -- packed offsets before / after the compaction, the KV lengths the prefill leaves in the two length groups
+ *            (cache_utils.py:139-149), and the packed row of every sequence's last token after the compaction. */
 int dl_prompt_layout(const int64_t* input_ids, int B, int W, int n_feat, int image_token, int user_id0, int user_id1, int32_t* seg,
-                     int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, void* stream);
+                     int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, const int32_t* w_true, int n_drop,
+                     int32_t* cu_seqlens, int32_t* cu_seqlens_sparse, int32_t* lens, int64_t* last_rows, void* stream);
 
 /* ---- the weight-streaming part of a batch-1 decode layer as ONE launch on the LDS-DMA engine (csrc/decode_block.hip): up to 4 chained
  * GEMV phases, y_i = W_i x_i, where phase 0 reads its input vector from memory (x_in: the attention output) and phase i > 0 consumes
