@@ -1576,7 +1576,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 ent["plan"]["device_instruct"] = True
                 if dev_layout:
                     ent["w_true"] = torch.zeros(1, dtype=torch.int32, device=self.device)
-                    ent["didx"] = ops.prompt_layout(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS)
+                    ent["didx"] = ops.prompt_layout(ent["ids"], n_feat, IMAGE_TOKEN_INDEX, USER_IDS)  # allocates the outputs (its launch saw an empty bucket buffer:
+                    ent["didx"]["err"].zero_()                                                        # forget that verdict)
                     ent["plan"]["img_start"] = ent["didx"]["img_start"]  # written by the layout kernel inside the graph
                 else:
                     ent["didx"] = self._dev_idx(lay)
