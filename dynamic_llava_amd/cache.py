@@ -86,6 +86,7 @@ class KVSlabCache:
         self.sparse_bound = None
         # rows of at most this many keys run ONE workgroup per (row, head).  The model raises it for batch-1 decoding on the fused
         # q|k|v + attention launch, where the slab part of the attention hides under the weight stream (tools/bench_qkv_attn.py)
+        self._sch = None  # decode schedule state (sched_*)
         self.single_split_max_keys = _SINGLE_SPLIT_MAX_KEYS
         self.min_keys_per_split = 64  # a split workgroup is given at least this many keys (tests lower it to force split launches on tiny rows)
 
@@ -104,6 +105,48 @@ class KVSlabCache:
             return self.logical_cap if self.full_bound is None else min(self.logical_cap, self.full_bound)
         cap = min(self.sparse_cap, self.logical_cap)
         return cap if self.sparse_bound is None else min(cap, self.sparse_bound)
+
+    # ---- the decode schedule: a deterministic function of (decode step index, lengths observed at chunk boundaries) ----
+    # Steps are enqueued in chunks (4, 4, then `sync_every`); after every chunk the evicted group's longest row is OBSERVED, and chunk i is
+    # scheduled from the observation made after chunk i-2 (one chunk late: generate() reads it from a non-blocking copy without draining the
+    # launch queue) plus the steps enqueued since.  forward()-driven loops (the reference's own driver, BLTM:310-337) follow the very same rule
+    # step by step, so generate() and a forward() loop replay the same kernels on the same data -- bit-identical, as before round 4.
+    def sched_begin(self, full0: int, sparse0: int, sync_every: int = 8):
+        """After a prefill (or on a cache of unknown history): `full0` / `sparse0` = longest row of the two length groups, one token produced."""
+        self._sch = dict(S=max(1, int(sync_every)), full0=int(full0), obs=[(1, int(sparse0))], produced=1, chunk_end=1, chunks=0)
+
+    def sched_active(self) -> bool:
+        return getattr(self, "_sch", None) is not None
+
+    def sched_at_boundary(self) -> bool:
+        return self._sch["produced"] == self._sch["chunk_end"]
+
+    def sched_observe(self, produced: int, sparse_max: int):
+        """The evicted group's longest row when `produced` tokens had been produced (recorded at a chunk boundary)."""
+        self._sch["obs"].append((int(produced), int(sparse_max)))
+        del self._sch["obs"][:-3]
+
+    def sched_chunk(self) -> int:
+        """Start the next chunk at the current position: sets the bounds its steps are scheduled with, returns its nominal length."""
+        sc = self._sch
+        n = min(sc["S"], 4) if sc["chunks"] < 2 else sc["S"]
+        p = sc["produced"]
+        # the newest observation the rule may use was made when the chunk BEFORE the previous one ended
+        usable = [o for o in sc["obs"] if o[0] <= sc.get("prev_start", 1)]
+        at, val = usable[-1] if usable else sc["obs"][0]
+        self.set_bounds(sc["full0"] + p - 1 + n, val + (p - at) + n)
+        sc["prev_start"], sc["chunk_end"], sc["chunks"] = p, p + n, sc["chunks"] + 1
+        return n
+
+    def sched_advance(self, n: int):
+        self._sch["produced"] += int(n)
+        if self._sch["produced"] > self._sch["chunk_end"]:
+            raise RuntimeError("decode schedule: advanced past the end of the current chunk")
+        # a chunk cut short by max_new_tokens simply ends the generation; nothing to fix up
+
+    def sched_drop(self):
+        self._sch = None
+        self.set_bounds(None, None)
 
     def set_bounds(self, full_bound, sparse_bound):
         self.full_bound = None if full_bound is None else int(full_bound)
@@ -152,7 +195,6 @@ class KVSlabCache:
         self.slab = new
         self.sparse_cap += new_cap - self.t_cap
         self.logical_cap += new_cap - self.t_cap
-        self.full_bound = self.sparse_bound = None
         self.t_cap = new_cap
         self.k = [self.slab[i, 0] for i in range(self.n_layers)]
         self.v = [self.slab[i, 1] for i in range(self.n_layers)]

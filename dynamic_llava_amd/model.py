@@ -462,6 +462,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self.smallm_max_decode_batch = int(os.environ["DL_SMALLM_MAX_B"])
         self.record_timing = False  # generate(): HIP events around the prefill / decode parts -> self.last_timing (tools/bench_varlen_stream.py)
         self.last_timing = None
+        self.decode_sync_every = int(os.environ.get("DL_SYNC_EVERY", "8"))  # decode steps per chunk of the schedule (KVSlabCache.sched_*)
+        self.force_text_decision = None  # tests only: forward() decode keeps / evicts the step's token as given, see forward()
         self.single_split_keys_override = None  # tests only: see _single_split_max_keys
         self.min_keys_per_split = 64  # tests only: KVSlabCache.min_keys_per_split of the caches this model schedules
         self.debug_records = None  # dict filled by forward passes when set to {} (tests)
@@ -724,6 +726,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         else:
             p.update(cu2_list=cu_list, cu2=p["cu"], max_len2=p["max_len"])
         SL, L = sc["sparse_layer"], cfg.num_hidden_layers
+        # rows the launches are SIZED for (>= the packed rows that exist).  Equally long rows are sized for their width bucket whatever path
+        # built the plan (device layout in generate(), host layout, forward()): the library GEMMs pick their kernel by row count, so the
+        # same request computes the same bits on every path; the rows past cu[B] hold zeros / padding that nobody consumes.
+        p["total"], p["total2"] = cu_list[-1], p["cu2_list"][-1]
+        if vision_on and not p["instruct_on"] and len(set(lens)) == 1:
+            W_ = lens[0] - n_img + 1
+            pad = (self._width_bucket(W_, n_img) - W_) * B
+            p["total"], p["total2"] = p["total"] + pad, p["total2"] + pad
         p["lens2"] = lens2
         p["lens_dev"] = i32([list(lens), lens2 if (SL < L) else list(lens)])
         p["last_rows"] = torch.tensor([c - 1 for c in p["cu2_list"][1:]], dtype=torch.long, device=dev)
@@ -739,11 +749,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
         vision_on, n_img, k = p["vision_on"], p["n_img"], p["k"]
         cos, sin = self._rope
-        cu, cu_list, max_len, total = p["cu"], p["cu_list"], p["max_len"], p["cu_list"][-1]
+        cu, cu_list, max_len, total = p["cu"], p["cu_list"], p["max_len"], (p["cu_list"][-1] if p["nocache"] else p["total"])
         zeros_b = p["zeros"]
         pos = None  # layers < SL: position = in-row index
         h = embeds.to(dt).contiguous()
-        if h.data_ptr() == embeds.data_ptr():
+        if h.shape[0] < total:  # sized for the width bucket (see _plan_prefill): the extra rows are zeros behind the last sequence
+            h = torch.cat([h, h.new_zeros((total - h.shape[0], h.shape[1]))], dim=0)
+        elif h.data_ptr() == embeds.data_ptr():
             h = h.clone()  # the residual stream is updated in place; never touch the caller's tensor
         rec = self.debug_records
         x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps)
@@ -760,13 +772,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 keep = ops.topk_select(score, k)
                 # compaction + this layer's input RMSNorm in one launch (unless a text-predictor compaction still follows at this layer)
                 fuse_norm = not p["instruct_on"] and not p["nocache"]
+                total2 = p["cu2_list"][-1] if p["nocache"] else p["total2"]
                 if fuse_norm:
-                    h, pos, x_fused = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, p["cu2_list"][-1], layer.input_layernorm.weight, eps)
+                    h, pos, x_fused = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, total2, layer.input_layernorm.weight, eps)
                 else:
-                    h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, p["cu2_list"][-1])
+                    h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, total2)
                 if rec is not None:
                     rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=p["cu2"])
-                cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], p["cu2_list"][-1]
+                cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], total2
             if i == SL and p["instruct_on"]:
                 # ---- SURVEY 8f N2 / DML:2261-2375: prefill, first instruct -- the instruct predictor drops tokens of the last
                 # instruct span (its final token always stays).  The kept count is data dependent: one device->host copy, as in
@@ -886,6 +899,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cache.sparse_cap = cache.logical_cap - (max(p["lens"]) - max(p["lens2"])) - p["instruct_drop"]  # host-known upper bound of the evicted group's lengths
         cache.prefill_sparse_max = max(p["lens2"]) - p["instruct_drop"]  # longest row of layers >= sparse_layer after the prefill (upper bound when the instruct compaction stayed on the device)
         cache.set_bounds(None, None)
+        cache.sched_begin(max(p["lens"]), cache.prefill_sparse_max, self.decode_sync_every)
         if p["instruct_drop"]:  # DML:2365-2375
             for ix in indices:
                 ix["instruct"][1] -= p["instruct_drop"]
@@ -1212,9 +1226,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._rope_tables(max(cache.full_len_host) + 2)
             st.cur_ids.copy_(input_ids[:, 0])
             self._eos, self._pad = -1, 0
-            # schedule: the un-evicted group's length is exact on the host; the evicted group's would need a device->host copy per call, so this
-            # eager path keeps its capacity bound (generate() observes the device lengths chunk by chunk instead)
-            cache.set_bounds(max(cache.full_len_host) + 1, None)
+            # the decode schedule (KVSlabCache.sched_*): the same rule generate() follows, evaluated step by step -- a forward()-driven loop
+            # replays the same kernels as generate() on the same request.  Costs one device->host copy of the lengths per CHUNK of steps
+            if not cache.sched_active():  # a cache of unknown history (imported legacy tuple, a chunk appended): start from what is there now
+                cache.sched_begin(max(cache.full_len_host), int(cache.lens[1].max()), self.decode_sync_every)
+            if cache.sched_at_boundary():
+                if cache._sch["chunks"] > 0:
+                    cache.sched_observe(cache._sch["produced"], int(cache.lens[1].max()))
+                cache.sched_chunk()
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
             if st.qa_gran is not None:
                 st.qa_gran.zero_()
@@ -1226,9 +1245,16 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             sc_ = self.config.sparse_config
             use_tp = bool(sc_["use_text_predictor"] and sc_["use_output_text_predictor"]) and sc_["sparse_layer"] < self.config.num_hidden_layers
             cache.lens[0] += 1
-            cache.lens[1] += st.decision if use_tp else 1
+            dec_ = st.decision if use_tp else 1
+            if use_tp and self.force_text_decision is not None:
+                # test hook (the oracle has the same one): continue a comparison past a keep/evict logit pair that sits on the decision boundary.
+                # Only the bookkeeping is overridden -- the step's own logits never depend on its decision (the token always attends itself,
+                # DML:1061-1076); debug_records keeps the predictor's own decision and logits
+                dec_ = torch.as_tensor(self.force_text_decision).to(device=self.device, dtype=torch.int32).reshape(st.decision.shape)
+            cache.lens[1] += dec_
             cache.full_len_host = [n + 1 for n in cache.full_len_host]
             cache.seen_tokens += 1
+            cache.sched_advance(1)
             if self.debug_records is not None:
                 self.debug_records.update(text_decision=st.decision.clone() if use_tp else None, text_logit=st.tp_logits.clone())
             logits = st.logits.to(torch.float32, copy=True).unsqueeze(1)  # never alias the persistent step buffer
@@ -1239,7 +1265,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         else:
             embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
         x, cache, lens2, cu_list = self._prefill(embeds, lens, indices, cache, reserve=256, last_only=False)
-        logits_packed = F.linear(x, self.lm_head.weight).float()
+        logits_packed = F.linear(x, self.lm_head.weight).float()[: cu_list[-1]]  # (x may be sized for a width bucket: rows past the last sequence are padding)
         B = len(lens2)
         if len(set(lens2)) == 1:
             logits = logits_packed.view(B, lens2[0], -1)
@@ -1343,6 +1369,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             cache.lens[1] += T
         cache.full_len_host = [n + T for n in cache.full_len_host]
         cache.seen_tokens += T  # cache.sparse_cap stays a valid (host-known) upper bound of the evicted group's lengths
+        cache.sched_drop()  # the next decode step re-starts the schedule from the lengths it finds
         logits = F.linear(x, self.lm_head.weight).float().view(B, T, -1)
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
 
@@ -1498,7 +1525,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             return self._generate_on_cache(inputs, images, **kwargs)
         attention_mask = kwargs.get("attention_mask")
         image_features = kwargs.get("image_features")
-        sync_every = int(kwargs.get("sync_every", os.environ.get("DL_SYNC_EVERY", 8)))  # decode steps enqueued between two observations of the device state
+        sync_every = int(kwargs.get("sync_every", self.decode_sync_every))  # decode steps enqueued between two observations of the device state
         want_dict = bool(kwargs.get("return_dict_in_generate"))
         want_scores = want_dict and bool(kwargs.get("output_scores"))
         inputs = inputs.to(self.device)
@@ -1650,39 +1677,38 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
         if want_scores:
             _score(0)
-            sync_every = 1
         # ---- decode loop: chunks of captured steps, scheduled from the lengths the predictor actually leaves (DML:2377-2391, CU:153-164) ----
         # Before a chunk the host knows: the un-evicted group's length exactly, and the evicted group's as OBSERVED after an earlier chunk
         # (non-blocking copy into pinned memory, consumed one chunk late so that the host never waits for steps it has just enqueued) plus
         # the steps enqueued since.  Those bounds pick the split-KV factor / the fused q|k|v+attention launch (cache.n_splits), i.e. which
         # captured graph is replayed; the values are data, never timing, so the schedule is deterministic for a given request.
         produced, chunks = 1, 0
-        full0 = max(cache.full_len_host)
-        sparse_obs, obs_at = getattr(cache, "prefill_sparse_max", None), 1
-        if sparse_obs is None:
-            sparse_obs = full0
+        cache.sched_begin(max(cache.full_len_host), getattr(cache, "prefill_sparse_max", None) or max(cache.full_len_host), sync_every)
         pending = []  # (ring slot, produced-when-copied)
         all_done = False
         while produced < max_new and not all_done:
-            n = min(sync_every if chunks >= 2 else min(sync_every, 4), max_new - produced)  # short first chunks: an early EOS is seen early
-            # EOS of a short answer (VQA: a few tokens) must not cost two chunks of wasted steps: the first chunks are observed blocking
-            # (one ~50 us queue drain each), later ones one chunk late
+            # EOS of a short answer (VQA: a few tokens) must not cost two chunks of wasted steps: the first chunks' flags are read blocking (one
+            # ~50 us queue drain each), later ones one chunk late.  The SCHEDULE never uses an observation newer than one chunk old either way.
             keep_newest = 0 if (eos_ids and chunks <= 2) else 1
             while len(pending) > keep_newest:
                 slot, at = pending.pop(0)
                 st.obs_ev[slot].synchronize()
                 row = st.obs_host[slot]
-                sparse_obs, obs_at = int(row[B : 2 * B].max()), at
+                cache.sched_observe(at, int(row[B : 2 * B].max()))
                 if eos_ids and int(row[2 * B :].min()) != 0:
                     all_done = True
             if all_done:
                 break
-            cache.set_bounds(full0 + produced - 1 + n, sparse_obs + (produced - obs_at) + n)
-            self._run_decode_steps(st, cache, n)
+            n = min(cache.sched_chunk(), max_new - produced)
+            if want_scores:  # the step buffer is read after every step; the schedule (chunks, bounds) is the same as without scores
+                for i_ in range(n):
+                    self._run_decode_steps(st, cache, 1)
+                    _score(produced + i_)
+            else:
+                self._run_decode_steps(st, cache, n)
             produced += n
             chunks += 1
-            if want_scores:
-                _score(produced - 1)
+            cache.sched_advance(n)
             if produced < max_new:
                 slot = chunks % 4
                 st.obs_host[slot, : 2 * B].copy_(cache.lens.view(-1), non_blocking=True)

@@ -1,8 +1,16 @@
-"""GPU: BASELINE.json configs[1] at FULL DEPTH -- LLaVA-1.5-7B, all 32 layers, bf16, the bench prompt (35 + 576 + 20 = 631
-tokens -> 170 after layer 2, vision_keep_rate 0.2, output-text KV eviction on) -- against the oracle run on the GPU box's host
-cores (bf16 as the reference computes, and fp32 on the same bf16 weights as ground truth).  Every other model-level oracle
-comparison uses <= 4 layers; this one checks that nothing drifts over 32 (error growth, RoPE positions after compaction, KV
-bookkeeping, decisions) on the exact weights bench.py times."""
+"""GPU: BASELINE.json configs at FULL DEPTH against the oracle run on the GPU box's host cores (bf16 as the reference computes, and fp32 on
+the same bf16 weights as ground truth).  Every other model-level oracle comparison uses <= 4 layers; these check that nothing drifts over the
+whole stack (error growth, RoPE positions after compaction, KV bookkeeping, decisions) on the exact models bench.py / tools/bench_configs.py time:
+
+  configs[1]  LLaVA-1.5-7B, 32 layers, B=1, the bench prompt (35 + 576 + 20 = 631 tokens -> 170 after layer 2), prefill + 8 decode steps
+  configs[2]  the same 7B model, B=32 ragged prompts (question lengths ~U[8,64]) through the packed-varlen batched path (decode batch > 24:
+              library GEMMs + the ragged decode attention); two rows' prefill + 4 decode steps against the oracle's B=1 runs of those rows
+              (B=1 is the only batched semantics the reference defines: SURVEY finding 2)
+  configs[4]  LLaVA-1.5-13B, 40 layers, B=1, prompt 35 + 576 + 29 = 640 -> 179, prefill + 8 decode steps with output-text KV eviction
+
+No comparison can end silently: a kept set that differs inside the bf16 rounding band of the k-th score, or a keep/evict logit pair on the
+decision boundary, is FORCED to the HIP path's outcome on the oracle side (test hooks of oracle/ref_cpu.py) and every later step is still
+compared; how many steps were compared / forced is printed and asserted."""
 import pytest
 import torch
 
@@ -11,102 +19,170 @@ pytestmark = pytest.mark.gpu
 from oracle import fixtures as fx  # noqa: E402
 from oracle.ref_cpu import Oracle  # noqa: E402
 
-N_SYS, N_Q, N_IMG = 35, 20, 576
+N_IMG, K_KEPT = 576, 115
+ULP = 2.0**-7
 
 
-def test_configs1_32_layers_prefill_and_decode_vs_oracle():
-    from dynamic_llava_amd.builder import build_random_model
-    from dynamic_llava_amd.config import DynamicLlavaConfig
-
+def _compare_rows_vs_oracle(model, cfg, prompts, feats, rows, forced, label):
+    """HIP: ONE (possibly batched, ragged) run of prefill + len(forced) teacher-forced decode steps through the reference's own driver loop
+    (BLTM:310-337).  Oracle: a B=1 run per row in `rows`, bf16 and fp32.  Returns a dict of what was compared."""
     dtype = torch.bfloat16
-    cfg = DynamicLlavaConfig()  # LLaVA-1.5-7B defaults: 32 layers, sparse_layer 2, keep 0.2
-    assert cfg.num_hidden_layers == 32 and cfg.hidden_size == 4096
-    model = build_random_model(cfg, dtype=dtype, device="cuda", seed=0, predictor_gain=50.0)  # == bench.py's model
-    g = torch.Generator().manual_seed(0)
-    ids = fx.make_prompt(cfg, N_SYS, N_Q, seed=0)[None]
-    images = torch.randn((1, 3, 336, 336), generator=g).to(dtype)
-    feats = model.encode_images(images.cuda())  # the same projector output feeds both sides (CLIP parity: test_kernels_gpu)
-    n_steps = 8
-    forced = fx.make_forced_tokens(cfg, n_steps, 1, seed=5)
-    # ---- HIP path, the reference's own driver loop (BLTM:310-337) ----
+    B, n_steps = len(prompts), forced.shape[0]
+    W = max(p.shape[0] for p in prompts)
+    ids = torch.zeros(B, W, dtype=torch.long)
+    am = torch.zeros(B, W, dtype=torch.long)
+    for b, p in enumerate(prompts):
+        ids[b, : p.shape[0]] = p
+        am[b, : p.shape[0]] = 1
+    ragged = B > 1
     model.debug_records = {}
-    out = model(ids.cuda(), image_features=feats)
+    out = model(ids.cuda(), attention_mask=am.cuda() if ragged else None, image_features=feats)
     pkv = out.past_key_values
-    hip_logits = [out.logits[0, -1].float().cpu()]
+    cu = model.debug_records["cu_after"].cpu().tolist()
+    n2 = [cu[b + 1] - cu[b] for b in range(B)]
+    assert n2 == [p.shape[0] - 1 + K_KEPT for p in prompts]
+    hip_logits = {b: [out.logits[b, n2[b] - 1].float().cpu()] for b in rows}
     pos_hip = model.debug_records["position_ids"].cpu()
     keep_hip = model.debug_records["keep_index"].cpu()
-    score_hip = model.debug_records["vision_score"].float().cpu()
-    assert out.logits.shape == (1, N_SYS + 115 + N_Q, cfg.vocab_size)
     dec_hip, gap_hip = [], []
     for j in range(n_steps):
         out = model(forced[j][:, None].cuda(), past_key_values=pkv)
         pkv = out.past_key_values
-        hip_logits.append(out.logits[0, -1].float().cpu())
-        dec_hip.append(int(model.debug_records["text_decision"][0]))
+        for b in rows:
+            hip_logits[b].append(out.logits[b, -1].float().cpu())
+        dec_hip.append(model.debug_records["text_decision"].cpu().clone())
         tl = model.debug_records["text_logit"].cpu()
-        gap_hip.append(float((tl[0, 0] - tl[0, 1]).abs()))
+        gap_hip.append((tl[:, 0] - tl[:, 1]).abs())
     lens = pkv[1]
-    assert int(lens[0][0]) == N_SYS + N_IMG + N_Q + n_steps and int(lens[-1][0]) == N_SYS + 115 + N_Q + sum(dec_hip)
+    for b in range(B):
+        assert int(lens[0][b]) == prompts[b].shape[0] - 1 + N_IMG + n_steps
+        assert int(lens[-1][b]) == n2[b] + sum(int(d[b]) for d in dec_hip)
     model.debug_records = None
-    # ---- oracle on the host cores: bf16 (what the reference computes) and fp32 on the same bf16 weights (truth) ----
+    model.check_device_errors()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if "vision_tower" not in k}
-    o = Oracle(cfg, sd, dtype)
-    with torch.no_grad():
-        l_ref, p_ref = o.forward(ids, image_features=feats.cpu())
-        pos_ref, keep_ref = o.records["position_ids"], o.records["keep_index"]
-        # kept-token index set: bit-exact unless the reference's own k-th score is inside the bf16 rounding band (then only
-        # tokens inside that band may differ)
-        forced_keep = None
-        if not torch.equal(keep_hip, keep_ref):
-            score_ref = o.records["vision_score"].float()
-            kth = torch.sort(score_ref[0], descending=True).values[114]
-            diff = set(keep_hip[0].tolist()) ^ set(keep_ref[0].tolist())
-            assert all(abs(float(score_ref[0, t]) - float(kth)) <= 4 * 2.0**-7 * max(1.0, abs(float(kth))) for t in diff), (diff, float(kth))
-            # both sets are valid top-k sets of scores that agree to the last bf16 bit: continue with the HIP path's set on both sides
-            forced_keep = keep_hip
-            o.force_keep_index = forced_keep
-            l_ref, p_ref = o.forward(ids, image_features=feats.cpu())
-            pos_ref = o.records["position_ids"]
-        assert torch.equal(pos_hip.long().view(-1), pos_ref.long().view(-1)), "position ids after compaction"
-        def step(orc, j, pkv_):
-            """One decode step of an oracle.  A keep/evict logit pair that sits on the boundary (|gap| <= 0.5 on either side) may
-            legitimately fall the other way: the step is then repeated with the HIP path's decision forced (oracle test hook), so that
-            every LATER step is still compared instead of the comparison ending here.  Away from the boundary a difference is an error."""
-            l_, p_ = orc.forward(forced[j][:, None], past_key_values=pkv_)
-            tl_ = orc.records["text_logit"]
-            gap_ = float((tl_[0, 0, 0] - tl_[0, 0, 1]).abs())
-            was_forced = False
-            if int(orc.records["text_decision"][0, 0]) != dec_hip[j]:
-                assert min(gap_, gap_hip[j]) <= 0.5, f"eviction decision differs away from the boundary, step {j}: oracle gap {gap_}, hip gap {gap_hip[j]}"
-                orc.force_text_decision = torch.tensor([[dec_hip[j]]])
-                l_, p_ = orc.forward(forced[j][:, None], past_key_values=pkv_)
-                orc.force_text_decision = None
-                was_forced = True
-            return l_, p_, was_forced
+    summary = {}
+    for b in rows:
+        ids_b, feats_b = prompts[b][None], feats[b : b + 1].cpu()
+        o = Oracle(cfg, sd, dtype)
+        with torch.no_grad():
+            l_ref, p_ref = o.forward(ids_b, image_features=feats_b)
+            keep_ref = o.records["keep_index"]
+            # kept-token index set: bit-exact unless the reference's own k-th score is inside the bf16 rounding band (then only tokens inside
+            # that band may differ, and both sides continue on the HIP path's set)
+            kept_forced = False
+            if not torch.equal(keep_hip[b : b + 1], keep_ref):
+                score_ref = o.records["vision_score"].float()
+                kth = torch.sort(score_ref[0], descending=True).values[K_KEPT - 1]
+                diff = set(keep_hip[b].tolist()) ^ set(keep_ref[0].tolist())
+                assert all(abs(float(score_ref[0, t]) - float(kth)) <= 4 * ULP * max(1.0, abs(float(kth))) for t in diff), (label, b, diff, float(kth))
+                kept_forced = True
+                o.force_keep_index = keep_hip[b : b + 1]
+                l_ref, p_ref = o.forward(ids_b, image_features=feats_b)
+            assert torch.equal(pos_hip[cu[b] : cu[b + 1]].long().view(-1), o.records["position_ids"].long().view(-1)), f"{label} row {b}: position ids after compaction"
 
-        ref_logits = [l_ref[0, -1].float()]
-        forced_steps = {"bf16": [], "fp32": []}
-        for j in range(n_steps):
-            l_ref, p_ref, f_ = step(o, j, p_ref)
-            ref_logits.append(l_ref[0, -1].float())
-            if f_:
-                forced_steps["bf16"].append(j)
-        lens_ref = p_ref[1]
-        assert int(lens_ref[-1][0]) == int(lens[-1][0]) and int(lens_ref[0][0]) == int(lens[0][0]), "KV lengths after the decode steps"
-        del o, p_ref
-        o32 = Oracle(cfg, sd, torch.float32)  # casts the bf16 tensors up: identical parameter values
-        o32.force_keep_index = keep_hip  # the fp32 run must follow the same kept set to be a ground truth for these logits
-        l_32, p_32 = o32.forward(ids, image_features=feats.cpu().float())
-        truth = [l_32[0, -1]]
-        for j in range(n_steps):
-            l_32, p_32, f_ = step(o32, j, p_32)
-            truth.append(l_32[0, -1])
-            if f_:
-                forced_steps["fp32"].append(j)
-    ulp = 2.0**-7
-    for j in range(n_steps + 1):  # EVERY step is compared (no early exit): boundary decisions were forced, not skipped
-        e_hip = float((hip_logits[j] - truth[j]).abs().max())
-        e_ref = float((ref_logits[j] - truth[j]).abs().max())
-        assert e_hip <= 2.0 * e_ref + 2 * ulp * float(truth[j].abs().max()), f"step {j}: hip err {e_hip} vs reference err {e_ref}"
-    print(f"full depth: kept set {'forced to the HIP set (near-tied boundary)' if forced_keep is not None else 'bit-exact'}; "
-          f"eviction decisions forced at steps {forced_steps} of {n_steps}; evicted {n_steps - sum(dec_hip)} of {n_steps}")
+            def step(orc, j, pkv_):
+                """One decode step of an oracle.  A keep/evict logit pair on the boundary (|gap| <= 0.5 on either side) may legitimately fall the
+                other way: the step is then repeated with the HIP path's decision forced, so that every LATER step is still compared.  Away from
+                the boundary a difference is an error."""
+                tok = forced[j][b : b + 1][:, None]
+                l_, p_ = orc.forward(tok, past_key_values=pkv_)
+                tl_ = orc.records["text_logit"]
+                gap_ = float((tl_[0, 0, 0] - tl_[0, 0, 1]).abs())
+                was_forced = False
+                if int(orc.records["text_decision"][0, 0]) != int(dec_hip[j][b]):
+                    assert min(gap_, float(gap_hip[j][b])) <= 0.5, f"{label} row {b} step {j}: eviction decision differs away from the boundary (oracle gap {gap_}, hip gap {float(gap_hip[j][b])})"
+                    orc.force_text_decision = torch.tensor([[int(dec_hip[j][b])]])
+                    l_, p_ = orc.forward(tok, past_key_values=pkv_)
+                    orc.force_text_decision = None
+                    was_forced = True
+                return l_, p_, was_forced
+
+            ref_logits = [l_ref[0, -1].float()]
+            forced_steps = {"bf16": [], "fp32": []}
+            for j in range(n_steps):
+                l_ref, p_ref, f_ = step(o, j, p_ref)
+                ref_logits.append(l_ref[0, -1].float())
+                if f_:
+                    forced_steps["bf16"].append(j)
+            lens_ref = p_ref[1]
+            assert int(lens_ref[-1][0]) == int(lens[-1][b]) and int(lens_ref[0][0]) == int(lens[0][b]), f"{label} row {b}: KV lengths after the decode steps"
+            del o, p_ref
+            o32 = Oracle(cfg, sd, torch.float32)  # casts the bf16 tensors up: identical parameter values
+            o32.force_keep_index = keep_hip[b : b + 1]  # the fp32 run must follow the same kept set to be a ground truth for these logits
+            l_32, p_32 = o32.forward(ids_b, image_features=feats_b.float())
+            truth = [l_32[0, -1]]
+            for j in range(n_steps):
+                l_32, p_32, f_ = step(o32, j, p_32)
+                truth.append(l_32[0, -1])
+                if f_:
+                    forced_steps["fp32"].append(j)
+            del o32, p_32
+        worst = 0.0
+        for j in range(n_steps + 1):  # EVERY step is compared (no early exit): boundary decisions were forced, not skipped
+            e_hip = float((hip_logits[b][j] - truth[j]).abs().max())
+            e_ref = float((ref_logits[j] - truth[j]).abs().max())
+            bound = 2.0 * e_ref + 2 * ULP * float(truth[j].abs().max())
+            assert e_hip <= bound, f"{label} row {b} step {j}: hip err {e_hip} vs reference err {e_ref}"
+            worst = max(worst, e_hip / bound)
+        summary[b] = dict(steps_compared=n_steps + 1, kept_set="forced to the HIP set (near-tied boundary)" if kept_forced else "bit-exact", decisions_forced=forced_steps,
+                          evicted=n_steps - sum(int(d[b]) for d in dec_hip), worst_err_over_bound=round(worst, 3))
+        print(f"{label} row {b}: {summary[b]}")
+    assert all(s["steps_compared"] == n_steps + 1 for s in summary.values())
+    return summary
+
+
+@pytest.fixture(scope="module")
+def model7b():
+    from dynamic_llava_amd.builder import build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    cfg = DynamicLlavaConfig()  # LLaVA-1.5-7B defaults: 32 layers, sparse_layer 2, keep 0.2
+    assert cfg.num_hidden_layers == 32 and cfg.hidden_size == 4096
+    model = build_random_model(cfg, dtype=torch.bfloat16, device="cuda", seed=0, predictor_gain=50.0)  # == bench.py's model
+    yield cfg, model
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_configs1_32_layers_prefill_and_decode_vs_oracle(model7b):
+    cfg, model = model7b
+    g = torch.Generator().manual_seed(0)
+    prompt = fx.make_prompt(cfg, 35, 20, seed=0)
+    images = torch.randn((1, 3, 336, 336), generator=g).to(torch.bfloat16)
+    feats = model.encode_images(images.cuda())  # the same projector output feeds both sides (CLIP parity: test_kernels_gpu)
+    forced = fx.make_forced_tokens(cfg, 8, 1, seed=5)
+    s = _compare_rows_vs_oracle(model, cfg, [prompt], feats, [0], forced, "configs[1] 7B x 32 layers")
+    assert s[0]["steps_compared"] == 9
+
+
+def test_configs2_batch32_ragged_32_layers_two_rows_vs_oracle(model7b):
+    """configs[2] at full depth: 32 ragged requests in one packed batch; rows 0 and 17 against the oracle's B=1 runs, prefill + 4 decode steps."""
+    cfg, model = model7b
+    g = torch.Generator().manual_seed(1)
+    B = 32
+    n_q = torch.randint(8, 65, (B,), generator=g).tolist()  # question lengths ~U[8,64] (SURVEY 8d, C3)
+    prompts = [fx.make_prompt(cfg, 35, n_q[b], seed=b) for b in range(B)]
+    images = torch.randn((B, 3, 336, 336), generator=g).to(torch.bfloat16)
+    feats = model.encode_images(images.cuda())
+    forced = fx.make_forced_tokens(cfg, 4, B, seed=6)
+    s = _compare_rows_vs_oracle(model, cfg, prompts, feats, [0, 17], forced, "configs[2] 7B x 32 layers, B=32 ragged")
+    assert model._dstate.B == B and not model._dstate.use_gemv and not model._dstate.use_smallm, "B=32 decodes on the library-GEMM + ragged-attention path"
+    assert sorted(s) == [0, 17] and all(v["steps_compared"] == 5 for v in s.values())
+
+
+def test_configs4_13b_40_layers_prefill_and_decode_vs_oracle():
+    """configs[4] at full depth: LLaVA-1.5-13B, all 40 layers, the model tools/bench_configs.py times."""
+    from dynamic_llava_amd.builder import build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    cfg = DynamicLlavaConfig(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40)
+    model = build_random_model(cfg, dtype=torch.bfloat16, device="cuda", seed=0, predictor_gain=50.0)
+    g = torch.Generator().manual_seed(2)
+    prompt = fx.make_prompt(cfg, 35, 29, seed=9)
+    images = torch.randn((1, 3, 336, 336), generator=g).to(torch.bfloat16)
+    feats = model.encode_images(images.cuda())
+    forced = fx.make_forced_tokens(cfg, 8, 1, seed=7)
+    s = _compare_rows_vs_oracle(model, cfg, [prompt], feats, [0], forced, "configs[4] 13B x 40 layers")
+    assert s[0]["steps_compared"] == 9
+    del model
+    torch.cuda.empty_cache()

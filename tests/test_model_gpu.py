@@ -188,6 +188,18 @@ def test_generate_schedule_follows_observed_lengths_and_matches_reference_golden
     # the same request again: same observations -> same schedule -> bit-identical
     out2 = model.generate(ids, images=images, max_new_tokens=n, eos_token_id=None, sync_every=3)
     assert torch.equal(out, out2)
+    # a forward()-driven loop (the reference's own driver, BLTM:310-337) follows the same schedule rule step by step: every decode step's
+    # logits are BIT-identical to generate()'s (HF `scores`), across the switch of kernels
+    res = model.generate(ids, images=images, max_new_tokens=n, eos_token_id=None, return_dict_in_generate=True, output_scores=True)
+    np.testing.assert_array_equal(res["sequences"].cpu().numpy()[0], g["ids"][:, 0])
+    o = model(ids, images=images)
+    pkv, seen = o.past_key_values, set()
+    for j in range(1, n):
+        o = model(res["sequences"][:, j - 1 : j], past_key_values=pkv)
+        pkv = o.past_key_values
+        seen.add(pkv.n_splits(model.config.num_hidden_layers - 1, model.config.num_attention_heads))
+        assert torch.equal(o.logits[:, -1].float(), res["scores"][j].float()), f"decode step {j}: forward() loop and generate() differ"
+    assert 1 in seen and max(seen) > 1, f"the forward() loop must have gone through both schedules too: {sorted(seen)}"
 
 
 def test_batched_ragged_rows_equal_their_b1_runs():
