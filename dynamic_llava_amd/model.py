@@ -778,7 +778,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 else:
                     h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, total2)
                 if rec is not None:
-                    rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos, cu_after=p["cu2"])
+                    rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos[: p["cu2_list"][-1]], cu_after=p["cu2"])
                 cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], total2
             if i == SL and p["instruct_on"]:
                 # ---- SURVEY 8f N2 / DML:2261-2375: prefill, first instruct -- the instruct predictor drops tokens of the last
