@@ -131,6 +131,19 @@ def _compare_rows_vs_oracle(model, cfg, prompts, feats, rows, forced, label):
     return summary
 
 
+def _calibrate(model, cfg, n_sys, n_q, seed):
+    """A random-init output-text predictor keeps (or evicts) every token; bench.py shifts its final bias until about half of a greedy
+    continuation is evicted -- the regime `output_text_keep_rate=0.5` names.  The same calibration here, so that the full-depth comparisons
+    contain kept AND evicted tokens (asserted by the tests)."""
+    from bench import calibrate_text_predictor
+
+    g = torch.Generator().manual_seed(100 + seed)
+    images = torch.randn((1, 3, 336, 336), generator=g).to(torch.bfloat16).cuda()
+    frac = calibrate_text_predictor(model, fx.make_prompt(cfg, n_sys, n_q, seed=seed)[None].cuda(), images, 24)
+    print(f"text predictor calibrated: keep fraction {frac}")
+    return frac
+
+
 @pytest.fixture(scope="module")
 def model7b():
     from dynamic_llava_amd.builder import build_random_model
@@ -139,6 +152,7 @@ def model7b():
     cfg = DynamicLlavaConfig()  # LLaVA-1.5-7B defaults: 32 layers, sparse_layer 2, keep 0.2
     assert cfg.num_hidden_layers == 32 and cfg.hidden_size == 4096
     model = build_random_model(cfg, dtype=torch.bfloat16, device="cuda", seed=0, predictor_gain=50.0)  # == bench.py's model
+    _calibrate(model, cfg, 35, 20, 0)
     yield cfg, model
     del model
     torch.cuda.empty_cache()
@@ -153,6 +167,7 @@ def test_configs1_32_layers_prefill_and_decode_vs_oracle(model7b):
     forced = fx.make_forced_tokens(cfg, 8, 1, seed=5)
     s = _compare_rows_vs_oracle(model, cfg, [prompt], feats, [0], forced, "configs[1] 7B x 32 layers")
     assert s[0]["steps_compared"] == 9
+    assert 0 < s[0]["evicted"] < 8, "the eviction must go both ways inside the compared steps"
 
 
 def test_configs2_batch32_ragged_32_layers_two_rows_vs_oracle(model7b):
@@ -177,6 +192,7 @@ def test_configs4_13b_40_layers_prefill_and_decode_vs_oracle():
 
     cfg = DynamicLlavaConfig(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40)
     model = build_random_model(cfg, dtype=torch.bfloat16, device="cuda", seed=0, predictor_gain=50.0)
+    _calibrate(model, cfg, 35, 29, 9)
     g = torch.Generator().manual_seed(2)
     prompt = fx.make_prompt(cfg, 35, 29, seed=9)
     images = torch.randn((1, 3, 336, 336), generator=g).to(torch.bfloat16)
@@ -184,5 +200,6 @@ def test_configs4_13b_40_layers_prefill_and_decode_vs_oracle():
     forced = fx.make_forced_tokens(cfg, 8, 1, seed=7)
     s = _compare_rows_vs_oracle(model, cfg, [prompt], feats, [0], forced, "configs[4] 13B x 40 layers")
     assert s[0]["steps_compared"] == 9
+    assert 0 < s[0]["evicted"] < 8, "the eviction must go both ways inside the compared steps"
     del model
     torch.cuda.empty_cache()
