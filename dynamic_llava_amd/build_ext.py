@@ -42,6 +42,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     os.makedirs(OBJ, exist_ok=True)
+    keep = {os.path.basename(s_) + ".o" for s_ in srcs} | {"stamp"}
+    for f in os.listdir(OBJ):  # objects of sources that no longer exist would otherwise sit there forever (they were never linked)
+        if f not in keep:
+            os.remove(os.path.join(OBJ, f))
 
     def cc(src):
         obj = os.path.join(OBJ, os.path.basename(src) + ".o")
