@@ -49,7 +49,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-gpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--persistent", action="store_true", help="decode: the four weight-streaming launches between two attentions as ONE launch on the LDS-DMA engine (dl_decode_block; opt-in: measured slower than the launch path, DESIGN.md 4b)")
     ap.add_argument("--predictor-gain", type=float, default=50.0, help="'trained-like' predictor scaling (no score ties); 1.0 = plain random init")
     ap.add_argument("--no-calibrate", action="store_true", help="leave the random-init output-text predictor as is (it then keeps or evicts everything)")
     return ap.parse_args()
@@ -435,7 +434,6 @@ def main():
     cfg = DynamicLlavaConfig(num_hidden_layers=args.layers)  # LLaVA-1.5-7B defaults, sparse_layer=2, keep 0.2
     model = build_random_model(cfg, dtype=dtype, device=device, seed=0, predictor_gain=args.predictor_gain)
     model.use_hip_graph = not args.no_graph
-    model.use_block_decode = args.persistent
     model.tp_side_stream = os.environ.get("DL_TP_SIDE", "0") == "1"
     prompt, images = make_inputs(cfg, device, dtype)
     n_prompt = N_SYS + N_IMG + N_Q
@@ -523,7 +521,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
                                f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
                    "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dp_rows_identical": dp_consistent, "dp_max_abs_logit_diff": (lg_diff if world > 1 else None), "hip_graph_decode": model.use_hip_graph,
-                   "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib, "persistent_decode": bool(args.persistent),
+                   "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib,
                    "parity_note": "ids / kept sets / KV lengths bit-exact vs the oracle; logits: 1e-3 asserted literally in fp32, bf16 held to the reference's own "
                                   "eager-bf16 noise class against an fp32 truth (DESIGN.md section 5)"},
         "phases": {"prefill_ms": round(pre_ms, 3), "clip_projector_ms": round(clip_ms, 3), "clip_projector_graph_ms": (None if clip_graph_ms is None else round(clip_graph_ms, 3)), "decode_ms_per_token": round(dec_ms, 4),

@@ -180,9 +180,11 @@ static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab
   if constexpr (FUSED) {
     // in-kernel combine: only when every workgroup of the grid is certainly resident -- what THIS device (CU count of the current
     // partition mode, occupancy of this kernel with its merge buffer) can hold at once, capped at 4 per CU -- and the caller gave a tag
-    if (call_tag >= 0 && n_splits > 1 &&
+    // (occupancy is queried ONCE per kernel and device, with the merge buffer of the LARGEST split count the ABI accepts for this path: a later
+    // launch with more splits than the first one must not inherit a capacity computed for a smaller LDS footprint -- it bounds a spin-wait)
+    if (call_tag >= 0 && n_splits > 1 && n_splits <= 32 &&
         (int64_t)n_splits * n_heads * B <= ink_resident_capacity((const void*)attn_decode_split_kernel<T, D, NW, true, U, true>, NW * 64,
-                                                                  (size_t)n_splits * (D + kAttnPartPad) * sizeof(float))) {
+                                                                  (size_t)32 * (D + kAttnPartPad) * sizeof(float))) {
       const size_t smem = (size_t)n_splits * (D + kAttnPartPad) * sizeof(float);
       hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, true, U, true>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64),
                          smem, st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,

@@ -35,16 +35,6 @@ class VpWeights(Structure):
     ]
 
 
-class BlockPhase(Structure):
-    """Mirror of dl_block_phase (include/dynllava.h): one GEMV phase of dl_decode_block."""
-
-    _fields_ = [("W", c_void_p), ("norm_w", c_void_p), ("out", c_void_p), ("x_in", c_void_p), ("h_in", c_void_p), ("h_out", c_void_p),
-                ("N", c_int32), ("K", c_int32), ("flags", c_int32), ("reserved", c_int32)]
-
-
-BLK_ADDNORM, BLK_SILU_PAIR = 1, 2
-
-
 class TpWeights(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln_w", "ln_b", "l1_w", "l1_b", "l3_w", "l3_b", "l5_w", "l5_b", "l7_w", "l7_b")]
 
@@ -108,8 +98,6 @@ SIGNATURES = {
     "dl_kv_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_prompt_layout": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dl_compact_rows_by_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "dl_decode_block_sync_bytes": (c_int64, [c_int]),
-    "dl_decode_block": (c_int, [POINTER(BlockPhase), c_int, c_void_p, c_int64, c_void_p, c_int, ctypes.c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dl_gemm_smallm_max_m": (c_int, []),
     "dl_gemm_smallm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "dl_gemm_smallm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -647,38 +635,6 @@ def silu_mul_parts(parts, out):
     assert parts.shape[1] == rows and parts.shape[2] == 2 * I
     _check(lib().dl_silu_mul_parts(_p(parts), parts.shape[0], _p(out), rows, I, dtype_code(out.dtype), _stream()), "dl_silu_mul_parts")
     return out
-
-
-# ------------------------------------------------------------------------------------------------
-# chained GEMV phases of a batch-1 decode layer in one launch (dl_decode_block; include/dynllava.h)
-# ------------------------------------------------------------------------------------------------
-def decode_block_sync(max_k, device):
-    """Granule workspace of dl_decode_block (zeroed: tag 0 is never expected)."""
-    return torch.zeros(int(lib().dl_decode_block_sync_bytes(int(max_k))) // 8, dtype=torch.int64, device=device)
-
-
-def block_phases(specs):
-    """specs: list of dicts(W=, norm_w=None, out=None, x_in=None, h_in=None, h_out=None, flags=0) -> ctypes array of dl_block_phase."""
-    arr = (BlockPhase * len(specs))()
-    for e, sp in zip(arr, specs):
-        W = sp["W"]
-        assert W.dim() == 2 and W.is_contiguous()
-        e.W, e.N, e.K, e.flags = W.data_ptr(), W.shape[0], W.shape[1], int(sp.get("flags", 0))
-        for k in ("norm_w", "out", "x_in", "h_in", "h_out"):
-            t = sp.get(k)
-            setattr(e, k, None if t is None else t.data_ptr())
-    return arr
-
-
-def decode_block(phases, sync, pos_base, call_tag, eps, dtype, err=None, n_workgroups=0, spin_limit=0, stamps=None, debug_mode=0):
-    """One launch: the chained GEMV phases of a batch-1 decode layer on the LDS-DMA engine (include/dynllava.h, dl_decode_block)."""
-    _dev(sync, pos_base)
-    assert pos_base.dtype == torch.int32 and sync.dtype == torch.int64
-    _check(
-        lib().dl_decode_block(phases, len(phases), _p(sync), sync.numel() * 8, _p(pos_base), int(call_tag), float(eps), None if err is None else _p(err), int(n_workgroups),
-                              int(spin_limit), None if stamps is None else _p(stamps), int(debug_mode), dtype_code(dtype), _stream()),
-        "dl_decode_block",
-    )
 
 
 def kv_pack_rows(k_slab0, v_slab0, layer_stride, n_layers, keep, kv_len, T_cap):

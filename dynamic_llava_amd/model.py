@@ -407,8 +407,6 @@ class _DecodeState:
         )
         self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
-        # dl_decode_block (opt-in): granule workspace + error word of the in-launch GEMV chain
-        self.blk_sync = None
         # dl_gemv_gu_tp's granules (batch 1; the predictor's stage 1 stages the row in LDS: H <= 5120)
         tpm = getattr(model.model, "output_text_score_predictor", None)
         self.tp_gran = ops.gemv_gu_tp_workspace(tpm.d_model, device) if (B == 1 and tpm is not None and dtype in (torch.bfloat16, torch.float16) and H <= 5120 and H % 8 == 0 and tpm.d_model % 32 == 0) else None
@@ -444,10 +442,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
-        # batch-1 decode: the four weight-streaming launches between two attentions (o_proj -> gate|up -> down -> next q|k|v) as ONE launch on
-        # the LDS-DMA engine (csrc/decode_block.hip).  Bit-identical to the launch path; measured SLOWER on MI355X (the
-        # in-launch all-gathers cost 8-12 us per edge against ~4.6 us of banked weight stream), so it is opt-in
-        self.use_block_decode = False
         self.gemv_max_decode_batch = 3  # B <= this: decode GEMMs run as hand-written weight-streaming GEMVs (dl_gemv)
         # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM.  tools/bench_decode_batch.py: 3.87 / 3.95 /
         # 4.24 ms per step at B = 4 / 8 / 16 against 5.1-5.3 on the library; a wash at 20-24 (4.64 / 4.80 vs 4.66 / 4.75) where the hand-written
@@ -931,15 +925,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
-    def _block_ok(self, st: _DecodeState) -> bool:
-        cfg = self.config
-        H, I = cfg.hidden_size, cfg.intermediate_size
-        return (self.use_block_decode and st.B == 1 and st.use_gemv and self.dtype in (torch.bfloat16, torch.float16) and H % 512 == 0 and I % 8 == 0
-                and H <= 8192 and cfg.num_attention_heads * cfg.head_dim == H)
-
     def check_device_errors(self):
-        """Raises if a launch with in-kernel hand-offs (dl_gemv_qkv_attn, dl_gemv_gu_tp, dl_decode_block) gave up on a wait since the last check
-        (such a launch poisons its output instead of hanging).  Costs one device->host copy: call it where a sync is acceptable."""
+        """Raises if a launch with in-kernel hand-offs (dl_gemv_qkv_attn, dl_gemv_gu_tp) gave up on a wait since the last check (such a launch
+        poisons its output instead of hanging).  Costs one device->host copy: call it where a sync is acceptable."""
         st = self._dstate
         if st is not None:
             code = int(st.blk_err.item())
@@ -947,12 +935,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 st.blk_err.zero_()
                 what = [n for bit, n in ((1, "dl_gemv_qkv_attn (attention never received its projection outputs)"), (2, "dl_gemv_gu_tp (a predictor stage never received its inputs)")) if code & bit]
                 if code & ~3:
-                    what.append(f"dl_decode_block (code {code & ~3:#x}: a workgroup was not resident or a producer never published)")
+                    what.append(f"unknown error bits {code & ~3:#x}")
                 raise ops.HipOpsError("in-kernel hand-off aborted: " + "; ".join(what))
-
-    def check_block_decode(self):
-        """Kept for callers of the opt-in dl_decode_block path: same as check_device_errors()."""
-        self.check_device_errors()
 
     def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
         if st.use_gemv:
@@ -978,26 +962,26 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
         h_cur, h_alt, delta = st.h, st.h2, None
         A = ops.GEMV_ADDNORM
-        block = self._block_ok(st)
-        if block and st.blk_sync is None:
-            st.blk_sync = ops.decode_block_sync(max(cfg.hidden_size, cfg.intermediate_size), self.device)
         for i, layer in enumerate(self.model.layers):
             lens = cache.len_of_layer(i)
             ns = cache.n_splits(i, st.B * nH)
             # q|k|v projection + single-split attention of a batch-1 layer in ONE launch (dl_gemv_qkv_attn: the attention workgroups fetch their
-            # K/V rows while the weights stream and receive the projection as granules): bit-identical to the two launches below
-            fused_attn = self.fuse_qkv_attn and not block and st.B == 1 and ns == 1 and st.qa_gran is not None
+            # K/V rows while the weights stream and receive the projection as granules).  Same bodies as the two launches below, so the
+            # results are bit-identical to them WHEN the stand-alone attention also runs four waves (KVSlabCache.eight_wave_single_split =
+            # False, as the kernel tests set it); by default the stand-alone single-split launch of a small batch runs eight waves -- another
+            # (equally valid) summation order, so DL_FUSE_QKV_ATTN=0 is an A/B of speed, not of bits (tokens / KV lengths: tested equal)
+            fused_attn = self.fuse_qkv_attn and st.B == 1 and ns == 1 and st.qa_gran is not None
             if fused_attn:
                 ops.gemv_qkv_attn(layer.w_qkv, st.qkv, h_cur, h_alt, delta, layer.input_layernorm.weight, eps, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i],
                                   st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
-            elif not (block and i > 0):  # with dl_decode_block the previous layer's launch already produced this layer's q|k|v
+            else:
                 ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
             # the predictor as extra workgroups of this layer's gate|up launch (dl_gemv_gu_tp): its input is that launch's h_in
-            fused_tp = i == SL and use_tp and self.fuse_gu_tp and not block and not self.tp_side_stream and st.B == 1 and st.tp_gran is not None
+            fused_tp = i == SL and use_tp and self.fuse_gu_tp and not self.tp_side_stream and st.B == 1 and st.tp_gran is not None
             if i == SL and use_tp and not fused_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 # only the end-of-step length advance consumes the decision: run the predictor on a side stream (a parallel
                 # branch of the captured graph) on a snapshot of the residual stream, off the layer chain's critical path
@@ -1013,21 +997,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if not fused_attn:
                 ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
                                      call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
-            if block:
-                # o_proj -> gate|up -> down -> next layer's q|k|v (lm_head after the last layer) in one launch; the residual stream goes
-                # h_cur -> (in LDS) -> h_alt exactly as the two add+norm prologues of the launch path update it
-                last = i + 1 == L
-                nxt_w = self.lm_head.weight if last else self.model.layers[i + 1].w_qkv
-                nxt_norm = self.model.norm.weight if last else self.model.layers[i + 1].input_layernorm.weight
-                ph = ops.block_phases([
-                    dict(W=layer.self_attn.o_proj.weight, x_in=st.attn),
-                    dict(W=layer.w_gu, h_in=h_cur, norm_w=layer.post_attention_layernorm.weight, flags=ops.BLK_ADDNORM | ops.BLK_SILU_PAIR),
-                    dict(W=layer.mlp.down_proj.weight),
-                    dict(W=nxt_w, norm_w=nxt_norm, h_out=h_alt, out=st.logits if last else st.qkv, flags=ops.BLK_ADDNORM),
-                ])
-                ops.decode_block(ph, st.blk_sync, cache.len_full, i & 0xff, eps, self.dtype, err=st.blk_err)
-                h_cur, h_alt = h_alt, h_cur
-                continue
             ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
             if fused_tp:
                 tp = self.model.output_text_score_predictor
@@ -1038,8 +1007,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             h_cur, h_alt = h_alt, h_cur
             ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
             delta = st.dn
-        if block:
-            return
         ops.gemv(self.lm_head.weight, st.logits, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=self.model.norm.weight, eps=eps)
         if use_tp and self.tp_side_stream:
             torch.cuda.current_stream().wait_stream(st.tp_stream)  # join before anything reads st.decision
@@ -1115,7 +1082,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         from .cache import _SINGLE_SPLIT_MAX_KEYS
         if self.single_split_keys_override is not None:  # tests: force the schedule to change inside a short generation
             return int(self.single_split_keys_override)
-        if not (self.fuse_qkv_attn and st.B == 1 and st.use_gemv and st.qa_gran is not None and not self._block_ok(st)):
+        if not (self.fuse_qkv_attn and st.B == 1 and st.use_gemv and st.qa_gran is not None):
             return _SINGLE_SPLIT_MAX_KEYS
         w = self.model.layers[0].w_qkv
         keys = int(384 * (w.numel() * w.element_size()) / 100.7e6) // 64 * 64
@@ -1169,7 +1136,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cfg = self.config
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
-        key = (self.use_block_decode, cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
+        key = (cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
                repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split)
         if not self.use_hip_graph:
             for _ in range(n_steps):
@@ -1233,14 +1200,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if cache.sched_at_boundary():
                 if cache._sch["chunks"] > 0:
                     cache.sched_observe(cache._sch["produced"], int(cache.lens[1].max()))
+                    self.check_device_errors()  # the queue has just been drained anyway: a fused launch that gave up must not go unnoticed in a forward() loop either
                 cache.sched_chunk()
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
             if st.qa_gran is not None:
                 st.qa_gran.zero_()
             if st.tp_gran is not None:
                 st.tp_gran.zero_()
-            if st.blk_sync is not None:
-                st.blk_sync.zero_()
             self._decode_step_kernels(st, cache, False)
             sc_ = self.config.sparse_config
             use_tp = bool(sc_["use_text_predictor"] and sc_["use_output_text_predictor"]) and sc_["sparse_layer"] < self.config.num_hidden_layers
@@ -1473,7 +1439,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         inputs = inputs.to(self.device)
         if inputs.shape[0] != cache.batch:
             raise ValueError(f"{inputs.shape[0]} rows of new tokens for a cache of {cache.batch} rows")
-        max_new, min_new, eos, pad = self._gen_kwargs({k: v for k, v in kwargs.items() if k != "past_key_values"}, [0])
+        if bool((inputs == IMAGE_TOKEN_INDEX).any()):
+            # HF's convention (prepare_inputs_for_generation, DML:2835-2848) passes the FULL dialogue and slices input_ids[:, past_length:]; with
+            # the image placeholder in the ids and 576 features in the cache that slice is meaningless, so it is refused instead of appending
+            # the whole prompt to the cache a second time
+            raise ValueError("generate(past_key_values=...) takes ONLY the new turn's token ids; these ids contain the image placeholder, i.e. the full dialogue "
+                             "(the first turn, image included, is already in the cache)")
+        # max_length counts what is already cached plus the new turn (the reference's own length accounting includes the 576 image tokens)
+        max_new, min_new, eos, pad = self._gen_kwargs({k: v for k, v in kwargs.items() if k != "past_key_values"}, [cache.seen_tokens + inputs.shape[1]])
         eos_set = [] if eos is None else (eos if isinstance(eos, list) else [eos])
         out = self.forward(inputs, attention_mask=kwargs.get("attention_mask"), past_key_values=cache)
         cache = out.past_key_values
@@ -1572,8 +1545,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             st.qa_gran.zero_()  # and of dl_gemv_qkv_attn
         if st.tp_gran is not None:
             st.tp_gran.zero_()  # and of dl_gemv_gu_tp
-        if st.blk_sync is not None:
-            st.blk_sync.zero_()  # same rule for the granules of dl_decode_block
         self._eos = -1 if eos is None else (tuple(eos) if isinstance(eos, list) else eos)  # one id or a tuple of up to three (the EOS set)
         self._pad = pad
         self._min_new = min_new
@@ -1717,7 +1688,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 st.obs_ev[slot].record()
                 pending.append((slot, produced))
         if B == 1:
-            self.check_block_decode()
+            self.check_device_errors()
         if dev_layout and int(ent["didx"]["err"].item()) != 0:
             # a row without exactly one image token (text-only row, several images): what was computed is meaningless -- repeat the
             # call with the host-side layout, which handles (or rejects) those rows like the reference does

@@ -249,36 +249,6 @@ int dl_prompt_layout(const int64_t* input_ids, int B, int W, int n_feat, int ima
                      int64_t* text_src, int64_t* text_dst, int64_t* img_dst, int32_t* img_start, int32_t* err, const int32_t* w_true, int n_drop,
                      int32_t* cu_seqlens, int32_t* cu_seqlens_sparse, int32_t* lens, int64_t* last_rows, void* stream);
 
-/* ---- the weight-streaming part of a batch-1 decode layer as ONE launch on the LDS-DMA engine (csrc/decode_block.hip): up to 4 chained
- * GEMV phases, y_i = W_i x_i, where phase 0 reads its input vector from memory (x_in: the attention output) and phase i > 0 consumes
- * phase i-1's output inside the launch (8-byte {tag, bf16 pair} granules in `sync_buf`); the last phase writes `out` to memory.  The
- * decode layer is o_proj (DML:1127) -> gate|up with residual add + RMSNorm prologue and SiLU*up epilogue (DML:1289-1295, 134-139, 328)
- * -> down_proj (DML:328) -> the next layer's q|k|v with add + norm (DML:1011-1013; lm_head DML:2709 after the last layer).  Arithmetic
- * and order are dl_gemv's: the result is bit-identical to the chain of dl_gemv launches it replaces.
- *   flags: DL_BLK_ADDNORM   x = norm_w * rmsnorm(h + delta): delta = the phase's input vector, h = h_in (memory) for the first such
- *                           phase of a block and the block's own running residual afterwards; h_out (may be NULL): the updated
- *                           residual stream is also written to memory (by one workgroup)
- *          DL_BLK_SILU_PAIR W = gate|up [2 I, K]: out[o] = cast(cast(silu(y_o)) * y_{I+o}), I = N / 2 outputs
- * N even, K % 8 == 0, bf16 / f16, batch 1.  pos_base[0] (the new token's position) and call_tag (0..255, e.g. the layer) make the
- * granule tags of this call unique among calls that reuse `sync_buf` (dl_decode_block_sync_bytes(max K); clear it once per request).
- * One 256-thread workgroup per CU (n_workgroups: 0 = all CUs), all of which must be resident: every in-kernel wait is bounded
- * (spin_limit, 0 = default) and a give-up ORs a code into *err_flag (may be NULL).  debug_stamps: NULL; debug_mode: 0 (measurement modes of
- * tools/bench_block.py: 1 = no arithmetic, 2 = loader wave alone; the outputs are then meaningless). */
-#define DL_BLK_ADDNORM 1
-#define DL_BLK_SILU_PAIR 2
-typedef struct dl_block_phase {
-  const void* W;      /* [N, K] row-major */
-  const void* norm_w; /* [K] (DL_BLK_ADDNORM) */
-  void* out;          /* last phase: [N] (or [N/2] with DL_BLK_SILU_PAIR); NULL otherwise */
-  const void* x_in;   /* phase 0: input vector [K]; NULL otherwise */
-  const void* h_in;   /* first DL_BLK_ADDNORM phase: residual stream [K] */
-  void* h_out;        /* DL_BLK_ADDNORM: updated residual stream [K], or NULL */
-  int32_t N, K, flags, reserved;
-} dl_block_phase;
-int64_t dl_decode_block_sync_bytes(int max_k);
-int dl_decode_block(const dl_block_phase* phases, int n_phases, void* sync_buf, int64_t sync_bytes, const int32_t* pos_base, int call_tag,
-                    float eps, int32_t* err_flag, int n_workgroups, int spin_limit, void* debug_stamps, int debug_mode, int dtype, void* stream);
-
 /* ---- decode-step bookkeeping (replaces HF greedy search's argmax + CU:153-164 / CU:197-199 host syncs):
  * next[b] = argmax_v logits[b,v] (lowest index on ties); finished rows emit pad_id;
  * out_ids[b, step[b]] = next[b]; ++step[b]; kv_len_full[b] += 1; kv_len_sparse[b] += decision ? decision[b] : 1.

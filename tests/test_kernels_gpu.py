@@ -652,45 +652,6 @@ def test_compact_rows_by_mask(ops, dtype, total, span0, n_span, H):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("H,I,NQ", [(4096, 11008, 12288), (5120, 13824, 15360), (512, 1536, 1536), (1024, 2816, 1000)])
-def test_decode_block_bit_identical_to_the_gemv_chain(ops, dtype, H, I, NQ):
-    """dl_decode_block (LDS-DMA loader wave + consumer waves, phase outputs handed over as granules inside the launch) against the chain of
-    dl_gemv launches it replaces: every one-phase block and the whole o -> gate|up -> down -> q|k|v block, bit for bit (7B, 13B, small and
-    ragged shapes: rows of 21.5 / 27 / 5.5 pieces, unit counts that do not divide by the CU count), repeated with other positions / call tags on
-    the same granule workspace (no stale granule may be consumed), residual stream included."""
-    g = torch.Generator(device="cuda").manual_seed(3)
-    rnd = lambda *shape, s=0.02: (torch.randn(*shape, device="cuda", generator=g) * s).to(dtype)
-    Wo, Wgu, Wd, Wq = rnd(H, H), rnd(2 * I, H), rnd(H, I), rnd(NQ, H)
-    nw1, nw2 = 1 + rnd(H, s=0.1), 1 + rnd(H, s=0.1)
-    attn, h0 = rnd(1, H, s=1.0), rnd(1, H, s=1.0)
-    eps = 1e-5
-    mk = lambda n: torch.zeros(1, n, dtype=dtype, device="cuda")
-    o_r, act_r, dn_r, qkv_r, hm_r, ho_r = mk(H), mk(I), mk(H), mk(NQ), mk(H), mk(H)
-    A, P = ops.BLK_ADDNORM, ops.BLK_SILU_PAIR
-    ops.gemv(Wo, o_r, x=attn)
-    ops.gemv(Wgu, act_r, mode=ops.GEMV_ADDNORM | ops.GEMV_OUT_SILU_PAIR, h_in=h0, h_out=hm_r, delta=o_r, norm_w=nw1, eps=eps)
-    ops.gemv(Wd, dn_r, x=act_r)
-    ops.gemv(Wq, qkv_r, mode=ops.GEMV_ADDNORM, h_in=hm_r, h_out=ho_r, delta=dn_r, norm_w=nw2, eps=eps)
-    pos = torch.tensor([77], dtype=torch.int32, device="cuda")
-    err = torch.zeros(1, dtype=torch.int32, device="cuda")
-    sync = ops.decode_block_sync(max(H, I), "cuda")
-    one = lambda spec, tag: ops.decode_block(ops.block_phases([spec]), sync, pos, tag, eps, dtype, err=err)
-    y, y2, hm, y3, y4, ho = mk(H), mk(I), mk(H), mk(H), mk(NQ), mk(H)
-    one(dict(W=Wo, x_in=attn, out=y), 1)
-    one(dict(W=Wgu, x_in=o_r, h_in=h0, h_out=hm, norm_w=nw1, out=y2, flags=A | P), 2)
-    one(dict(W=Wd, x_in=act_r, out=y3), 3)
-    one(dict(W=Wq, x_in=dn_r, h_in=hm_r, h_out=ho, norm_w=nw2, out=y4, flags=A), 4)
-    assert torch.equal(y, o_r) and torch.equal(y2, act_r) and torch.equal(hm, hm_r) and torch.equal(y3, dn_r) and torch.equal(y4, qkv_r) and torch.equal(ho, ho_r)
-    for rep in range(12):
-        pos.fill_(100 + rep // 2)  # the same position under another call tag, then the next position
-        qkv_b, ho_b = mk(NQ), mk(H)
-        ph = ops.block_phases([dict(W=Wo, x_in=attn), dict(W=Wgu, h_in=h0, norm_w=nw1, flags=A | P), dict(W=Wd), dict(W=Wq, norm_w=nw2, h_out=ho_b, out=qkv_b, flags=A)])
-        ops.decode_block(ph, sync, pos, rep & 1, eps, dtype, err=err)
-        assert torch.equal(qkv_b, qkv_r) and torch.equal(ho_b, ho_r), rep
-    assert int(err.item()) == 0
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,s", [(170, 4096, 11008, 8), (117, 4096, 4096, 4), (1, 256, 1024, 2), (192, 320, 1088, 8), (200, 512, 2048, 4), (631, 4096, 1024, 1), (33, 256, 128, 1)])
 def test_linear_splitk(ops, dtype, M, N, K, s):
     """Split-K projection: the slices summed in order == F.linear with fp32 accumulation (both tilings: all rows in one tile up to 192 rows,

@@ -182,7 +182,7 @@ def test_generate_schedule_follows_observed_lengths_and_matches_reference_golden
         np.testing.assert_array_equal(out.cpu().numpy()[0], g["ids"][:, 0])
         np.testing.assert_array_equal(model.last_cache[1][-1].numpy(), g["len_last"][n - 1])
         np.testing.assert_array_equal(model.last_cache[1][0].numpy(), g["len_first"][n - 1])
-        splits = sorted({k[3] for k in model._dstate.graphs})  # (layers < sparse_layer, layer sparse_layer, last layer) split factors of each captured step
+        splits = sorted({k[2] for k in model._dstate.graphs})  # (layers < sparse_layer, layer sparse_layer, last layer) split factors of each captured step
         assert any(s[2] == 1 for s in splits) and any(s[2] > 1 for s in splits), f"one call must have replayed both schedules: {splits}"
         print(f"sync_every={sync_every}: captured decode graphs by split factors {splits}")
     # the same request again: same observations -> same schedule -> bit-identical
@@ -552,6 +552,14 @@ def test_generate_continues_on_a_returned_cache_vs_oracle(name):
     assert int(lens[0][0]) == int(pkv[1][0][0]) and int(lens[-1][0]) == int(pkv[1][-1][0])
     with pytest.raises(NotImplementedError):
         model.generate(turn2.cuda(), images=images.cuda(), past_key_values=model.last_cache, max_new_tokens=2)
+    # the HF convention (the FULL dialogue's ids + the cache, DML:2835-2848) must be refused, not silently appended a second time
+    full = torch.cat([ids, r1["sequences"].cpu(), turn2], dim=1)
+    with pytest.raises(ValueError, match="ONLY the new turn"):
+        model.generate(full.cuda(), past_key_values=model.last_cache, max_new_tokens=2)
+    # ... and a max_length-style limit counts what the cache already holds
+    seen = model.last_cache.seen_tokens
+    out3 = model.generate(turn2.cuda(), past_key_values=model.last_cache, max_length=seen + turn2.shape[1] + 3, eos_token_id=None)
+    assert out3.shape[1] == 3
 
 
 def test_generate_with_a_set_of_eos_ids(golden_dir):
@@ -987,6 +995,34 @@ def test_decode_graph_is_reused_across_prompt_lengths():
         outs.setdefault(W, out)
         assert torch.equal(outs[W], out)
     assert len(model._dstate.graphs) == 1, list(model._dstate.graphs)
+
+
+def test_fused_qkv_attention_launch_vs_the_two_launches_default_config():
+    """dl_gemv_qkv_attn (four waves) against dl_gemv + the stand-alone single-split attention as the DEFAULT configuration runs it
+    (eight waves at batch 1: another summation order, so bits may differ -- the kernel-level bit-identity test switches that off).  What must
+    hold in the default configuration: same greedy tokens, same eviction decisions / KV lengths, prefill logits untouched, on the 7B-width model."""
+    from dynamic_llava_amd.builder import build_from_state_dict
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    dtype = torch.bfloat16
+    cfg = fx.llava7b_config(num_hidden_layers=3)
+    cfg.vocab_size = 4096
+    sd = fx.make_state_dict(cfg, seed=11, predictor_gain=50.0)
+    ids = fx.make_prompt(cfg, 35, 20, seed=0)[None].cuda()
+    feats = torch.randn(1, 576, 4096, generator=torch.Generator().manual_seed(3)).to(dtype).cuda()
+    runs = {}
+    for fuse in (True, False):
+        model = build_from_state_dict(DynamicLlavaConfig.from_namespace(cfg), sd, None, dtype=dtype, device="cuda")
+        model.fuse_qkv_attn = fuse
+        out = model.generate(ids, image_features=feats, max_new_tokens=24, eos_token_id=None)
+        model.check_device_errors()
+        runs[fuse] = (out.cpu(), [t.clone() for t in model.last_cache[1]], model.last_prefill_logits.float().cpu().clone())
+        del model
+    assert torch.equal(runs[True][2], runs[False][2]), "the prefill does not depend on the decode launch choice"
+    assert torch.equal(runs[True][0], runs[False][0]), "greedy tokens, fused vs two launches"
+    assert all(torch.equal(a, b) for a, b in zip(runs[True][1], runs[False][1])), "KV lengths (eviction decisions), fused vs two launches"
+    kept = int(runs[True][1][-1][0]) - (35 + 115 + 20)
+    print(f"fused == unfused on tokens and KV lengths over 24 tokens ({kept} of 23 decode tokens kept)")
 
 
 def test_width_buckets_share_prefill_graphs_and_every_width_matches_the_oracle():
