@@ -1611,7 +1611,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     # prefill graphs record into ONE memory pool -- they never run concurrently and leave nothing behind in it (logits, ids
                     # and K/V land in persistent buffers), so a hundred cached shapes cost one shape's activations
                     prefill_path = "graph-capture"
-                    if self._prefill_pool is None:
+                    if self._prefill_pool is None or not any(e["graph"] is not None for e in self._prefill_graphs.values()):
+                        # (the allocator drops a private pool with its last graph: a handle whose graphs are all gone must not be reused)
                         self._prefill_pool = torch.cuda.graph_pool_handle()
                     g_ = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_, pool=self._prefill_pool):
