@@ -217,6 +217,55 @@ def gemv_roofline(model):
     return agg, res
 
 
+def fused_launch_roofline(model):
+    """The PRODUCT's q|k|v launch of a batch-1 decode layer whose rows run one attention workgroup per head: dl_gemv_qkv_attn (projection with the
+    residual-add + RMSNorm prologue AND RoPE / KV append / attention over the slab) on the real weights of every such layer and the K/V the last
+    generate() left in the slab, captured in one hipGraph and timed between HIP events.  Algorithmic bytes per launch = the layer's q|k|v weights
+    + 2 T H E of K/V + the appended row (SURVEY 8d's decode_attn bytes)."""
+    from dynamic_llava_amd import hip_ops as ops
+
+    st, cache = model._dstate, model.last_cache
+    if st is None or cache is None or st.B != 1 or st.qa_gran is None:
+        return None
+    cfg = model.config
+    nH, nKV, d, SL = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.sparse_config["sparse_layer"]
+    cos, sin = model._rope
+    layers = list(enumerate(model.model.layers))[SL:]
+    T = int(cache.lens[1][0]) + 1
+    if T > cache.single_split_max_keys or not layers:
+        return None
+    delta = torch.randn_like(st.h)
+
+    def step():
+        for i, layer in layers:
+            ops.gemv_qkv_attn(layer.w_qkv, st.qkv, st.h, st.h2, delta, layer.input_layernorm.weight, cfg.rms_norm_eps, cos, sin, cache.len_full, cache.lens[1], cache.k[i], cache.v[i],
+                              st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
+
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        step()
+    torch.cuda.current_stream().wait_stream(s_)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(5):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    model.check_device_errors()
+    us = a.elapsed_time(b) / (5 * len(layers)) * 1e3
+    H = nH * d
+    nb = layers[0][1].w_qkv.numel() * 2 + 2 * T * nKV * d * 2 + 2 * H * 2
+    return {"kernel": "dl_gemv_qkv_attn (gemv_qkv_attn_kernel: the product's q|k|v + attention launch of layers >= sparse_layer at batch 1)",
+            "shape": f"{list(layers[0][1].w_qkv.shape)} bf16 + K/V of T={T} keys, {len(layers)} layers' weights and slabs in one graph", "bytes": nb, "us": round(us, 3),
+            "achieved": round(nb / us / 1e3, 1), "frac": round(nb / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+
 def other_kernel_rooflines(model, n_tokens):
     """HBM-bound row kernels on the workload's prefill shape (algorithmic bytes per SURVEY 8d)."""
     from dynamic_llava_amd import hip_ops as ops
@@ -491,7 +540,9 @@ def main():
     nH, d = cfg.num_attention_heads, cfg.head_dim
     roof_attn = decode_attn_roofline(model, f"bench workload, layers>=2 at the last decode step: B=1, T={t_sparse + 1} (170 prompt + kept decode tokens + the new one)", 1, [t_sparse + 1], nH, d)
     roof_main, gemv_shapes = gemv_roofline(model)
-    extra = [
+    model.generate(prompt, images=images, max_new_tokens=T_new, do_sample=False, num_beams=1, use_cache=True, eos_token_id=None)  # leave the slab at the final lengths
+    roof_fused = fused_launch_roofline(model)
+    extra = ([roof_fused] if roof_fused else []) + [
         roof_attn,
         decode_attn_roofline(model, f"bench workload, layers 0-1 at the last decode step: B=1, T={t_full + 1}", 1, [t_full + 1], nH, d),
         decode_attn_roofline(model, "configs[2]-like: B=32 ragged T~U[200,900]", 32, [200 + (i * 701) % 700 for i in range(32)], nH, d),
@@ -511,8 +562,20 @@ def main():
         traffic_src = (f"{pmc_rel}: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes over the four "
                        f"per-layer dl_gemv shapes: measured traffic / algorithmic bytes = {ratio:.4f}, applied to this run's average launch")
         roof_attn["traffic_over_algorithmic_pmc"] = pmc["decode_attn B=1 T=226"]["traffic_over_algorithmic"]
+        if roof_fused and "gemv_qkv_attn T=226" in pmc:
+            roof_fused["traffic_over_algorithmic_pmc"] = pmc["gemv_qkv_attn T=226"]["traffic_over_algorithmic"]
     except Exception:
         pass
+    # the WHOLE decode step of the product (every launch of the captured graph, idle gaps included): algorithmic bytes = all streamed weights +
+    # the K/V rows the step's attention reads (2 T H E per layer) over the measured time per token
+    H_ = cfg.hidden_size
+    SL_ = cfg.sparse_config["sparse_layer"]
+    kv_bytes = sum(2 * ((t_full if i < SL_ else t_sparse) + 1) * H_ * 2 for i in range(cfg.num_hidden_layers))
+    step_bytes = roof_main["bytes_per_step"] + kv_bytes
+    whole = {"bytes_per_token": int(step_bytes), "ms_per_token": round(dec_ms, 4), "achieved": round(step_bytes / dec_ms / 1e6, 1),
+             "frac": round(step_bytes / dec_ms / 1e6 / HBM_PEAK_GBS, 4),
+             "note": "all weights streamed by one decode step + the K/V rows its attention reads (at the final lengths), over decode_ms_per_token of the timed generate() "
+                     "calls: includes every launch of the step's graph, launch boundaries and the host loop"}
     res = {
         "metric": "prefill+decode tokens/s/GPU, LLaVA-1.5-7B @ vision_keep_rate=0.2, 1 img",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -533,7 +596,7 @@ def main():
         # dominant kernel of the step by time (~84 % of a decode step, rocprof: profiles/): the hand-written weight-streaming GEMV
         "roofline": {"bound": "hbm", "achieved": roof_main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof_main["frac"], "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": roof_main["kernel"], "launches_per_step": roof_main["launches_per_step"], "bytes_per_launch": roof_main["bytes"], "us_per_launch": roof_main["us"],
-                     "bytes_per_step": roof_main["bytes_per_step"], "us_per_step": roof_main["us_per_step"],
+                     "bytes_per_step": roof_main["bytes_per_step"], "us_per_step": roof_main["us_per_step"], "whole_step": whole,
                      "note": "averaged over the 129 dl_gemv launches of one decode step replayed as one hipGraph between HIP events on the launch stream (includes inter-kernel gaps); the north_star's sparse-attention kernel is the first entry of roofline_kernels; in the product step the q|k|v launches of the single-split layers also carry that layer's attention workgroups (dl_gemv_qkv_attn) and one gate|up launch the text predictor (dl_gemv_gu_tp): same streaming body, same bytes"},
         "roofline_kernels": extra,
     }

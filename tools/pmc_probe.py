@@ -51,6 +51,46 @@ for tag, N, K, mode in [("gemv qkv", 12288, 4096, ops.GEMV_ADDNORM), ("gemv o", 
         torch.cuda.synchronize()
     plan.append({"tag": tag, "kernel": "gemv_kernel", "N": N, "K": K, "algorithmic_bytes": N * K * 2})
 
+# round 4: the two FUSED launches of the product's batch-1 decode step (the PMC passes only covered the separate kernels)
+from dynamic_llava_amd.model import TextPredictor  # noqa: E402
+
+for T in (226, 380):  # dl_gemv_qkv_attn: q|k|v projection + single-workgroup attention over T keys (the new token included)
+    N, K = 3 * H, H
+    T_cap = T + 8
+    h, h2, dl = (torch.randn(1, K, device=dev, dtype=dt) for _ in range(3))
+    nw = torch.ones(K, device=dev, dtype=dt)
+    qkv, out = torch.empty(1, N, device=dev, dtype=dt), torch.empty(1, H, device=dev, dtype=dt)
+    lens = torch.tensor([T - 1], dtype=torch.int32, device=dev)
+    gran = ops.gemv_qkv_attn_workspace(nH, nH, d, dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        w = torch.randn(N, K, device=dev, dtype=dt) * 0.02
+        k = torch.randn(1, nH, T_cap, d, device=dev, dtype=dt)
+        v = torch.randn_like(k)
+        torch.cuda.synchronize()
+        ops.gemv_qkv_attn(w, qkv, h, h2, dl, nw, 1e-5, cos, sin, lens, lens, k, v, out, gran, rep + 1, nH, nH, d, err=err)
+        torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    plan.append({"tag": f"gemv_qkv_attn T={T}", "kernel": "gemv_qkv_attn_kernel", "N": N, "K": K, "algorithmic_bytes": N * K * 2 + 2 * T * H * 2 + 2 * H * 2})
+
+tp = TextPredictor(H, 512).to(device=dev, dtype=dt)
+N, K = 22016, H
+h, h2, dl = (torch.randn(1, K, device=dev, dtype=dt) for _ in range(3))
+nw = torch.ones(K, device=dev, dtype=dt)
+y = torch.empty(1, N // 2, device=dev, dtype=dt)
+tp_ws, tp_lg, dec = ops.text_predictor_workspace(1, tp.d_model, dev), torch.zeros(1, 2, device=dev), torch.ones(1, dtype=torch.int32, device=dev)
+pos = torch.tensor([300], dtype=torch.int32, device=dev)
+gran = ops.gemv_gu_tp_workspace(tp.d_model, dev)
+err = torch.zeros(1, dtype=torch.int32, device=dev)
+for rep in range(3):
+    w = torch.randn(N, K, device=dev, dtype=dt) * 0.02
+    torch.cuda.synchronize()
+    ops.gemv_gu_tp(w, y, h, h2, dl, nw, 1e-5, tp._weights(), tp.d_model, tp_ws, tp_lg, dec, pos, gran, rep + 1, err=err)
+    torch.cuda.synchronize()
+assert int(err.item()) == 0
+tp_bytes = sum(p_.numel() * 2 for p_ in tp.parameters())
+plan.append({"tag": "gemv_gu_tp", "kernel": "gemv_gu_tp_kernel", "N": N, "K": K, "algorithmic_bytes": N * K * 2 + tp_bytes + K * 2})
+
 for rows in (631, 170):
     x = torch.randn(rows, H, device=dev, dtype=dt)
     w = torch.ones(H, device=dev, dtype=dt)
