@@ -452,6 +452,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
         # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
+        # split-K slices of the two WIDE projections (q|k|v, gate|up: 768 / 1376 sixteen-neuron wave tiles without any split) on dl_gemm_smallm; 0 = the
+        # kernel's own choice (8 / 4).  Round 4 measured the review's proposal -- fewer slices, so the consumers re-read fewer fp32 partial slabs --
+        # and it LOSES at every batch: 2 slices 4.09 / 4.39 / 4.65 / 4.94 ms per step at B = 8 / 16 / 24 / 32 against 3.71 / 4.04 / 4.60 / 4.87 (library
+        # 5.03 / 5.20 / 4.64 / 4.80): many short weight streams beat few long ones by more than the partial traffic costs (tools/bench_decode_batch.py)
+        self.smallm_wide_slices = int(os.environ.get("DL_SMALLM_WIDE_SLICES", "0"))
         if os.environ.get("DL_SMALLM_MAX_B"):  # tuning experiments only
             self.smallm_max_decode_batch = int(os.environ["DL_SMALLM_MAX_B"])
         self.record_timing = False  # generate(): HIP events around the prefill / decode parts -> self.last_timing (tools/bench_varlen_stream.py)
@@ -1027,7 +1032,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
-            qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws) if sm else F.linear(st.x, layer.w_qkv)
+            qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws, n_slices=self.smallm_wide_slices) if sm else F.linear(st.x, layer.w_qkv)
             ns = cache.n_splits(i, st.B * nH)
             ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
                                  call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
@@ -1035,7 +1040,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if sm:
                 parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)
                 ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=st.x)
-                parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws)
+                parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws, n_slices=self.smallm_wide_slices)
                 ops.silu_mul_parts(parts, st.act)
                 parts, _ = ops.gemm_smallm_parts(st.act, layer.mlp.down_proj.weight, ws)
                 ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)

@@ -22,14 +22,16 @@ def run(B, n_new):
     torch.cuda.synchronize(); return time.perf_counter() - t0
 
 
-for B in (1, 2, 3, 4, 8, 16, 20, 24, 32):
-    for maxb in (0, 32):  # 0: dl_gemm_smallm off (library GEMM past the dl_gemv range)
-        if B <= 3 and maxb == 0:
+batches = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 8, 16, 20, 24, 32]
+for B in batches:
+    for maxb, wide in ((0, 0), (32, 0), (32, 2), (32, 3)):  # 0: dl_gemm_smallm off (library GEMM past the dl_gemv range); wide: split-K slices of q|k|v and gate|up
+        if B <= 3 and (maxb == 0 or wide):
             continue
         model.smallm_max_decode_batch = maxb
+        model.smallm_wide_slices = wide
         model._dstate = None
         for _ in range(2):
             run(B, 33); run(B, 1)
         t = min(run(B, 65) for _ in range(3)) - min(run(B, 1) for _ in range(3))
         path = "dl_gemv" if B <= model.gemv_max_decode_batch else ("dl_gemm_smallm" if B <= maxb else "library GEMM")
-        print(f"B={B} ({path:12s}): {t / 64 * 1e3:6.3f} ms/step  {B * 64 / t:8.1f} tok/s", flush=True)
+        print(f"B={B} ({path:12s}{', q|k|v and gate|up in ' + str(wide) + ' slices' if wide and path == 'dl_gemm_smallm' else ''}): {t / 64 * 1e3:6.3f} ms/step  {B * 64 / t:8.1f} tok/s", flush=True)
