@@ -156,57 +156,16 @@ __device__ __forceinline__ void attn_split_prefetch2(AttnSplitState<T, D, NW, U>
   }
 }
 
-// Part 2.  qrow / krow / vrow: the D-element q, k, v vectors of this head (un-rotated when FUSED; any address space).  cos_/sin_:
-// RoPE tables [n_pos, D]; pos: the new token's position.  sm_m/sm_l [NG], sm_o [NG][D]: LDS scratch of this (virtual) workgroup.
-// `write_kv`: this workgroup stores the new token's rotated key / value at slab slot T_old (one writer per kv head).
-// Contains ONE __syncthreads(): every wave of the real workgroup must call it.  Result for threads vtid < D: M, L (same for all)
-// and O = un-normalised output of head dim vtid.
-// `before_new` (default: nothing): called by EVERY thread right before the new token's key / value rows are read -- a caller whose k / v rows
-// arrive late (dl_gemv_qkv_attn: they are the last outputs of the projection running in the same launch) waits for them there, after the
-// scores / softmax / P.V over the slab keys, which need q only.  With a waiter the k / v loads and the key's RoPE move behind the call; the
-// arithmetic and its order are the same.
-struct AttnNoWait {
-  __device__ __forceinline__ void operator()() const {}
-};
-template <typename T, int D, int NW, bool FUSED, int U, typename BeforeNew = AttnNoWait>
-__device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s, int vtid, const void* qrow_, const void* krow_,
-                                                  const void* vrow_, const void* cos_, const void* sin_, int n_pos, int pos, float scale,
-                                                  bool write_kv, int T_cap, float* sm_m, float* sm_l, float* sm_o, float& M_out, float& L_out,
-                                                  float& O_out, BeforeNew before_new = BeforeNew()) {
-  constexpr bool LATE = !__is_same(BeforeNew, AttnNoWait);
+// ---- the two halves of attn_split_finish that the "new key last" variant below shares with it (same code, same order, same bits) ----
+// Online softmax over this split's slab keys [k0, k1): per lane group (m, l, o[V]).
+template <typename T, int D, int NW, int U>
+__device__ __forceinline__ void attn_split_keys(AttnSplitState<T, D, NW, U>& s, const float (&qv)[Elem<T>::kVec], float scale, float& m, float& l,
+                                                float (&o)[Elem<T>::kVec]) {
   using St = AttnSplitState<T, D, NW, U>;
-  using S = typename St::S;
   constexpr int V = St::V, LPK = St::LPK, KPW = St::KPW, NG = St::NG;
-  constexpr int HALF = D / 2;
-  const int c = s.c, g = s.g, wid = s.wid, lane = s.lane;
-  const int cpar = c < HALF ? c + HALF : c - HALF;
-  const S* qrow = reinterpret_cast<const S*>(qrow_);
-  float qv[V], cs[V], sn[V];
-  const bool owns_new = FUSED && s.T_old >= s.k0 && s.T_old < s.k1s && wid == 0 && g == 0;
-  float kn[V], vn[V];
-  if constexpr (FUSED) {
-    int p = pos;
-    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
-    float own[V], par[V], kown[V], kpar[V];
-    load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
-    load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
-    load16<T>(qrow + c, own);
-    load16<T>(qrow + cpar, par);
-    if (owns_new && !LATE) {
-      const S* krow = reinterpret_cast<const S*>(krow_);
-      load16<T>(krow + c, kown);
-      load16<T>(krow + cpar, kpar);
-      load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
-    }
-    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
-    if (owns_new && !LATE) {
-      if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
-    }
-  } else {
-    load16<T>(qrow + c, qv);
-  }
-
-  float m = -INFINITY, l = 0.f, o[V];
+  const int g = s.g, wid = s.wid;
+  m = -INFINITY;
+  l = 0.f;
 #pragma unroll
   for (int i = 0; i < V; ++i) o[i] = 0.f;
 
@@ -289,6 +248,105 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
       }
     }
   }
+}
+
+// Merge of the NG lane groups' (m, l, o) through LDS -> (M, L, O) for threads vtid < D.  Contains ONE __syncthreads().
+template <typename T, int D, int NW, int U>
+__device__ __forceinline__ void attn_split_lds_merge(const AttnSplitState<T, D, NW, U>& s, int vtid, float m, float l, const float (&o)[Elem<T>::kVec], float* sm_m,
+                                                     float* sm_l, float* sm_o, float& M_out, float& L_out, float& O_out) {
+  using St = AttnSplitState<T, D, NW, U>;
+  constexpr int V = St::V, LPK = St::LPK, KPW = St::KPW, NG = St::NG;
+  const int c = s.c, g = s.g, wid = s.wid, lane = s.lane;
+  const int gg = wid * KPW + g;
+  if ((lane % LPK) == 0) {
+    sm_m[gg] = m;
+    sm_l[gg] = l;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) sm_o[gg * D + c + i] = o[i];
+  __syncthreads();
+  M_out = -INFINITY;
+  L_out = 0.f;
+  O_out = 0.f;
+  if (vtid < D) {
+    // NG <= 32 partials: every LDS read is issued before the first use (a rolled loop pays the LDS latency NG times over)
+    float mg[NG], lg[NG], og[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      mg[i] = sm_m[i];
+      lg[i] = sm_l[i];
+      og[i] = sm_o[i * D + vtid];
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) M = fmaxf(M, mg[i]);
+    float L = 0.f, O = 0.f;
+    if (M > -INFINITY) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const float w = __expf(mg[i] - M);  // empty group: exp(-inf) = 0
+        L += lg[i] * w;
+        O += og[i] * w;
+      }
+    }
+    M_out = M;
+    L_out = L;
+    O_out = O;
+  }
+}
+
+// Part 2.  qrow / krow / vrow: the D-element q, k, v vectors of this head (un-rotated when FUSED; any address space).  cos_/sin_:
+// RoPE tables [n_pos, D]; pos: the new token's position.  sm_m/sm_l [NG], sm_o [NG][D]: LDS scratch of this (virtual) workgroup.
+// `write_kv`: this workgroup stores the new token's rotated key / value at slab slot T_old (one writer per kv head).
+// Contains ONE __syncthreads(): every wave of the real workgroup must call it.  Result for threads vtid < D: M, L (same for all)
+// and O = un-normalised output of head dim vtid.
+// `before_new` (default: nothing): called by EVERY thread right before the new token's key / value rows are read -- a caller whose k / v rows
+// arrive late (dl_gemv_qkv_attn: they are the last outputs of the projection running in the same launch) waits for them there, after the
+// scores / softmax / P.V over the slab keys, which need q only.  With a waiter the k / v loads and the key's RoPE move behind the call; the
+// arithmetic and its order are the same.
+struct AttnNoWait {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <typename T, int D, int NW, bool FUSED, int U, typename BeforeNew = AttnNoWait>
+__device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s, int vtid, const void* qrow_, const void* krow_,
+                                                  const void* vrow_, const void* cos_, const void* sin_, int n_pos, int pos, float scale,
+                                                  bool write_kv, int T_cap, float* sm_m, float* sm_l, float* sm_o, float& M_out, float& L_out,
+                                                  float& O_out, BeforeNew before_new = BeforeNew()) {
+  constexpr bool LATE = !__is_same(BeforeNew, AttnNoWait);
+  using St = AttnSplitState<T, D, NW, U>;
+  using S = typename St::S;
+  constexpr int V = St::V, LPK = St::LPK, KPW = St::KPW, NG = St::NG;
+  constexpr int HALF = D / 2;
+  const int c = s.c, g = s.g, wid = s.wid, lane = s.lane;
+  const int cpar = c < HALF ? c + HALF : c - HALF;
+  const S* qrow = reinterpret_cast<const S*>(qrow_);
+  float qv[V], cs[V], sn[V];
+  const bool owns_new = FUSED && s.T_old >= s.k0 && s.T_old < s.k1s && wid == 0 && g == 0;
+  float kn[V], vn[V];
+  if constexpr (FUSED) {
+    int p = pos;
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    float own[V], par[V], kown[V], kpar[V];
+    load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
+    load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
+    load16<T>(qrow + c, own);
+    load16<T>(qrow + cpar, par);
+    if (owns_new && !LATE) {
+      const S* krow = reinterpret_cast<const S*>(krow_);
+      load16<T>(krow + c, kown);
+      load16<T>(krow + cpar, kpar);
+      load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
+    }
+    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
+    if (owns_new && !LATE) {
+      if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
+    }
+  } else {
+    load16<T>(qrow + c, qv);
+  }
+
+  float m, l, o[V];
+  attn_split_keys<T, D, NW, U>(s, qv, scale, m, l, o);
 
   if constexpr (FUSED && LATE) {
     before_new();
@@ -326,41 +384,77 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
   }
 
   // merge the NG lane groups of this (virtual) workgroup
-  const int gg = wid * KPW + g;
-  if ((lane % LPK) == 0) {
-    sm_m[gg] = m;
-    sm_l[gg] = l;
+  attn_split_lds_merge<T, D, NW, U>(s, vtid, m, l, o, sm_m, sm_l, sm_o, M_out, L_out, O_out);
+}
+
+// "New key last" (round 4, dl_gemv_qkv_attn only): the caller's k / v rows are the LAST outputs of the projection that runs in the same launch, so
+// whatever happens after they arrive is the launch's tail.  attn_split_finish folds the new token into lane group 0's partial and THEN merges the
+// lane groups through LDS (barrier + NG-way merge behind the wait).  Here the slab keys' partials are merged FIRST -- while the weights still stream --
+// and after the wait the D threads that hold (M, L, O[d]) fold the new token in themselves: RoPE of their own element of k, one 128-term dot product
+// (wave reduction + one LDS word per wave), one softmax update, the slab append, the normalised output.  Same mathematics; the new token's term is
+// added after the slab merge instead of before it, so the last bits may differ from attn_split_finish (kernel tests: noise class, not bits).
+//   rows: LDS, the raw (un-rotated) q | k | v vectors of this head, 3 D elements (q valid on entry, k / v valid after before_new())
+//   red : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains TWO __syncthreads() + before_new()'s.
+template <typename T, int D, int NW, int U, typename BeforeNew>
+__device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const void* cos_,
+                                                          const void* sin_, int n_pos, int pos, float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
+                                                          float* sm_o, float* red, float& out, BeforeNew before_new) {
+  using St = AttnSplitState<T, D, NW, U>;
+  using S = typename St::S;
+  constexpr int V = St::V;
+  constexpr int HALF = D / 2;
+  static_assert(D % 64 == 0 && D / 64 <= NW, "the D finishing threads are whole waves of this workgroup");
+  const int c = s.c;
+  const int cpar = c < HALF ? c + HALF : c - HALF;
+  int p = pos;
+  p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+  const S* cos_row = reinterpret_cast<const S*>(cos_) + (int64_t)p * D;  // table = cat(freqs, freqs)
+  const S* sin_row = reinterpret_cast<const S*>(sin_) + (int64_t)p * D;
+  float qv[V];
+  {
+    float cs[V], sn[V], own[V], par[V];
+    load16<T>(cos_row + (c % HALF), cs);
+    load16<T>(sin_row + (c % HALF), sn);
+    load16<T>(rows + c, own);
+    load16<T>(rows + cpar, par);
+    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
   }
-#pragma unroll
-  for (int i = 0; i < V; ++i) sm_o[gg * D + c + i] = o[i];
-  __syncthreads();
-  M_out = -INFINITY;
-  L_out = 0.f;
-  O_out = 0.f;
+  float m, l, o[V];
+  attn_split_keys<T, D, NW, U>(s, qv, scale, m, l, o);
+  float M, L, O;
+  attn_split_lds_merge<T, D, NW, U>(s, vtid, m, l, o, sm_m, sm_l, sm_o, M, L, O);
+  // this thread's own element of the rotated query (needs q only: done before the wait)
+  const int d = vtid < D ? vtid : 0, dpar = d < HALF ? d + HALF : d - HALF;
+  const float cs1 = Elem<T>::to_f(cos_row[d % HALF]), sn1 = Elem<T>::to_f(sin_row[d % HALF]);
+  const float q_own = Elem<T>::to_f(rows[d]), q_par = Elem<T>::to_f(rows[dpar]);
+  const float q_rot = Elem<T>::round(Elem<T>::round(q_own * cs1) + Elem<T>::round((d < HALF ? -q_par : q_par) * sn1));  // DML:283-284, as rope16
+  before_new();
+  float part = 0.f, k_rot = 0.f, vv = 0.f;
   if (vtid < D) {
-    // NG <= 32 partials: every LDS read is issued before the first use (a rolled loop pays the LDS latency NG times over)
-    float mg[NG], lg[NG], og[NG];
+    const float k_own = Elem<T>::to_f(rows[D + d]), k_par = Elem<T>::to_f(rows[D + dpar]);
+    k_rot = Elem<T>::round(Elem<T>::round(k_own * cs1) + Elem<T>::round((d < HALF ? -k_par : k_par) * sn1));
+    vv = Elem<T>::to_f(rows[2 * D + d]);
+    part = q_rot * k_rot;
+  }
+  part = wave_sum(part);
+  if (s.lane == 0) red[s.wid] = part;
+  __syncthreads();
+  out = 0.f;
+  if (vtid < D) {
+    float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      mg[i] = sm_m[i];
-      lg[i] = sm_l[i];
-      og[i] = sm_o[i * D + vtid];
+    for (int w = 0; w < D / 64; ++w) dot += red[w];
+    const float sc_ = dot * scale;
+    const float mn = fmaxf(M, sc_);
+    const float alpha = __expf(M - mn);  // empty slab: M = -inf -> 0
+    const float pn = __expf(sc_ - mn);
+    out = (O * alpha + pn * vv) / (L * alpha + pn);
+    if (write_kv && s.T_old < T_cap) {  // one writer per kv head; eviction = the length is simply not advanced later
+      S* kd = const_cast<S*>(s.kb) - c + (int64_t)s.T_old * D;  // (kb / vb carry this lane's column offset c)
+      S* vd = const_cast<S*>(s.vb) - c + (int64_t)s.T_old * D;
+      kd[d] = Elem<T>::from_f(k_rot);
+      vd[d] = rows[2 * D + d];
     }
-    float M = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) M = fmaxf(M, mg[i]);
-    float L = 0.f, O = 0.f;
-    if (M > -INFINITY) {
-#pragma unroll
-      for (int i = 0; i < NG; ++i) {
-        const float w = __expf(mg[i] - M);  // empty group: exp(-inf) = 0
-        L += lg[i] * w;
-        O += og[i] * w;
-      }
-    }
-    M_out = M;
-    L_out = L;
-    O_out = O;
   }
 }
 

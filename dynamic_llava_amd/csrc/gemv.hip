@@ -464,12 +464,14 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
     __syncthreads();
   };
   fetch(0, D, h * D + D - 1, true);
-  float M, L, O;
-  attn_split_finish<T, D, NW, true, U>(st, tid, rows, rows + D, rows + 2 * D, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], 1.0f / sqrtf((float)D),
-                                       h % n_rep == 0, a.T_cap, sm_m, sm_l, sm_o, M, L, O,
-                                       [&]() { fetch(D, 3 * D, (a.n_heads + a.n_kv_heads + kvh) * D + D - 1, false); });
+  // the slab keys' partials are merged while the projection still streams; the new token is folded in by the D finishing threads after its k / v
+  // rows (the projection's last outputs) have arrived: attn_split_finish_newlast
+  __shared__ float red[NW];
+  float o_head;
+  attn_split_finish_newlast<T, D, NW, U>(st, tid, rows, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], 1.0f / sqrtf((float)D), h % n_rep == 0, a.T_cap, sm_m, sm_l,
+                                         sm_o, red, o_head, [&]() { fetch(D, 3 * D, (a.n_heads + a.n_kv_heads + kvh) * D + D - 1, false); });
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
-  if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : (L > 0.f ? O / L : 0.f));
+  if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o_head);
   if (any_bad && tid == 0 && a.err) atomicOr(a.err, 1);
 }
 
