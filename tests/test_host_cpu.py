@@ -133,3 +133,73 @@ def test_library_has_no_packed_f32_op_that_reads_src1_high_half_into_the_low_lan
         bad += [ln.strip() for ln in dis.splitlines() if re.search(r"v_pk_(fma|mul|add)_f32", ln) and re.search(r"op_sel:\[[01],1", ln)]
     assert n_mfma > 0, "disassembly looks empty"
     assert not bad, f"{len(bad)} packed fp32 instructions with op_sel[1]=1, e.g. {bad[:3]}"
+
+
+def test_decode_schedule_rule_is_the_same_chunked_and_step_by_step():
+    """Round 4: the decode attention is scheduled from the lengths the predictor leaves, by a deterministic rule (KVSlabCache.sched_*): chunks of
+    4, 4, then `sync_every` steps; chunk i uses the evicted group's longest row as observed after chunk i-2.  generate() evaluates the rule chunk by
+    chunk (observations arrive one chunk late), a forward()-driven loop step by step with an immediate read at every chunk boundary.  Both must give
+    every decode step the same bounds -- that is what keeps generate() and a forward() loop bit-identical -- and the bounds must always cover the
+    true lengths (they size split-KV launches; a bound below the true length would only cost speed, but it would be a bug in the rule)."""
+    import random
+
+    import torch
+
+    from dynamic_llava_amd.cache import KVSlabCache
+
+    def lens_after(keep, n_sparse0, produced):  # evicted group's length when `produced` tokens exist: prefill + kept decode tokens so far
+        return n_sparse0 + sum(keep[: produced - 1])
+
+    for seed in range(20):
+        rnd = random.Random(seed)
+        S = rnd.choice([1, 3, 8, 16])
+        n_full0, n_sparse0, max_new = rnd.randint(40, 700), rnd.randint(20, 200), rnd.randint(2, 90)
+        keep = [rnd.random() < rnd.choice([0.0, 0.3, 0.9, 1.0]) for _ in range(max_new)]
+        # --- generate(): chunk by chunk, observation of chunk k consumed before chunk k + 2 ---
+        a = KVSlabCache(2, 1, 1, 1, 8, 8, torch.float32, "cpu")
+        a.logical_cap = a.sparse_cap = 10 ** 6
+        a.sched_begin(n_full0, n_sparse0, S)
+        bounds_a, produced, pending = {}, 1, []
+        while produced < max_new:
+            while len(pending) > 1:
+                at = pending.pop(0)
+                a.sched_observe(at, lens_after(keep, n_sparse0, at))
+            n = min(a.sched_chunk(), max_new - produced)
+            for j in range(n):
+                bounds_a[produced + j] = (a.key_bound(0), a.key_bound(1))
+            produced += n
+            a.sched_advance(n)
+            pending.append(produced)
+        # --- forward() loop: step by step, immediate read at chunk boundaries ---
+        b = KVSlabCache(2, 1, 1, 1, 8, 8, torch.float32, "cpu")
+        b.logical_cap = b.sparse_cap = 10 ** 6
+        b.sched_begin(n_full0, n_sparse0, S)
+        bounds_b = {}
+        for produced in range(1, max_new):
+            if b.sched_at_boundary():
+                if b._sch["chunks"] > 0:
+                    b.sched_observe(b._sch["produced"], lens_after(keep, n_sparse0, produced))
+                b.sched_chunk()
+            bounds_b[produced] = (b.key_bound(0), b.key_bound(1))
+            b.sched_advance(1)
+        assert bounds_a == bounds_b, f"seed {seed}: the two evaluations of the rule disagree"
+        for produced, (fb, sb) in bounds_a.items():
+            # the step that consumes token `produced` attends the rows cached so far + the new token
+            assert fb >= n_full0 + produced and sb >= lens_after(keep, n_sparse0, produced) + 1, (seed, produced, fb, sb)
+            assert sb <= lens_after(keep, n_sparse0, produced) + 1 + 2 * max(S, 4) + 4, "the bound stays within two chunks of the true length"
+
+
+def test_split_factor_follows_the_bounds_not_the_capacity():
+    import torch
+
+    from dynamic_llava_amd.cache import KVSlabCache
+
+    c = KVSlabCache(4, 2, 1, 32, 128, 2048, torch.float32, "meta")
+    c.logical_cap, c.sparse_cap = 2048, 1588  # BASELINE configs[4]: 1588 slots reserved in layers >= 2 ...
+    assert c.n_splits(3, 40) == 6 and c.n_splits(0, 40) == 6
+    c.set_bounds(700, 260)  # ... of which 259 + the new token are in use
+    assert c.n_splits(0, 40) == 6 and c.n_splits(3, 40) == 5
+    c.single_split_max_keys = 576  # the fused q|k|v + attention launch of the 13B model (model._single_split_max_keys)
+    assert c.n_splits(3, 40) == 1 and c.n_splits(0, 40) == 6
+    c.set_bounds(None, None)
+    assert c.n_splits(3, 40) == 6

@@ -51,13 +51,17 @@ if "c2" in which:
         res["configs[2]"]["ref_gpu_error"] = repr(e)
     del model
     torch.cuda.empty_cache()
-if "c4" in which:
+if "c4" in which or "c4cal" in which:
     cfg = DynamicLlavaConfig(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40)
     model = build_random_model(cfg, dtype=dt, device=dev, seed=0, predictor_gain=50.0)
     g = torch.Generator().manual_seed(2)
     ids = torch.cat([torch.tensor([1]), torch.randint(3, 32000, (34,), generator=g), torch.tensor([-200]), torch.randint(3, 32000, (29,), generator=g)])[None].to(dev)
     images = torch.randn(1, 3, 336, 336, generator=g).to(dt).to(dev)
     T_new = 2048 - 640
+    calib = None
+    if "c4cal" in which:  # the random-init output-text predictor evicts nearly everything; calibrated like bench.py does (about half kept)
+        import bench as _bench
+        calib = _bench.calibrate_text_predictor(model, ids, images, 64)
     t_full, out = wall(lambda: model.generate(ids, images=images, max_new_tokens=T_new, eos_token_id=None), 1)
     lens = model.last_cache.lens.cpu().tolist()
     t_pre, _ = wall(lambda: model.generate(ids, images=images, max_new_tokens=1, eos_token_id=None))
@@ -65,5 +69,7 @@ if "c4" in which:
     dec_ms = (t_full - t_pre) / (T_new - 1) * 1e3
     res["configs[4]"] = {"model": "LLaVA-1.5-13B random init", "prompt_tokens": 640, "new_tokens": T_new, "step_ms": round(t_full * 1e3, 1), "prefill_ms": round(t_pre * 1e3, 2),
                          "decode_ms_per_token": round(dec_ms, 4), "decode_tokens_per_s": round(1e3 / dec_ms, 1), "tokens_per_s": round((640 + T_new) / t_full, 1),
-                         "kv_len_layers_0_1": lens[0][0], "kv_len_layers_ge2": lens[1][0], "kept_of_generated": lens[1][0] - 179, "decode_weight_stream_GBps": round(wbytes / dec_ms / 1e6, 1)}
+                         "kv_len_layers_0_1": lens[0][0], "kv_len_layers_ge2": lens[1][0], "kept_of_generated": lens[1][0] - 179, "decode_weight_stream_GBps": round(wbytes / dec_ms / 1e6, 1),
+                         "text_predictor_calibrated_keep_fraction": calib, "decode_graphs_captured": len(model._dstate.graphs),
+                         "split_factors_seen": sorted({k[2] for k in model._dstate.graphs})}
 print(json.dumps(res))

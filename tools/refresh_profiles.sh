@@ -15,8 +15,18 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $RAW/pmc_write -o p -- python tools
 python tools/pmc_report.py "$(find $RAW/pmc_fetch -name '*.db' | head -1)" "$(find $RAW/pmc_write -name '*.db' | head -1)" gpurun_out/pmc_fetch.log > gpurun_out/pmc_report.txt
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $RAW/pmc_mfma -o m -- python tools/prefill_kernels.py > /dev/null 2>&1
 python tools/mfma_report.py "$(find $RAW/pmc_mfma -name '*.db' | head -1)" > gpurun_out/mfma_report.txt
+# round 4: the variable-shape request stream (VQAL:123-196) next to the same stream with one width; BASELINE configs[2] / [4]; the N > 1 path as two
+# ranks on this one GPU (gloo; bench.py starts its own ranks)
+python tools/bench_varlen_stream.py > gpurun_out/stream_var.json 2> gpurun_out/stream_var.err
+python tools/bench_varlen_stream.py --fixed > gpurun_out/stream_fixed.json 2>/dev/null
+python tools/bench_configs.py c2 c4 2>/dev/null | tail -1 > gpurun_out/bench_configs_2_4.json
+python tools/bench_configs.py c4cal 2>/dev/null | tail -1 > gpurun_out/bench_configs_4_calibrated.json
+DL_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_dp2_one_gpu.json 2> gpurun_out/bench_dp2_one_gpu.err
+python bench.py --steps 10 --warmup 3 --new-tokens 128 --no-cpu-baseline --no-ref-gpu > gpurun_out/bench_b1_128tokens.json 2>/dev/null
 # then, back in the development container (gpurun merges gpurun_out/):
 #   cp gpurun_out/bench_default.json profiles/${R}_bench_b1.json; cp gpurun_out/kernel_stats.txt profiles/${R}_bench_kernel_stats.txt
 #   grep -v '^JSON' gpurun_out/pmc_report.txt > profiles/${R}_pmc_traffic.txt; grep '^JSON' gpurun_out/pmc_report.txt | sed 's/^JSON //' > profiles/${R}_pmc_traffic.json
 #   grep -v '^JSON' gpurun_out/mfma_report.txt > profiles/${R}_prefill_mfma_util.txt
+#   cp gpurun_out/stream_var.json profiles/${R}_varlen_stream.json; cp gpurun_out/stream_fixed.json profiles/${R}_varlen_stream_fixed_width.json
+#   cp gpurun_out/bench_configs_2_4.json profiles/${R}_bench_configs_2_4.json; cp gpurun_out/bench_dp2_one_gpu.json profiles/${R}_bench_dp2_one_gpu.json
 echo "done: gpurun_out/{bench_default.json,kernel_stats.txt,pmc_report.txt,mfma_report.txt}"
