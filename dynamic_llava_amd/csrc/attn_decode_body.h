@@ -393,12 +393,14 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
 // and after the wait the D threads that hold (M, L, O[d]) fold the new token in themselves: RoPE of their own element of k, one 128-term dot product
 // (wave reduction + one LDS word per wave), one softmax update, the slab append, the normalised output.  Same mathematics; the new token's term is
 // added after the slab merge instead of before it, so the last bits may differ from attn_split_finish (kernel tests: noise class, not bits).
-//   rows: LDS, the raw (un-rotated) q | k | v vectors of this head, 3 D elements (q valid on entry, k / v valid after before_new())
-//   red : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains TWO __syncthreads() + before_new()'s.
-template <typename T, int D, int NW, int U, typename BeforeNew>
+//   rows : LDS, the raw (un-rotated) q vector of this head, D elements.
+//   fetch_kv(d, dpar, k_own, k_par, v): called by the threads vtid < D after the slab merge -- returns the raw k[d], k[dpar], v[d] of the new token
+//          (dl_gemv_qkv_attn polls the projection's granules there: three requests per thread in one round trip, no LDS staging, no barrier).
+//   red  : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains TWO __syncthreads().
+template <typename T, int D, int NW, int U, typename FetchKV>
 __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const void* cos_,
                                                           const void* sin_, int n_pos, int pos, float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
-                                                          float* sm_o, float* red, float& out, BeforeNew before_new) {
+                                                          float* sm_o, float* red, float& out, FetchKV fetch_kv) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
   constexpr int V = St::V;
@@ -428,12 +430,14 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
   const float cs1 = Elem<T>::to_f(cos_row[d % HALF]), sn1 = Elem<T>::to_f(sin_row[d % HALF]);
   const float q_own = Elem<T>::to_f(rows[d]), q_par = Elem<T>::to_f(rows[dpar]);
   const float q_rot = Elem<T>::round(Elem<T>::round(q_own * cs1) + Elem<T>::round((d < HALF ? -q_par : q_par) * sn1));  // DML:283-284, as rope16
-  before_new();
   float part = 0.f, k_rot = 0.f, vv = 0.f;
+  S v_raw = S();
   if (vtid < D) {
-    const float k_own = Elem<T>::to_f(rows[D + d]), k_par = Elem<T>::to_f(rows[D + dpar]);
+    S k_own_raw, k_par_raw;
+    fetch_kv(d, dpar, k_own_raw, k_par_raw, v_raw);
+    const float k_own = Elem<T>::to_f(k_own_raw), k_par = Elem<T>::to_f(k_par_raw);
     k_rot = Elem<T>::round(Elem<T>::round(k_own * cs1) + Elem<T>::round((d < HALF ? -k_par : k_par) * sn1));
-    vv = Elem<T>::to_f(rows[2 * D + d]);
+    vv = Elem<T>::to_f(v_raw);
     part = q_rot * k_rot;
   }
   part = wave_sum(part);
@@ -453,7 +457,7 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
       S* kd = const_cast<S*>(s.kb) - c + (int64_t)s.T_old * D;  // (kb / vb carry this lane's column offset c)
       S* vd = const_cast<S*>(s.vb) - c + (int64_t)s.T_old * D;
       kd[d] = Elem<T>::from_f(k_rot);
-      vd[d] = rows[2 * D + d];
+      vd[d] = v_raw;
     }
   }
 }

@@ -425,19 +425,23 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
   constexpr int NG = St::NG;
   __shared__ float sm_m[NG], sm_l[NG];
   __shared__ float sm_o[NG * D];
-  __shared__ __attribute__((aligned(16))) S rows[3 * D];
+  __shared__ __attribute__((aligned(16))) S rows[D];
   const int h = (int)blockIdx.x - n_gemv, tid = threadIdx.x;
   const int n_rep = a.n_heads / a.n_kv_heads, kvh = h / n_rep;
   const int T_old = a.kv_len[0];
   St st;
   attn_split_issue<T, D, NW, true, U>(st, tid, a.k_slab, a.v_slab, a.stride_b, a.stride_h, T_old, 1, 0, kvh, 0, 1, a.T_cap, 256);
   attn_split_prefetch2<T, D, NW, U>(st);  // two trips in flight while the projection produces q
-  // q first (the projection's first third): the slab keys need nothing else; k / v of the new token (its last third) only before the end
+  // q first (the projection's first third): the slab keys need nothing else; k / v of the new token (its last third) only at the very end
   bool bad = false;
-  auto fetch = [&](int i0, int i1, int last, bool gate) {  // rows[i0, i1) <- granules; gate: one lane watches `last` (produced last) with long naps first
-    if (gate && tid == 0) {
+  auto value_of = [](u64_t v) -> S {
+    if constexpr (Elem<T>::kBytes == 4) return __uint_as_float((uint32_t)v);
+    else return (S)(uint32_t)v;
+  };
+  {  // rows[0, D) <- the q granules of this head; one lane watches the head's last neuron (produced last) with long naps first
+    if (tid == 0) {
       for (int spins = 0;; ++spins) {
-        if ((uint32_t)(gr_load(a.gran + last) >> 32) == tag) break;
+        if ((uint32_t)(gr_load(a.gran + h * D + D - 1) >> 32) == tag) break;
         if (spins > (1 << 20)) {
           bad = true;
           break;
@@ -446,11 +450,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
       }
     }
     __syncthreads();
-    for (int i = i0 + tid; i < i1; i += kGemvThreads) {
-      const int n = i < D ? h * D + i : (i < 2 * D ? (a.n_heads + kvh) * D + (i - D) : (a.n_heads + a.n_kv_heads + kvh) * D + (i - 2 * D));
+    for (int i = tid; i < D; i += kGemvThreads) {
       u64_t v = 0;
       for (int spins = 0;; ++spins) {
-        v = gr_load(a.gran + n);
+        v = gr_load(a.gran + h * D + i);
         if ((uint32_t)(v >> 32) == tag) break;
         if (spins > (1 << 20)) {
           bad = true;
@@ -458,18 +461,34 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      if constexpr (Elem<T>::kBytes == 4) rows[i] = __uint_as_float((uint32_t)v);
-      else rows[i] = (S)(uint32_t)v;
+      rows[i] = value_of(v);
     }
     __syncthreads();
-  };
-  fetch(0, D, h * D + D - 1, true);
-  // the slab keys' partials are merged while the projection still streams; the new token is folded in by the D finishing threads after its k / v
-  // rows (the projection's last outputs) have arrived: attn_split_finish_newlast
+  }
+  // the slab keys' partials are merged while the projection still streams; the new token is folded in by the D finishing threads, each of which
+  // receives its three values (k[d], k[d +- D/2], v[d]: the projection's last outputs) straight from the granules: attn_split_finish_newlast
   __shared__ float red[NW];
   float o_head;
+  const u64_t* gk = a.gran + (int64_t)(a.n_heads + kvh) * D;
+  const u64_t* gv = a.gran + (int64_t)(a.n_heads + a.n_kv_heads + kvh) * D;
   attn_split_finish_newlast<T, D, NW, U>(st, tid, rows, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], 1.0f / sqrtf((float)D), h % n_rep == 0, a.T_cap, sm_m, sm_l,
-                                         sm_o, red, o_head, [&]() { fetch(D, 3 * D, (a.n_heads + a.n_kv_heads + kvh) * D + D - 1, false); });
+                                         sm_o, red, o_head, [&](int d, int dpar, S& k_own, S& k_par, S& v_new) {
+                                           u64_t g0 = 0, g1 = 0, g2 = 0;
+                                           for (int spins = 0;; ++spins) {  // the three requests travel together; repeated until all carry this step's tag
+                                             g0 = gr_load(gk + d);
+                                             g1 = gr_load(gk + dpar);
+                                             g2 = gr_load(gv + d);
+                                             if ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag) break;
+                                             if (spins > (1 << 20)) {
+                                               bad = true;
+                                               break;
+                                             }
+                                             __builtin_amdgcn_s_sleep(1);
+                                           }
+                                           k_own = value_of(g0);
+                                           k_par = value_of(g1);
+                                           v_new = value_of(g2);
+                                         });
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o_head);
   if (any_bad && tid == 0 && a.err) atomicOr(a.err, 1);
