@@ -1373,8 +1373,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return int(max_new), min(min_new, int(max_new)), eos, (0 if pad is None else int(pad))
 
     @torch.no_grad()
-    def _generate_sample(self, inputs, images, **kwargs):
-        """do_sample=True: temperature / top_k / top_p sampling as HF's logits warpers define them (TemperatureLogitsWarper,
+    def _generate_sample(self, inputs, images, greedy=False, **kwargs):
+        """`greedy=True` (round 4): the same plain loop over forward() taking the argmax -- the route for requests the device-side greedy loop does not
+        take (more than three EOS ids: dl_decode_advance compares three).  do_sample=True: temperature / top_k / top_p sampling as HF's logits warpers define them (TemperatureLogitsWarper,
         TopKLogitsWarper, TopPLogitsWarper: the smallest set of most probable tokens whose mass reaches top_p is kept), drawn with
         torch's generator -- a plain loop over forward() (no hipGraph: this is the convenience path, the harness default is greedy).
         Token streams cannot match HF's draw for draw (different RNG consumption); the distribution per step is the same."""
@@ -1408,7 +1409,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 remove[:, -1] = False  # always keep the most probable token
                 z = z.masked_fill(remove.scatter(1, si, remove), float("-inf"))
             scores.append(z)
-            nxt = torch.multinomial(z.softmax(dim=-1), 1, generator=gen)[:, 0]
+            nxt = z.argmax(dim=-1) if greedy else torch.multinomial(z.softmax(dim=-1), 1, generator=gen)[:, 0]
             nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
             toks.append(nxt)
             for e in eos_set:
@@ -1536,7 +1537,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         lens, indices, B = lay["lens"], lay["indices"], lay["B"]
         max_new, min_new, eos, pad = self._gen_kwargs(kwargs, lens)
         if isinstance(eos, list) and len(eos) > 3:
-            raise NotImplementedError("more than three eos_token_ids on the greedy device path (three ids are compared on the device)")
+            # three ids are compared on the device; a longer EOS set takes the plain forward() loop (same kernels per step, host-side stop test)
+            return self._generate_sample(inputs, images, greedy=True, **{k: v for k, v in kwargs.items() if k not in ("do_sample", "sync_every")})
         cache = self._pooled_cache(B, max(lens) + max_new + 1)
         self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)

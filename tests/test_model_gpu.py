@@ -583,8 +583,12 @@ def test_generate_with_a_set_of_eos_ids(golden_dir):
         # min_new_tokens bans the whole set: the run must go past position `first`
         out = model.generate(ids, images=images, max_new_tokens=n, min_new_tokens=first + 2, eos_token_id=[gold[3], gold[5]])
         assert out.shape[1] > first + 1 and gold[3] not in out.cpu().tolist()[0][: first + 2] and gold[5] not in out.cpu().tolist()[0][: first + 2]
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, images=images, max_new_tokens=2, eos_token_id=[1, 2, 3, 4])
+    # more than three EOS ids (round 4): the plain forward() loop takes over -- same tokens, stop at the first id of the set
+    others = [t for t in range(cfg.vocab_size) if t not in gold][:3]
+    out = model.generate(ids, images=images, max_new_tokens=n, eos_token_id=others + [gold[4], never])
+    assert out.cpu().tolist()[0] == gold[: gold.index(gold[4]) + 1]
+    out = model.generate(ids, images=images, max_new_tokens=n, eos_token_id=others + [never])
+    assert out.cpu().tolist()[0] == gold
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])

@@ -21,7 +21,9 @@
 
 #include "gemv_dot.h"
 #include "granule.h"
-#include "lds_dma.h"
+#include "lds_dma_r03.h"
+#include "dynllava.h"
+#include "experiments_abi.h"
 
 namespace dl {
 

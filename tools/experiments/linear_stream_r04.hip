@@ -17,7 +17,8 @@
 #include <type_traits>
 
 #include "dl_common.h"
-#include "../../include/dynllava.h"
+#include "dynllava.h"
+#include "experiments_abi.h"
 
 namespace dl {
 
