@@ -239,7 +239,7 @@ def fused_launch_roofline(model):
     def step():
         for i, layer in layers:
             ops.gemv_qkv_attn(layer.w_qkv, st.qkv, st.h, st.h2, delta, layer.input_layernorm.weight, cfg.rms_norm_eps, cos, sin, cache.len_full, cache.lens[1], cache.k[i], cache.v[i],
-                              st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, finish_ws=st.fin_ws if (model.defer_attn_finish and st.fin_ws is not None) else None)
+                              st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
 
     s_ = torch.cuda.Stream()
     s_.wait_stream(torch.cuda.current_stream())
@@ -261,7 +261,7 @@ def fused_launch_roofline(model):
     us = a.elapsed_time(b) / (5 * len(layers)) * 1e3
     H = nH * d
     nb = layers[0][1].w_qkv.numel() * 2 + 2 * T * nKV * d * 2 + 2 * H * 2
-    return {"kernel": "dl_gemv_qkv_attn (gemv_qkv_attn_kernel: the product's q|k|v + attention launch of layers >= sparse_layer at batch 1" + ("; the new token is folded in by the o_proj launch that follows, dl_gemv_oproj_attn_finish)" if (model.defer_attn_finish and st.fin_ws is not None) else ")"),
+    return {"kernel": "dl_gemv_qkv_attn (gemv_qkv_attn_kernel: the product's q|k|v + attention launch of layers >= sparse_layer at batch 1)",
             "shape": f"{list(layers[0][1].w_qkv.shape)} bf16 + K/V of T={T} keys, {len(layers)} layers' weights and slabs in one graph", "bytes": nb, "us": round(us, 3),
             "achieved": round(nb / us / 1e3, 1), "frac": round(nb / us / 1e3 / HBM_PEAK_GBS, 4)}
 

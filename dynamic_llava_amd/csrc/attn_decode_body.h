@@ -400,7 +400,7 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
 template <typename T, int D, int NW, int U, typename FetchKV>
 __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const void* cos_,
                                                           const void* sin_, int n_pos, int pos, float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
-                                                          float* sm_o, float* red, float& out, FetchKV fetch_kv, float* defer_ws = nullptr) {
+                                                          float* sm_o, float* red, float& out, FetchKV fetch_kv) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
   constexpr int V = St::V;
@@ -430,20 +430,6 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
   const float cs1 = Elem<T>::to_f(cos_row[d % HALF]), sn1 = Elem<T>::to_f(sin_row[d % HALF]);
   const float q_own = Elem<T>::to_f(rows[d]), q_par = Elem<T>::to_f(rows[dpar]);
   const float q_rot = Elem<T>::round(Elem<T>::round(q_own * cs1) + Elem<T>::round((d < HALF ? -q_par : q_par) * sn1));  // DML:283-284, as rope16
-  if (defer_ws) {
-    // the caller finishes elsewhere (dl_gemv_oproj_attn_finish: the NEXT launch's prologue folds the new token in): publish this head's slab state
-    // [M, L, O[D], q_rot[D]] and leave -- this workgroup never waits for the projection's last outputs
-    out = 0.f;
-    if (vtid < D) {
-      defer_ws[2 + d] = O;
-      defer_ws[2 + D + d] = q_rot;
-      if (d == 0) {
-        defer_ws[0] = M;
-        defer_ws[1] = L;
-      }
-    }
-    return;
-  }
   float part = 0.f, k_rot = 0.f, vv = 0.f;
   S v_raw = S();
   if (vtid < D) {

@@ -49,16 +49,10 @@ __device__ __forceinline__ uint32_t gemv_bits(float f) {
 // The body is a device function so that dl_gemv_qkv_attn can run it as part of a wider grid: `bid` / `nblk` are this workgroup's index and the
 // number of workgroups that share the rows.  gran != nullptr: every output is ALSO published as an 8-byte {gtag, value bits} granule
 // (granule.h) for consumers inside the same launch.
-struct GemvNoPrologue {
-  template <typename S_>
-  __device__ __forceinline__ void operator()(S_*) const {}
-};
-// MODE 3: `custom(xs)` builds x in LDS (called by every thread of the workgroup before the barrier that precedes the stream)
-template <typename T, int B, int MODE, bool PAIR, int R, int U, typename Custom = GemvNoPrologue>
+template <typename T, int B, int MODE, bool PAIR, int R, int U>
 __device__ __forceinline__ void gemv_body(const void* __restrict__ W_, int N, int K, const void* x_, int64_t x_rs, const void* __restrict__ h_,
                                           void* __restrict__ h_out_, const void* __restrict__ delta_, const void* __restrict__ nw_, float eps,
-                                          void* __restrict__ y_, int64_t y_rs, const int bid, const int nblk, u64_t* gran, uint32_t gtag,
-                                          Custom custom = Custom()) {
+                                          void* __restrict__ y_, int64_t y_rs, const int bid, const int nblk, u64_t* gran, uint32_t gtag) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,8 +182,6 @@ __device__ __forceinline__ void gemv_body(const void* __restrict__ W_, int N, in
         for (int e = 0; e < V; ++e) g[e] = Elem<T>::round(g[e] / (1.0f + expf(-g[e]))) * u[e];
         store16<T>(xs + b * K + v * V, g);
       }
-  } else if constexpr (MODE == 3) {
-    custom(xs);
   } else {
     const S* x = reinterpret_cast<const S*>(x_);
 #pragma unroll
@@ -415,7 +407,6 @@ struct QkvAttnArgs {
   int64_t stride_b, stride_h;
   int n_pos, T_cap, n_heads, n_kv_heads, call_tag;
   u64_t* gran; int32_t* err;
-  float* fin_ws;  // non-NULL: the new token is folded in by the next launch (dl_gemv_oproj_attn_finish); per head [M, L, O[D], q_rot[D]]
 };
 
 template <typename T, int D>
@@ -497,97 +488,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
                                            k_own = value_of(g0);
                                            k_par = value_of(g1);
                                            v_new = value_of(g2);
-                                         }, a.fin_ws ? a.fin_ws + (int64_t)h * (2 * D + 2) : nullptr);
+                                         });
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
-  if (a.fin_ws) {  // deferred finish: poison the published state instead of the output
-    if (any_bad && tid < D) a.fin_ws[(int64_t)h * (2 * D + 2) + 2 + tid] = __uint_as_float(0x7fc00000u);
-  } else if (tid < D) {
-    store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o_head);
-  }
+  if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o_head);
   if (any_bad && tid == 0 && a.err) atomicOr(a.err, 1);
-}
-
-// ---- dl_gemv_oproj_attn_finish: o_proj of a batch-1 decode layer whose prologue FINISHES the attention (round 4) ----
-// In dl_gemv_qkv_attn the attention's last step -- folding in the new token, whose k / v are the projection's LAST outputs -- was the launch's tail
-// (~2.7 us after the stream's end).  With `finish_ws` the attention workgroups leave after the slab keys (publishing per head [M, L, O[D], q_rot[D]])
-// and this launch, which follows it and reads the complete q|k|v row from memory, does that step while it builds its own x: every workgroup
-// rotates the new key (DML:283-284), takes the 32 x 128-term scores (wave reduction + one LDS word per wave), the softmax update, normalises and
-// ROUNDS the attention output to the model dtype exactly where the reference materialises it (DML:1114-1122 -> bf16 before o_proj, DML:1127), and
-// streams W_o against it; workgroup 0 also appends the rotated key / the value to the slab (CU:109-268) and stores the attention output row.
-// The arithmetic is attn_split_finish_newlast's (same formulas, same roundings); the 128-term dot is reduced in another order.
-struct OprojFinArgs {
-  const void* W; int N, K; void* y;
-  const float* fin_ws; const void* qkv; const void* cos_tab; const void* sin_tab; const int32_t* pos_base; const int32_t* kv_len;
-  void* k_slab; void* v_slab; int64_t stride_h; void* attn_out;
-  int n_pos, T_cap, n_heads, n_kv_heads;
-};
-
-template <typename T, int D>
-__global__ __launch_bounds__(kGemvThreads) void gemv_oproj_attnfin_kernel(OprojFinArgs a) {
-  using S = typename Elem<T>::storage;
-  constexpr int HALF = D / 2, WPH = D / 64;  // waves per head
-  __shared__ float red[64 * 4];              // [round][wave]: K / 256 rounds <= 64
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int n_rep = a.n_heads / a.n_kv_heads;
-  gemv_body<T, 1, 3, false, 1, 8>(a.W, a.N, a.K, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, a.y, a.N, (int)blockIdx.x, (int)gridDim.x, nullptr, 0u, [&](S* xs) {
-    const int rounds = a.K / kGemvThreads;  // elements e = tid + 256 j; a head's D elements sit in WPH consecutive waves of one round
-    int p = a.pos_base[0];
-    p = p < 0 ? 0 : (p >= a.n_pos ? a.n_pos - 1 : p);
-    const S* cos_row = reinterpret_cast<const S*>(a.cos_tab) + (int64_t)p * D;
-    const S* sin_row = reinterpret_cast<const S*>(a.sin_tab) + (int64_t)p * D;
-    const S* row = reinterpret_cast<const S*>(a.qkv);
-    const int T_old = a.kv_len[0];
-    const float scale = 1.0f / sqrtf((float)D);
-    constexpr int MAXR = 32;  // K <= 8192
-    float k_rot[MAXR], part[MAXR];
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-      k_rot[j] = 0.f;
-      part[j] = 0.f;
-      if (j < rounds) {
-        const int e = tid + kGemvThreads * j, h = e / D, d = e % D, kvh = h / n_rep;
-        const int dpar = d < HALF ? d + HALF : d - HALF;
-        const float cs1 = Elem<T>::to_f(cos_row[d % HALF]), sn1 = Elem<T>::to_f(sin_row[d % HALF]);
-        const S* krow = row + (int64_t)(a.n_heads + kvh) * D;
-        const float k_own = Elem<T>::to_f(krow[d]), k_par = Elem<T>::to_f(krow[dpar]);
-        k_rot[j] = Elem<T>::round(Elem<T>::round(k_own * cs1) + Elem<T>::round((d < HALF ? -k_par : k_par) * sn1));
-        part[j] = a.fin_ws[(int64_t)h * (2 * D + 2) + 2 + D + d] * k_rot[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j)
-      if (j < rounds) {
-        const float sum = wave_sum(part[j]);
-        if (lane == 0) red[j * 4 + wid] = sum;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j)
-      if (j < rounds) {
-        const int e = tid + kGemvThreads * j, h = e / D, d = e % D, kvh = h / n_rep;
-        const int w0 = wid / WPH * WPH;  // first wave of this head inside the round
-        float dot = 0.f;
-#pragma unroll
-        for (int w = 0; w < WPH; ++w) dot += red[j * 4 + w0 + w];
-        const float* ws = a.fin_ws + (int64_t)h * (2 * D + 2);
-        const float M = ws[0], L = ws[1], O = ws[2 + d];
-        const S v_raw = row[(int64_t)(a.n_heads + a.n_kv_heads + kvh) * D + d];
-        const float sc_ = dot * scale;
-        const float mn = fmaxf(M, sc_);
-        const float alpha = __expf(M - mn);  // empty slab: M = -inf -> 0
-        const float pn = __expf(sc_ - mn);
-        const float o = (O * alpha + pn * Elem<T>::to_f(v_raw)) / (L * alpha + pn);
-        const S o_bits = Elem<T>::from_f(o);
-        xs[e] = o_bits;
-        if (blockIdx.x == 0) {
-          reinterpret_cast<S*>(a.attn_out)[e] = o_bits;
-          if (h % n_rep == 0 && T_old < a.T_cap) {  // one writer per kv head; eviction = the length is simply not advanced later
-            reinterpret_cast<S*>(a.k_slab)[(int64_t)kvh * a.stride_h + (int64_t)T_old * D + d] = Elem<T>::from_f(k_rot[j]);
-            reinterpret_cast<S*>(a.v_slab)[(int64_t)kvh * a.stride_h + (int64_t)T_old * D + d] = v_raw;
-          }
-        }
-      }
-  });
 }
 
 // ---- dl_gemv_gu_tp: the gate|up projection of layer `sparse_layer` and the text predictor, in ONE launch ----
@@ -726,8 +630,8 @@ extern "C" int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads,
 extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* qkv,
                                 const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base, const int32_t* kv_len, void* k_slab,
                                 void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
-                                int32_t* err_flag, void* finish_ws, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream) {
-  DL_REQUIRE(W && h_in && norm_w && qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && (out || finish_ws) && granules, "dl_gemv_qkv_attn: NULL pointer");
+                                int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream) {
+  DL_REQUIRE(W && h_in && norm_w && qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && out && granules, "dl_gemv_qkv_attn: NULL pointer");
   DL_REQUIRE(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && (head_dim == 128 || head_dim == 64) && K > 0 && n_pos > 0 && T_cap > 0,
              "dl_gemv_qkv_attn: bad shape");
   DL_REQUIRE(!delta || (h_out && h_out != h_in), "dl_gemv_qkv_attn: h_out must be a distinct buffer when delta is given");
@@ -742,7 +646,7 @@ extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_
     a.W = W; a.h = h_in; a.h_out = h_out; a.delta = delta; a.nw = norm_w; a.y = qkv; a.N = N; a.K = K; a.eps = eps;
     a.cos_tab = cos_tab; a.sin_tab = sin_tab; a.pos_base = pos_base; a.kv_len = kv_len; a.k_slab = k_slab; a.v_slab = v_slab; a.out = out;
     a.stride_b = slab_stride_b; a.stride_h = slab_stride_h; a.n_pos = n_pos; a.T_cap = T_cap; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads;
-    a.call_tag = call_tag; a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag; a.fin_ws = reinterpret_cast<float*>(finish_ws);
+    a.call_tag = call_tag; a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag;
 
     const int groups = (N + 7) / 8;
     if (grid_cap > 2 * n_heads) grid_cap -= n_heads;  // projection + attention workgroups together stay within what is resident at once
@@ -756,36 +660,6 @@ extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_
   return DL_OK;
 }
 
-
-extern "C" int64_t dl_gemv_attn_finish_workspace_bytes(int n_heads, int head_dim) { return (int64_t)n_heads * (2 * head_dim + 2) * (int64_t)sizeof(float); }
-
-extern "C" int dl_gemv_oproj_attn_finish(const void* W, int N, const void* finish_ws, const void* qkv, const void* cos_tab, const void* sin_tab, int n_pos,
-                                         const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_h, int T_cap,
-                                         void* attn_out, void* y, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream) {
-  DL_REQUIRE(W && finish_ws && qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && attn_out && y, "dl_gemv_oproj_attn_finish: NULL pointer");
-  DL_REQUIRE(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && (head_dim == 128 || head_dim == 64) && N > 0 && n_pos > 0 && T_cap > 0 && grid_cap >= 0,
-             "dl_gemv_oproj_attn_finish: bad shape");
-  const int K = n_heads * head_dim;
-  DL_REQUIRE(K % kGemvThreads == 0 && K <= 32 * kGemvThreads, "dl_gemv_oproj_attn_finish: n_heads * head_dim = %d must be a multiple of 256, at most 8192", K);
-  if (grid_cap == 0) grid_cap = kGemvGridCap;
-  hipStream_t st = as_stream(stream);
-  int rc = DL_OK;
-  DL_DISPATCH_DTYPE(dtype, T, {
-    DL_REQUIRE(Elem<T>::kBytes == 2, "dl_gemv_oproj_attn_finish: 16-bit dtypes only");
-    OprojFinArgs a;
-    a.W = W; a.N = N; a.K = K; a.y = y; a.fin_ws = reinterpret_cast<const float*>(finish_ws); a.qkv = qkv; a.cos_tab = cos_tab; a.sin_tab = sin_tab;
-    a.pos_base = pos_base; a.kv_len = kv_len; a.k_slab = k_slab; a.v_slab = v_slab; a.stride_h = slab_stride_h; a.attn_out = attn_out;
-    a.n_pos = n_pos; a.T_cap = T_cap; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads;
-    const int groups = (N + 3) / 4;  // one neuron per wave per pass
-    const int grid = groups < grid_cap ? groups : grid_cap;
-    const size_t smem = (size_t)K * Elem<T>::kBytes;
-    if (head_dim == 128) hipLaunchKernelGGL((gemv_oproj_attnfin_kernel<T, 128>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
-    else hipLaunchKernelGGL((gemv_oproj_attnfin_kernel<T, 64>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
-  });
-  if (rc != DL_OK) return rc;
-  DL_CHECK_LAUNCH("dl_gemv_oproj_attn_finish");
-  return DL_OK;
-}
 
 extern "C" int dl_gemv_max_batch(int K, int dtype) {
   const int es = dtype == DL_F32 ? 4 : 2;

@@ -87,10 +87,7 @@ SIGNATURES = {
     "dl_gemv_gu_tp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, POINTER(TpWeights), c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dl_gemv_qkv_attn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dl_gemv_attn_finish_workspace_bytes": (c_int64, [c_int, c_int]),
-    "dl_gemv_oproj_attn_finish": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
-                                          c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                 c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_attn_policy_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "dl_attn_policy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p]),
@@ -447,11 +444,9 @@ def gemv_qkv_attn_workspace(n_heads, n_kv_heads, head_dim, device):
 
 
 def gemv_qkv_attn(w, qkv, h_in, h_out, delta, norm_w, eps, cos, sin, pos_base, kv_len, k_slab, v_slab, out, granules, call_tag, n_heads, n_kv_heads, head_dim,
-                  err=None, grid_cap=0, finish_ws=None):
-    """One launch = gemv(w, qkv, mode=GEMV_ADDNORM, ...) + attn_decode_rope(qkv, ..., n_splits=1) for ONE row (see include/dynllava.h).
-    finish_ws (gemv_attn_finish_workspace): the attention stops after the slab keys; gemv_oproj_attn_finish must follow and produces `out` + the K/V append."""
-    _dev(w, qkv, h_in, h_out, delta, norm_w, cos, sin, pos_base, kv_len, k_slab, v_slab, out, granules, err, finish_ws)
-    assert finish_ws is None or (finish_ws.dtype == torch.float32 and finish_ws.numel() * 4 >= lib().dl_gemv_attn_finish_workspace_bytes(int(n_heads), int(head_dim)))
+                  err=None, grid_cap=0):
+    """One launch = gemv(w, qkv, mode=GEMV_ADDNORM, ...) + attn_decode_rope(qkv, ..., n_splits=1) for ONE row (see include/dynllava.h)."""
+    _dev(w, qkv, h_in, h_out, delta, norm_w, cos, sin, pos_base, kv_len, k_slab, v_slab, out, granules, err)
     N, K = w.shape
     assert w.is_contiguous() and qkv.shape == (1, N) and qkv.is_contiguous() and h_in.is_contiguous() and h_in.shape == (1, K)
     assert delta is None or (delta.is_contiguous() and h_out.is_contiguous())
@@ -462,32 +457,11 @@ def gemv_qkv_attn(w, qkv, h_in, h_out, delta, norm_w, eps, cos, sin, pos_base, k
     _check(
         lib().dl_gemv_qkv_attn(
             _p(w), K, _p(h_in), _p(h_out), _p(delta), _p(norm_w), eps, _p(qkv), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), sb, sh,
-            k_slab.shape[2], _p(out), _p(granules), int(call_tag), _p(err), _p(finish_ws), int(n_heads), int(n_kv_heads), int(head_dim), dtype_code(w.dtype), int(grid_cap), _stream(),
+            k_slab.shape[2], _p(out), _p(granules), int(call_tag), _p(err), int(n_heads), int(n_kv_heads), int(head_dim), dtype_code(w.dtype), int(grid_cap), _stream(),
         ),
         "dl_gemv_qkv_attn",
     )
     return out
-
-
-def gemv_attn_finish_workspace(n_heads, head_dim, device):
-    """Per-head slab state [M, L, O[d], q_rot[d]] handed from gemv_qkv_attn(finish_ws=) to gemv_oproj_attn_finish."""
-    return torch.zeros(int(lib().dl_gemv_attn_finish_workspace_bytes(int(n_heads), int(head_dim))) // 4, dtype=torch.float32, device=device)
-
-
-def gemv_oproj_attn_finish(w_o, finish_ws, qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, attn_out, y, n_heads, n_kv_heads, head_dim, grid_cap=0):
-    """o_proj whose prologue finishes the attention gemv_qkv_attn(finish_ws=) left open (new token folded in, K/V append, attn_out) -- ONE row."""
-    _dev(w_o, finish_ws, qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, attn_out, y)
-    N, K = w_o.shape
-    assert w_o.is_contiguous() and K == n_heads * head_dim and qkv.is_contiguous() and qkv.shape == (1, (n_heads + 2 * n_kv_heads) * head_dim)
-    assert attn_out.shape == (1, K) and attn_out.is_contiguous() and y.shape == (1, N) and y.is_contiguous() and finish_ws.dtype == torch.float32
-    assert pos_base.dtype == torch.int32 and kv_len.dtype == torch.int32
-    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
-    _check(
-        lib().dl_gemv_oproj_attn_finish(_p(w_o), N, _p(finish_ws), _p(qkv), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(1),
-                                        k_slab.shape[2], _p(attn_out), _p(y), int(n_heads), int(n_kv_heads), int(head_dim), dtype_code(w_o.dtype), int(grid_cap), _stream()),
-        "dl_gemv_oproj_attn_finish",
-    )
-    return y
 
 
 def gemv_gu_tp_workspace(d_model, device):

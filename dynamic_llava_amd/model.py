@@ -412,8 +412,6 @@ class _DecodeState:
         self.tp_gran = ops.gemv_gu_tp_workspace(tpm.d_model, device) if (B == 1 and tpm is not None and dtype in (torch.bfloat16, torch.float16) and H <= 5120 and H % 8 == 0 and tpm.d_model % 32 == 0) else None
         # dl_gemv_qkv_attn's granules (batch 1, 16-bit dtypes at the decoder widths the kernel takes)
         self.qa_gran = ops.gemv_qkv_attn_workspace(nH, nKV, d, device) if (B == 1 and dtype in (torch.bfloat16, torch.float16) and d in (64, 128) and H * 2 <= 48 * 1024) else None
-        # round 4: the fused launch's attention stops after the slab keys; the o_proj launch's prologue folds the new token in (dl_gemv_oproj_attn_finish)
-        self.fin_ws = ops.gemv_attn_finish_workspace(nH, d, device) if (self.qa_gran is not None and (nH * d) % 256 == 0 and nH * d <= 8192) else None
         self.blk_err = torch.zeros(1, dtype=torch.int32, device=device)
         # generate(): ring of pinned host words [lens (2 x B) | finished (B)] + events -- the decode loop observes the evicted lengths and the
         # EOS flags with non-blocking copies and reads them one chunk of steps late (the launch queue never drains)
@@ -451,9 +449,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.smallm_max_decode_batch = 24
         self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
         self.fuse_gu_tp = os.environ.get("DL_FUSE_GU_TP", "1") == "1"
-        # the fused q|k|v + attention launch leaves the new token to the o_proj launch that follows (no wait for the projection's last outputs inside
-        # the launch): dl_gemv_qkv_attn(finish_ws) + dl_gemv_oproj_attn_finish; DL_DEFER_ATTN_FINISH=0 keeps the attention complete in the first launch
-        self.defer_attn_finish = os.environ.get("DL_DEFER_ATTN_FINISH", "1") == "1"
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
         # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
@@ -981,10 +976,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             # False, as the kernel tests set it); by default the stand-alone single-split launch of a small batch runs eight waves -- another
             # (equally valid) summation order, so DL_FUSE_QKV_ATTN=0 is an A/B of speed, not of bits (tokens / KV lengths: tested equal)
             fused_attn = self.fuse_qkv_attn and st.B == 1 and ns == 1 and st.qa_gran is not None
-            defer = fused_attn and self.defer_attn_finish and st.fin_ws is not None
             if fused_attn:
                 ops.gemv_qkv_attn(layer.w_qkv, st.qkv, h_cur, h_alt, delta, layer.input_layernorm.weight, eps, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i],
-                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, finish_ws=st.fin_ws if defer else None)
+                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
             else:
@@ -1008,10 +1002,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if not fused_attn:
                 ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
                                      call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
-            if defer:
-                ops.gemv_oproj_attn_finish(layer.self_attn.o_proj.weight, st.fin_ws, st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.o, nH, nKV, d)
-            else:
-                ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
+            ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
             if fused_tp:
                 tp = self.model.output_text_score_predictor
                 ops.gemv_gu_tp(layer.w_gu, st.gu, h_cur, h_alt, st.o, layer.post_attention_layernorm.weight, eps, tp._weights(), tp.d_model, st.tp_ws, st.tp_logits,
@@ -1151,8 +1142,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
         key = (cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
-               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, self.defer_attn_finish,
-               KVSlabCache.eight_wave_single_split)
+               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)

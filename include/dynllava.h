@@ -325,27 +325,12 @@ int dl_linear_splitk(const void* A, int64_t lda, const void* W, float* parts, in
  * beside the ordinary stores to `qkv`.  Bit-identical to dl_gemv(ADDNORM) + dl_attn_decode_rope(n_splits = 1).  B = 1 only.
  * W: [(n_heads + 2 n_kv_heads) head_dim, K].  granules: dl_gemv_qkv_attn_workspace_bytes() bytes, zeroed once per request (tags are made of
  * pos_base[0] and call_tag, 0..255: distinct for every (step, layer) of a request).  err_flag (may be NULL): bit 0 is set, and the output poisoned
- * with NaN, if a consumer gave up waiting.  out: [n_heads * head_dim].
- * Round 4: the new token is folded in AFTER the merge of the slab keys' partials (rounding class of dl_attn_decode_rope, not its bits; the
- * projection row, the residual stream and the appended K/V row stay bit-identical).  finish_ws (may be NULL; dl_gemv_attn_finish_workspace_bytes):
- * when given, the attention workgroups do not wait for the new token's k / v at all -- they publish per head [M, L, O[head_dim], q_rot[head_dim]]
- * (fp32) and leave; `out` and the K/V append are then produced by dl_gemv_oproj_attn_finish, which must be the next launch on the stream. */
+ * with NaN, if a consumer gave up waiting.  out: [n_heads * head_dim]. */
 int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads, int head_dim);
 int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* qkv,
                      const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base, const int32_t* kv_len, void* k_slab,
                      void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
-                     int32_t* err_flag, void* finish_ws, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
-
-/* ---- o_proj of a batch-1 decode layer (DML:1127) whose prologue FINISHES the attention that dl_gemv_qkv_attn(finish_ws) left open: every workgroup
- * rotates the new token's key (DML:283-284), takes its score against the rotated query of every head, applies the softmax update to the slab
- * state [M, L, O], normalises and rounds the attention output to the model dtype (where the reference materialises it, DML:1114-1122), and streams
- * W_o [N, n_heads * head_dim] against it -> y [N].  Workgroup 0 also appends the rotated key and the value at slab slot kv_len[0] (CU:109-268; the
- * caller advances the length, or not: eviction) and stores the attention output row to attn_out [n_heads * head_dim].
- * qkv: the complete projection row of dl_gemv_qkv_attn.  k_slab / v_slab: row 0 of the layer's slabs.  16-bit dtypes, head_dim 64 / 128. */
-int64_t dl_gemv_attn_finish_workspace_bytes(int n_heads, int head_dim);
-int dl_gemv_oproj_attn_finish(const void* W, int N, const void* finish_ws, const void* qkv, const void* cos_tab, const void* sin_tab, int n_pos,
-                              const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_h, int T_cap,
-                              void* attn_out, void* y, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
+                     int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
 
 /* ---- the gate|up projection of layer `sparse_layer` at decode batch 1 (dl_gemv ADDNORM | OUT_SILU_PAIR: DML:1289 + DML:134-139 + DML:328) AND the
  * text predictor (dl_text_predictor_decide: DML:1385-1387, 2388-2391) on the residual stream entering that layer -- the h_in of this launch --
