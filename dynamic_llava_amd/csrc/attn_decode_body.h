@@ -12,6 +12,18 @@
 
 namespace dl {
 
+// tools/qa_timing.hip compiles gemv.hip with -DDL_QA_TIMING: per-workgroup wall-clock stamps of dl_gemv_qkv_attn (100 MHz)
+#ifdef DL_QA_TIMING
+__device__ long long g_qa_stamps[1200][8];
+#define DL_QSTAMP(i)                                                              \
+  do {                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 1200) g_qa_stamps[blockIdx.x][i] = wall_clock64(); \
+  } while (0)
+#else
+#define DL_QSTAMP(i)
+#endif
+
+
 template <typename T, bool UPPER>
 __device__ __forceinline__ void rope16(const float (&own)[Elem<T>::kVec], const float (&par)[Elem<T>::kVec], const float (&cs)[Elem<T>::kVec],
                                        const float (&sn)[Elem<T>::kVec], float (&out)[Elem<T>::kVec]) {
@@ -397,9 +409,61 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
 //   fetch_kv(d, dpar, k_own, k_par, v): called by the threads vtid < D after the slab merge -- returns the raw k[d], k[dpar], v[d] of the new token
 //          (dl_gemv_qkv_attn polls the projection's granules there: three requests per thread in one round trip, no LDS staging, no barrier).
 //   red  : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains TWO __syncthreads().
+// "These values must be in registers NOW": an empty asm that claims to modify them.  Without it the compiler is free to sink a load below a later
+// polling loop (nothing orders a plain load against relaxed atomic loads), which turns a prefetch into a cold round trip on the critical path.
+__device__ __forceinline__ void pin_reg(uint4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+__device__ __forceinline__ void pin_reg(float& x) { asm volatile("" : "+v"(x)); }
+template <typename T, int D, int NW, int U>
+__device__ __forceinline__ void attn_split_pin_prefetched(AttnSplitState<T, D, NW, U>& s) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pin_reg(s.kraw[u]);
+    pin_reg(s.vraw[u]);
+  }
+  if constexpr (U <= 4) {
+    if (s.pre2) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        pin_reg(s.kraw2[u]);
+        pin_reg(s.vraw2[u]);
+      }
+    }
+  }
+}
+
+// The RoPE table entries of the new token's position, requested BEFORE the caller waits for q (a cold table row is an HBM + TLB round trip of 2-3 us:
+// inside attn_split_finish_newlast it sat on the launch's critical path, right after q's arrival -- tools/qa_timing.hip)
+template <typename T>
+struct AttnRopeRow {
+  float cs[Elem<T>::kVec], sn[Elem<T>::kVec];  // this lane's slice (columns c % (D/2) ...)
+  float cs1, sn1;                              // the finishing thread's own element
+};
+template <typename T, int D, int NW, int U>
+__device__ __forceinline__ void attn_newlast_preload(const AttnSplitState<T, D, NW, U>& s, int vtid, const void* cos_, const void* sin_, int n_pos, int pos,
+                                                     AttnRopeRow<T>& r) {
+  using S = typename Elem<T>::storage;
+  constexpr int HALF = D / 2;
+  int p = pos;
+  p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+  const S* cos_row = reinterpret_cast<const S*>(cos_) + (int64_t)p * D;  // table = cat(freqs, freqs)
+  const S* sin_row = reinterpret_cast<const S*>(sin_) + (int64_t)p * D;
+  load16<T>(cos_row + (s.c % HALF), r.cs);
+  load16<T>(sin_row + (s.c % HALF), r.sn);
+  const int d = vtid < D ? vtid : 0;
+  r.cs1 = Elem<T>::to_f(cos_row[d % HALF]);
+  r.sn1 = Elem<T>::to_f(sin_row[d % HALF]);
+#pragma unroll
+  for (int i = 0; i < Elem<T>::kVec; ++i) {
+    pin_reg(r.cs[i]);
+    pin_reg(r.sn[i]);
+  }
+  pin_reg(r.cs1);
+  pin_reg(r.sn1);
+}
+
 template <typename T, int D, int NW, int U, typename FetchKV>
-__device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const void* cos_,
-                                                          const void* sin_, int n_pos, int pos, float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
+__device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const AttnRopeRow<T>& rope,
+                                                          float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
                                                           float* sm_o, float* red, float& out, FetchKV fetch_kv) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
@@ -408,26 +472,23 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
   static_assert(D % 64 == 0 && D / 64 <= NW, "the D finishing threads are whole waves of this workgroup");
   const int c = s.c;
   const int cpar = c < HALF ? c + HALF : c - HALF;
-  int p = pos;
-  p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
-  const S* cos_row = reinterpret_cast<const S*>(cos_) + (int64_t)p * D;  // table = cat(freqs, freqs)
-  const S* sin_row = reinterpret_cast<const S*>(sin_) + (int64_t)p * D;
   float qv[V];
   {
-    float cs[V], sn[V], own[V], par[V];
-    load16<T>(cos_row + (c % HALF), cs);
-    load16<T>(sin_row + (c % HALF), sn);
+    float own[V], par[V];
     load16<T>(rows + c, own);
     load16<T>(rows + cpar, par);
-    if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
+    if (c < HALF) rope16<T, false>(own, par, rope.cs, rope.sn, qv); else rope16<T, true>(own, par, rope.cs, rope.sn, qv);
   }
+  DL_QSTAMP(4);  // q rotated
   float m, l, o[V];
   attn_split_keys<T, D, NW, U>(s, qv, scale, m, l, o);
+  DL_QSTAMP(5);  // slab keys done (this wave)
   float M, L, O;
   attn_split_lds_merge<T, D, NW, U>(s, vtid, m, l, o, sm_m, sm_l, sm_o, M, L, O);
+  DL_QSTAMP(2);  // slab keys merged
   // this thread's own element of the rotated query (needs q only: done before the wait)
   const int d = vtid < D ? vtid : 0, dpar = d < HALF ? d + HALF : d - HALF;
-  const float cs1 = Elem<T>::to_f(cos_row[d % HALF]), sn1 = Elem<T>::to_f(sin_row[d % HALF]);
+  const float cs1 = rope.cs1, sn1 = rope.sn1;
   const float q_own = Elem<T>::to_f(rows[d]), q_par = Elem<T>::to_f(rows[dpar]);
   const float q_rot = Elem<T>::round(Elem<T>::round(q_own * cs1) + Elem<T>::round((d < HALF ? -q_par : q_par) * sn1));  // DML:283-284, as rope16
   float part = 0.f, k_rot = 0.f, vv = 0.f;

@@ -244,6 +244,9 @@ __device__ __forceinline__ void gemv_body(const void* __restrict__ W_, int N, in
       }
     }
     if (grp == bid) DL_GSTAMP(2);  // first neuron group streamed
+#ifdef DL_QA_TIMING
+    if (grp == bid && threadIdx.x == 0 && blockIdx.x < 1200) g_qa_stamps[blockIdx.x][2] = wall_clock64();
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -398,6 +401,15 @@ static int gemv_launch(int mode, const void* W, int N, int K, const void* x, int
 // are the last blocks); q arrives 12.4 us; slab part done 18.4 us; the stream's last outputs (v) arrive 19.0 us; attention done 21.9 us.
 // No producer ever waits, so the launch cannot deadlock; the consumers' wait is bounded and poisons the output (NaN + error word) on give-up.
 // Both halves are the shared bodies (gemv_body, attn_decode_body.h): the results are bit-identical to dl_gemv + dl_attn_decode_rope.
+// neurons per wave per pass x 16-byte chunks in flight per neuron of the fused launch's projection.  ONE neuron per wave: a pass of the grid then covers
+// ~4 x 992 neurons, i.e. the q rows (the first third of the projection) are complete after the FIRST pass -- the attention workgroups can start on the
+// slab keys at about a third of the stream instead of two thirds (tools/qa_timing.hip: with 2 x 4 the last head received its q at 16.3 us of an
+// 18.2 us stream, and the slab keys' 5.4 us then ran past the stream's end)
+#ifndef DL_QA_R
+#define DL_QA_R 1
+#endif
+constexpr int kQaR = DL_QA_R, kQaU = 8 / DL_QA_R;
+
 struct QkvAttnArgs {
   // projection
   const void* W; const void* h; void* h_out; const void* delta; const void* nw; void* y;
@@ -416,8 +428,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
   // the attention workgroups are the LAST blocks of the grid (and the grid stays within what the device holds at once): as first blocks they
   // displaced 32 streaming workgroups into a late second round (26.9 vs 25.4 us per launch)
   const int n_gemv = (int)gridDim.x - a.n_heads;
+  DL_QSTAMP(0);
   if ((int)blockIdx.x < n_gemv) {
-    gemv_body<T, 1, 1, false, 2, 4>(a.W, a.N, a.K, nullptr, 0, a.h, a.h_out, a.delta, a.nw, a.eps, a.y, a.N, (int)blockIdx.x, n_gemv, a.gran, tag);
+    gemv_body<T, 1, 1, false, kQaR, kQaU>(a.W, a.N, a.K, nullptr, 0, a.h, a.h_out, a.delta, a.nw, a.eps, a.y, a.N, (int)blockIdx.x, n_gemv, a.gran, tag);
+    DL_QSTAMP(1);
     return;
   }
   constexpr int NW = 4, U = 4;
@@ -432,6 +446,9 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
   St st;
   attn_split_issue<T, D, NW, true, U>(st, tid, a.k_slab, a.v_slab, a.stride_b, a.stride_h, T_old, 1, 0, kvh, 0, 1, a.T_cap, 256);
   attn_split_prefetch2<T, D, NW, U>(st);  // two trips in flight while the projection produces q
+  AttnRopeRow<T> rope;  // the RoPE table row of the new token's position: requested now, not after q has arrived
+  attn_newlast_preload<T, D, NW, U>(st, tid, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], rope);
+  attn_split_pin_prefetched<T, D, NW, U>(st);  // the two trips of K/V really are in registers before the wait for q begins (this workgroup is idle until then anyway)
   // q first (the projection's first third): the slab keys need nothing else; k / v of the new token (its last third) only at the very end
   bool bad = false;
   auto value_of = [](u64_t v) -> S {
@@ -464,6 +481,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
       rows[i] = value_of(v);
     }
     __syncthreads();
+    DL_QSTAMP(1);  // q has arrived
   }
   // the slab keys' partials are merged while the projection still streams; the new token is folded in by the D finishing threads, each of which
   // receives its three values (k[d], k[d +- D/2], v[d]: the projection's last outputs) straight from the granules: attn_split_finish_newlast
@@ -471,7 +489,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
   float o_head;
   const u64_t* gk = a.gran + (int64_t)(a.n_heads + kvh) * D;
   const u64_t* gv = a.gran + (int64_t)(a.n_heads + a.n_kv_heads + kvh) * D;
-  attn_split_finish_newlast<T, D, NW, U>(st, tid, rows, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], 1.0f / sqrtf((float)D), h % n_rep == 0, a.T_cap, sm_m, sm_l,
+  attn_split_finish_newlast<T, D, NW, U>(st, tid, rows, rope, 1.0f / sqrtf((float)D), h % n_rep == 0, a.T_cap, sm_m, sm_l,
                                          sm_o, red, o_head, [&](int d, int dpar, S& k_own, S& k_par, S& v_new) {
                                            u64_t g0 = 0, g1 = 0, g2 = 0;
                                            for (int spins = 0;; ++spins) {  // the three requests travel together; repeated until all carry this step's tag
@@ -490,6 +508,7 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
                                            v_new = value_of(g2);
                                          });
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  DL_QSTAMP(3);
   if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o_head);
   if (any_bad && tid == 0 && a.err) atomicOr(a.err, 1);
 }
@@ -648,7 +667,7 @@ extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_
     a.stride_b = slab_stride_b; a.stride_h = slab_stride_h; a.n_pos = n_pos; a.T_cap = T_cap; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads;
     a.call_tag = call_tag; a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag;
 
-    const int groups = (N + 7) / 8;
+    const int groups = (N + 4 * kQaR - 1) / (4 * kQaR);
     if (grid_cap > 2 * n_heads) grid_cap -= n_heads;  // projection + attention workgroups together stay within what is resident at once
     const int grid = (groups < grid_cap ? groups : grid_cap) + n_heads;
     const size_t smem = (size_t)K * Elem<T>::kBytes;
