@@ -449,6 +449,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.smallm_max_decode_batch = 24
         self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
         self.fuse_gu_tp = os.environ.get("DL_FUSE_GU_TP", "1") == "1"
+        self.gu_grid_cap = int(os.environ.get("DL_GU_GRID", "0"))  # workgroups of the batch-1 gate|up launch (0: the kernel's default, 1024)
+        self.qkv_attn_grid_cap = int(os.environ.get("DL_QA_GRID", "0"))  # workgroups of the fused q|k|v + attention launch (0: the kernel's default)
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
         # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
@@ -978,7 +980,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             fused_attn = self.fuse_qkv_attn and st.B == 1 and ns == 1 and st.qa_gran is not None
             if fused_attn:
                 ops.gemv_qkv_attn(layer.w_qkv, st.qkv, h_cur, h_alt, delta, layer.input_layernorm.weight, eps, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i],
-                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
+                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, grid_cap=self.qkv_attn_grid_cap)
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
             else:
@@ -1008,7 +1010,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 ops.gemv_gu_tp(layer.w_gu, st.gu, h_cur, h_alt, st.o, layer.post_attention_layernorm.weight, eps, tp._weights(), tp.d_model, st.tp_ws, st.tp_logits,
                                st.decision, cache.len_full, st.tp_gran, i & 0xff, err=st.blk_err)
             else:
-                ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps)
+                ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps, grid_cap=self.gu_grid_cap)
             h_cur, h_alt = h_alt, h_cur
             ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
             delta = st.dn
