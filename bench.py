@@ -239,7 +239,7 @@ def fused_launch_roofline(model):
     def step():
         for i, layer in layers:
             ops.gemv_qkv_attn(layer.w_qkv, st.qkv, st.h, st.h2, delta, layer.input_layernorm.weight, cfg.rms_norm_eps, cos, sin, cache.len_full, cache.lens[1], cache.k[i], cache.v[i],
-                              st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err)
+                              st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, n_splits=cache.fused_attn_splits(i, model.fused_attn_max_splits))
 
     s_ = torch.cuda.Stream()
     s_.wait_stream(torch.cuda.current_stream())

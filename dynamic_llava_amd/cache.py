@@ -88,6 +88,7 @@ class KVSlabCache:
         # q|k|v + attention launch, where the slab part of the attention hides under the weight stream (tools/bench_qkv_attn.py)
         self._sch = None  # decode schedule state (sched_*)
         self.single_split_max_keys = _SINGLE_SPLIT_MAX_KEYS
+        self.fused_single_keys = 256  # see fused_attn_splits
         self.min_keys_per_split = 64  # a split workgroup is given at least this many keys (tests lower it to force split launches on tiny rows)
 
     def n_splits(self, layer_idx: int, rows_times_heads: int, max_splits: int = 32) -> int:
@@ -147,6 +148,15 @@ class KVSlabCache:
     def sched_drop(self):
         self._sch = None
         self.set_bounds(None, None)
+
+    def fused_attn_splits(self, layer_idx: int, max_splits: int = 4) -> int:
+        """Attention workgroups per head INSIDE the fused q|k|v + attention launch (dl_gemv_qkv_attn).  One while the row is short enough for its later
+        K/V trips to hide under the weight stream (`fused_single_keys`, set by the model); beyond that one per 128 keys of the bound -- a workgroup
+        holds two 64-key trips in registers while it waits for q, so the whole row is on chip before q arrives (tools/bench_qkv_attn.py)."""
+        bound = self.key_bound(self.group(layer_idx))
+        if bound <= self.fused_single_keys:
+            return 1
+        return max(1, min(max_splits, -(-bound // 128)))
 
     def set_bounds(self, full_bound, sparse_bound):
         self.full_bound = None if full_bound is None else int(full_bound)

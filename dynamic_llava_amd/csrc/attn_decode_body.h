@@ -461,10 +461,16 @@ __device__ __forceinline__ void attn_newlast_preload(const AttnSplitState<T, D, 
   pin_reg(r.sn1);
 }
 
-template <typename T, int D, int NW, int U, typename FetchKV>
+//   after_slab(M, L, O) -> bool: called by every thread once the slab keys of THIS workgroup are merged ((M, L, O) valid for vtid < D).  A workgroup
+//          that holds only a PART of the head's keys (several workgroups per head) publishes its partial there and returns false (the function
+//          returns at once); the head's primary workgroup folds the other parts into (M, L, O) there and returns true.
+struct AttnSlabWhole {
+  __device__ __forceinline__ bool operator()(float&, float&, float&) const { return true; }
+};
+template <typename T, int D, int NW, int U, typename FetchKV, typename AfterSlab = AttnSlabWhole>
 __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const AttnRopeRow<T>& rope,
                                                           float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
-                                                          float* sm_o, float* red, float& out, FetchKV fetch_kv) {
+                                                          float* sm_o, float* red, float& out, FetchKV fetch_kv, AfterSlab after_slab = AfterSlab()) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
   constexpr int V = St::V;
@@ -486,6 +492,8 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
   float M, L, O;
   attn_split_lds_merge<T, D, NW, U>(s, vtid, m, l, o, sm_m, sm_l, sm_o, M, L, O);
   DL_QSTAMP(2);  // slab keys merged
+  out = 0.f;
+  if (!after_slab(M, L, O)) return;
   // this thread's own element of the rotated query (needs q only: done before the wait)
   const int d = vtid < D ? vtid : 0, dpar = d < HALF ? d + HALF : d - HALF;
   const float cs1 = rope.cs1, sn1 = rope.sn1;

@@ -419,15 +419,24 @@ struct QkvAttnArgs {
   int64_t stride_b, stride_h;
   int n_pos, T_cap, n_heads, n_kv_heads, call_tag;
   u64_t* gran; int32_t* err;
+  int n_splits, chunk_keys;  // attention workgroups per head, keys per workgroup (the last one takes the rest)
 };
 
-template <typename T, int D>
-__global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs a) {
+constexpr int kQaMaxSplits = 4;
+
+// four workgroups per CU or the grid (projection + attention workgroups) is not resident at once: hold the kernel to 128 VGPRs
+// MULTI: several attention workgroups per head (run-time n_splits).  Two instantiations because the general form needs ~20 VGPRs more than the
+// one-workgroup-per-head form (126), and the grid is only resident at once with four workgroups per CU = 128 VGPRs: the general form is held to
+// that by the attribute (a few dwords of spill in the attention path, measured faster than three workgroups per CU by far).
+template <typename T, int D, bool MULTI>
+__global__ __launch_bounds__(kGemvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemv_qkv_attn_kernel(QkvAttnArgs a_) {
+  QkvAttnArgs a = a_;
+  if constexpr (!MULTI) a.n_splits = 1;
   using S = typename Elem<T>::storage;
   const uint32_t tag = ((((uint32_t)a.pos_base[0] & 0x7fffffu) << 8) | ((uint32_t)a.call_tag & 0xffu)) + 1u;
   // the attention workgroups are the LAST blocks of the grid (and the grid stays within what the device holds at once): as first blocks they
   // displaced 32 streaming workgroups into a late second round (26.9 vs 25.4 us per launch)
-  const int n_gemv = (int)gridDim.x - a.n_heads;
+  const int n_gemv = (int)gridDim.x - a.n_heads * a.n_splits;
   DL_QSTAMP(0);
   if ((int)blockIdx.x < n_gemv) {
     gemv_body<T, 1, 1, false, kQaR, kQaU>(a.W, a.N, a.K, nullptr, 0, a.h, a.h_out, a.delta, a.nw, a.eps, a.y, a.N, (int)blockIdx.x, n_gemv, a.gran, tag);
@@ -440,11 +449,16 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
   __shared__ float sm_m[NG], sm_l[NG];
   __shared__ float sm_o[NG * D];
   __shared__ __attribute__((aligned(16))) S rows[D];
-  const int h = (int)blockIdx.x - n_gemv, tid = threadIdx.x;
+  // round 4: `n_splits` workgroups per head, each with `chunk_keys` (= two register trips) of the head's slab keys -- the whole key range is then in
+  // registers BEFORE q arrives, so what follows q is arithmetic + one exchange of partials instead of a chain of cold K/V round trips
+  const int aw = (int)blockIdx.x - n_gemv, tid = threadIdx.x;
+  const int h = aw / a.n_splits, split = aw % a.n_splits;
   const int n_rep = a.n_heads / a.n_kv_heads, kvh = h / n_rep;
   const int T_old = a.kv_len[0];
   St st;
-  attn_split_issue<T, D, NW, true, U>(st, tid, a.k_slab, a.v_slab, a.stride_b, a.stride_h, T_old, 1, 0, kvh, 0, 1, a.T_cap, 256);
+  // (constant chunk sizes: with a run-time chunk the compiler keeps the non-speculative request path alive too, ~20 VGPRs the kernel does not have)
+  if (a.n_splits == 1) attn_split_issue<T, D, NW, true, U>(st, tid, a.k_slab, a.v_slab, a.stride_b, a.stride_h, T_old, 1, 0, kvh, 0, 1, a.T_cap, 256);
+  else attn_split_issue<T, D, NW, true, U>(st, tid, a.k_slab, a.v_slab, a.stride_b, a.stride_h, T_old, 1, 0, kvh, split, a.n_splits, a.T_cap, 128);
   attn_split_prefetch2<T, D, NW, U>(st);  // two trips in flight while the projection produces q
   AttnRopeRow<T> rope;  // the RoPE table row of the new token's position: requested now, not after q has arrived
   attn_newlast_preload<T, D, NW, U>(st, tid, a.cos_tab, a.sin_tab, a.n_pos, a.pos_base[0], rope);
@@ -506,7 +520,54 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_qkv_attn_kernel(QkvAttnArgs
                                            k_own = value_of(g0);
                                            k_par = value_of(g1);
                                            v_new = value_of(g2);
+                                         },
+                                         [&](float& M, float& L, float& O) -> bool {
+                                           if (a.n_splits == 1) return true;
+                                           // partials of a head: granules [head][split - 1][M, L, O[D]] behind the projection's N granules
+                                           constexpr int PG = D + 2;
+                                           u64_t* pg = a.gran + a.N + ((int64_t)h * (kQaMaxSplits - 1)) * PG;
+                                           if (split != 0) {
+                                             if (tid < D) {
+                                               u64_t* mine = pg + (int64_t)(split - 1) * PG;
+                                               gr_store(mine + 2 + tid, tag, __float_as_uint(O));
+                                               if (tid == 0) {
+                                                 gr_store(mine, tag, __float_as_uint(M));
+                                                 gr_store(mine + 1, tag, __float_as_uint(L));
+                                               }
+                                             }
+                                             return false;
+                                           }
+                                           if (tid < D) {  // the primary: fold the other parts in, one after the other in split order (few live registers)
+                                             for (int j = 0; j < a.n_splits - 1; ++j) {
+                                               const u64_t* src = pg + (int64_t)j * PG;
+                                               u64_t gm = 0, gl = 0, go = 0;
+                                               for (int spins = 0;; ++spins) {  // the three requests travel together; repeated until all carry this step's tag
+                                                 gm = gr_load(src);
+                                                 gl = gr_load(src + 1);
+                                                 go = gr_load(src + 2 + tid);
+                                                 if ((uint32_t)(gm >> 32) == tag && (uint32_t)(gl >> 32) == tag && (uint32_t)(go >> 32) == tag) break;
+                                                 if (spins > (1 << 20)) {
+                                                   bad = true;
+                                                   break;
+                                                 }
+                                                 __builtin_amdgcn_s_sleep(1);
+                                               }
+                                               const float Mj = __uint_as_float((uint32_t)gm), Lj = __uint_as_float((uint32_t)gl), Oj = __uint_as_float((uint32_t)go);
+                                               const float Mt = fmaxf(M, Mj);
+                                               if (Mt > -INFINITY) {
+                                                 const float w0 = __expf(M - Mt), w1 = __expf(Mj - Mt);  // an empty part: exp(-inf) = 0
+                                                 L = L * w0 + Lj * w1;
+                                                 O = O * w0 + Oj * w1;
+                                                 M = Mt;
+                                               }
+                                             }
+                                           }
+                                           return true;
                                          });
+  if (split != 0) {  // (uniform per workgroup: the secondaries have published their part)
+    if (__syncthreads_or(bad ? 1 : 0) && tid == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   DL_QSTAMP(3);
   if (tid < D) store1<T>(a.out, (int64_t)h * D + tid, any_bad ? __uint_as_float(0x7fc00000u) : o_head);
@@ -643,18 +704,20 @@ extern "C" int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void
 }
 
 extern "C" int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads, int head_dim) {
-  return (int64_t)(n_heads + 2 * n_kv_heads) * head_dim * (int64_t)sizeof(u64_t);
+  // the projection's N granules + the partials of the secondary attention workgroups: [head][kQaMaxSplits - 1][M, L, O[head_dim]]
+  return ((int64_t)(n_heads + 2 * n_kv_heads) * head_dim + (int64_t)n_heads * (kQaMaxSplits - 1) * (head_dim + 2)) * (int64_t)sizeof(u64_t);
 }
 
 extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* qkv,
                                 const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base, const int32_t* kv_len, void* k_slab,
                                 void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
-                                int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream) {
+                                int32_t* err_flag, int n_splits, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream) {
   DL_REQUIRE(W && h_in && norm_w && qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && out && granules, "dl_gemv_qkv_attn: NULL pointer");
   DL_REQUIRE(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0 && (head_dim == 128 || head_dim == 64) && K > 0 && n_pos > 0 && T_cap > 0,
              "dl_gemv_qkv_attn: bad shape");
   DL_REQUIRE(!delta || (h_out && h_out != h_in), "dl_gemv_qkv_attn: h_out must be a distinct buffer when delta is given");
   DL_REQUIRE(call_tag >= 0 && grid_cap >= 0, "dl_gemv_qkv_attn: call_tag / grid_cap must be >= 0");
+  DL_REQUIRE(n_splits >= 1 && n_splits <= kQaMaxSplits, "dl_gemv_qkv_attn: n_splits=%d must be in [1, %d]", n_splits, kQaMaxSplits);
   if (grid_cap == 0) grid_cap = kGemvGridCap;
   const int N = (n_heads + 2 * n_kv_heads) * head_dim;
   hipStream_t st = as_stream(stream);
@@ -667,12 +730,22 @@ extern "C" int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_
     a.stride_b = slab_stride_b; a.stride_h = slab_stride_h; a.n_pos = n_pos; a.T_cap = T_cap; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads;
     a.call_tag = call_tag; a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag;
 
+    // one workgroup per head: the whole row (speculative first request of 256 keys, as the stand-alone single-split launch); several: 128 keys
+    // each = the two trips a workgroup holds in registers while it waits for q, the last one takes what is left
+    a.n_splits = n_splits;
+    a.chunk_keys = n_splits == 1 ? 256 : 128;
+    const int n_attn = n_heads * n_splits;
     const int groups = (N + 4 * kQaR - 1) / (4 * kQaR);
-    if (grid_cap > 2 * n_heads) grid_cap -= n_heads;  // projection + attention workgroups together stay within what is resident at once
-    const int grid = (groups < grid_cap ? groups : grid_cap) + n_heads;
+    if (grid_cap > 2 * n_attn) grid_cap -= n_attn;  // projection + attention workgroups together stay within what is resident at once
+    const int grid = (groups < grid_cap ? groups : grid_cap) + n_attn;
     const size_t smem = (size_t)K * Elem<T>::kBytes;
-    if (head_dim == 128) hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 128>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
-    else hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 64>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+    if (n_splits == 1) {
+      if (head_dim == 128) hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 128, false>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+      else hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 64, false>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+    } else {
+      if (head_dim == 128) hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 128, true>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+      else hipLaunchKernelGGL((gemv_qkv_attn_kernel<T, 64, true>), dim3((unsigned)grid), dim3(kGemvThreads), smem, st, a);
+    }
   });
   if (rc != DL_OK) return rc;
   DL_CHECK_LAUNCH("dl_gemv_qkv_attn");

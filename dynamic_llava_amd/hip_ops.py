@@ -87,7 +87,7 @@ SIGNATURES = {
     "dl_gemv_gu_tp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, POINTER(TpWeights), c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "dl_gemv_qkv_attn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                 c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_attn_policy_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "dl_attn_policy_fwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_void_p]),
@@ -444,20 +444,21 @@ def gemv_qkv_attn_workspace(n_heads, n_kv_heads, head_dim, device):
 
 
 def gemv_qkv_attn(w, qkv, h_in, h_out, delta, norm_w, eps, cos, sin, pos_base, kv_len, k_slab, v_slab, out, granules, call_tag, n_heads, n_kv_heads, head_dim,
-                  err=None, grid_cap=0):
-    """One launch = gemv(w, qkv, mode=GEMV_ADDNORM, ...) + attn_decode_rope(qkv, ..., n_splits=1) for ONE row (see include/dynllava.h)."""
+                  err=None, grid_cap=0, n_splits=1):
+    """One launch = gemv(w, qkv, mode=GEMV_ADDNORM, ...) + attn_decode_rope(qkv, ..., n_splits=1) for ONE row (see include/dynllava.h).
+    n_splits: attention workgroups per head (1..4; > 1: 128 slab keys each, partials merged by the head's first workgroup)."""
     _dev(w, qkv, h_in, h_out, delta, norm_w, cos, sin, pos_base, kv_len, k_slab, v_slab, out, granules, err)
     N, K = w.shape
     assert w.is_contiguous() and qkv.shape == (1, N) and qkv.is_contiguous() and h_in.is_contiguous() and h_in.shape == (1, K)
     assert delta is None or (delta.is_contiguous() and h_out.is_contiguous())
     assert out.shape == (1, n_heads * head_dim) and out.is_contiguous() and N == (n_heads + 2 * n_kv_heads) * head_dim
-    assert pos_base.dtype == torch.int32 and kv_len.dtype == torch.int32 and granules.numel() * granules.element_size() >= N * 8
+    assert pos_base.dtype == torch.int32 and kv_len.dtype == torch.int32 and granules.numel() * granules.element_size() >= lib().dl_gemv_qkv_attn_workspace_bytes(int(n_heads), int(n_kv_heads), int(head_dim))
     assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
     sb, sh = k_slab.stride(0), k_slab.stride(1)
     _check(
         lib().dl_gemv_qkv_attn(
             _p(w), K, _p(h_in), _p(h_out), _p(delta), _p(norm_w), eps, _p(qkv), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), sb, sh,
-            k_slab.shape[2], _p(out), _p(granules), int(call_tag), _p(err), int(n_heads), int(n_kv_heads), int(head_dim), dtype_code(w.dtype), int(grid_cap), _stream(),
+            k_slab.shape[2], _p(out), _p(granules), int(call_tag), _p(err), int(n_splits), int(n_heads), int(n_kv_heads), int(head_dim), dtype_code(w.dtype), int(grid_cap), _stream(),
         ),
         "dl_gemv_qkv_attn",
     )

@@ -449,6 +449,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.smallm_max_decode_batch = 24
         self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
         self.fuse_gu_tp = os.environ.get("DL_FUSE_GU_TP", "1") == "1"
+        # attention workgroups per head inside the fused launch: up to this many, one per 128 keys of the scheduled bound (DL_QA_SPLITS=1: always one)
+        self.fused_attn_max_splits = int(os.environ.get("DL_QA_SPLITS", "4"))
         self.gu_grid_cap = int(os.environ.get("DL_GU_GRID", "0"))  # workgroups of the batch-1 gate|up launch (0: the kernel's default, 1024)
         self.qkv_attn_grid_cap = int(os.environ.get("DL_QA_GRID", "0"))  # workgroups of the fused q|k|v + attention launch (0: the kernel's default)
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
@@ -980,7 +982,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             fused_attn = self.fuse_qkv_attn and st.B == 1 and ns == 1 and st.qa_gran is not None
             if fused_attn:
                 ops.gemv_qkv_attn(layer.w_qkv, st.qkv, h_cur, h_alt, delta, layer.input_layernorm.weight, eps, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i],
-                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, grid_cap=self.qkv_attn_grid_cap)
+                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, grid_cap=self.qkv_attn_grid_cap,
+                                  n_splits=cache.fused_attn_splits(i, self.fused_attn_max_splits))
                 if delta is not None:
                     h_cur, h_alt = h_alt, h_cur
             else:
@@ -1081,39 +1084,23 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         c.set_bounds(None, None)
         return c
 
-    def _single_split_max_keys(self, st) -> int:
-        """Largest row (keys) that runs as ONE attention workgroup per head.  Stand-alone launch: 256 (cache.py).  Inside dl_gemv_qkv_attn the
-        slab part of the attention runs while the q|k|v weights still stream, so the break-even against `dl_gemv` + a split launch moves out with
-        the stream's length (tools/bench_qkv_attn.py, 1x MI355X: 7B -- 100.7 MB, 17.6 us -- one launch 26.9 vs 27.5 us at 350 keys, 27.6 vs 27.3 at
-        400; 13B -- 157 MB, 28.1 us -- 36.2 vs 37.7 at 512, 37.7 vs 38.9 at 640): 384 keys per 100 MB of q|k|v weights, in steps of 64."""
+    def _single_split_max_keys(self, st):
+        """-> (largest row, in keys, that the fused q|k|v + attention launch takes; largest row it takes with ONE attention workgroup per head).
+        Stand-alone launches: 256 keys as one workgroup per (row, head) (cache.py).  Inside dl_gemv_qkv_attn the slab part of the attention runs while
+        the q|k|v weights still stream, so the break-even against `dl_gemv` + a split launch moves out with the stream's length, and further with
+        several attention workgroups per head (round 4).  tools/bench_qkv_attn.py on 1x MI355X, one launch with 1 / 4 workgroups per head vs the two
+        launches: 7B (100.7 MB of q|k|v, 17.8 us) 22.8 / 23.4 vs 26.8 at 256 keys, 25.2 / 23.6 vs 28.0 at 448, 27.8 / 25.7 vs 28.5 at 640, 29.1 / 28.2 vs
+        28.3 at 768; 13B (157 MB, 28 us) 32.2 / 33.6 vs 37.5 at 384, 36.0 / 34.1 vs 38.1 at 640, 36.5 / 36.5 vs 39.0 at 768, 39.7 / 42.1 vs 39.9 at 1024."""
         from .cache import _SINGLE_SPLIT_MAX_KEYS
         if self.single_split_keys_override is not None:  # tests: force the schedule to change inside a short generation
-            return int(self.single_split_keys_override)
+            return int(self.single_split_keys_override), int(self.single_split_keys_override)
         if not (self.fuse_qkv_attn and st.B == 1 and st.use_gemv and st.qa_gran is not None):
-            return _SINGLE_SPLIT_MAX_KEYS
+            return _SINGLE_SPLIT_MAX_KEYS, _SINGLE_SPLIT_MAX_KEYS
         w = self.model.layers[0].w_qkv
-        keys = int(384 * (w.numel() * w.element_size()) / 100.7e6) // 64 * 64
-        return max(_SINGLE_SPLIT_MAX_KEYS, min(768, keys))
-
-    def _width_bucket(self, W: int, n_feat: int) -> int:
-        """Prompt-width bucket of the device-layout prefill: the smallest width >= W whose COMPACTED row count (W - 1 + kept image tokens: the
-        M of 30 of the 32 layers' GEMMs) is a multiple of `prefill_width_bucket` -- 16 by default, one MFMA tile of rows, so a bucket never
-        adds a row tile to those GEMMs that the true width would not have needed.  0 / 1 disables bucketing."""
-        g = int(self.prefill_width_bucket or 0)
-        if g <= 1:
-            return W
-        sc = self.config.sparse_config
-        kept = int(n_feat * sc["vision_keep_rate"]) if (sc["use_vision_predictor"] and sc["sparse_layer"] < self.config.num_hidden_layers) else n_feat
-        rows = W - 1 + kept
-        return W + (-rows) % g
-
-    def _evict_prefill_entries(self):
-        """Bound the prefill-shape cache: at most `max_prefill_graphs` captured graphs and as many seen-once entries (oldest first)."""
-        cap = self.max_prefill_graphs
-        graphs = [k for k, e in self._prefill_graphs.items() if e["graph"] is not None]
-        seen = [k for k, e in self._prefill_graphs.items() if e["graph"] is None]
-        for k in graphs[: max(0, len(graphs) - cap + 1)] + seen[: max(0, len(seen) - cap + 1)]:
-            self._prefill_graphs.pop(k)
+        big = (w.numel() * w.element_size()) >= 130e6  # 13B-class stream
+        if self.fused_attn_max_splits <= 1:
+            return (576 if big else 384), (576 if big else 384)
+        return (768 if big else 704), (576 if big else 256)
 
     def _get_dstate(self, B, out_cap):
         st = self._dstate
@@ -1143,7 +1130,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cfg = self.config
         nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
         splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
-        key = (cache.slab.data_ptr(), cache.t_cap, splits, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
+        fused_ns = (cache.fused_attn_splits(0, self.fused_attn_max_splits), cache.fused_attn_splits(cfg.num_hidden_layers - 1, self.fused_attn_max_splits)) if (st.B == 1 and st.qa_gran is not None) else (1, 1)
+        key = (cache.slab.data_ptr(), cache.t_cap, splits, fused_ns, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
                repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split)
         if not self.use_hip_graph:
             for _ in range(n_steps):
@@ -1195,7 +1183,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 return self._forward_chunk(input_ids, attention_mask, cache)
             B = input_ids.shape[0]
             st = self._get_dstate(B, 0)
-            cache.single_split_max_keys, cache.min_keys_per_split = self._single_split_max_keys(st), self.min_keys_per_split
+            (cache.single_split_max_keys, cache.fused_single_keys), cache.min_keys_per_split = self._single_split_max_keys(st), self.min_keys_per_split
             cache.ensure_capacity(2)
             self._rope_tables(max(cache.full_len_host) + 2)
             st.cur_ids.copy_(input_ids[:, 0])
@@ -1544,7 +1532,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         cache = self._pooled_cache(B, max(lens) + max_new + 1)
         self._rope_tables(max(lens) + max_new + 1)
         st = self._get_dstate(B, max_new)
-        cache.single_split_max_keys, cache.min_keys_per_split = self._single_split_max_keys(st), self.min_keys_per_split
+        (cache.single_split_max_keys, cache.fused_single_keys), cache.min_keys_per_split = self._single_split_max_keys(st), self.min_keys_per_split
         st.step.zero_(); st.finished.zero_(); st.decision.fill_(1)
         # the in-kernel split merge of the decode attention validates its granules by tag = (position of the new token, layer): within one
         # request positions only grow, so a slot left by an earlier step never matches -- but a slot left by an EARLIER REQUEST at the same

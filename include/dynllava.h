@@ -325,12 +325,16 @@ int dl_linear_splitk(const void* A, int64_t lda, const void* W, float* parts, in
  * beside the ordinary stores to `qkv`.  Bit-identical to dl_gemv(ADDNORM) + dl_attn_decode_rope(n_splits = 1).  B = 1 only.
  * W: [(n_heads + 2 n_kv_heads) head_dim, K].  granules: dl_gemv_qkv_attn_workspace_bytes() bytes, zeroed once per request (tags are made of
  * pos_base[0] and call_tag, 0..255: distinct for every (step, layer) of a request).  err_flag (may be NULL): bit 0 is set, and the output poisoned
- * with NaN, if a consumer gave up waiting.  out: [n_heads * head_dim]. */
+ * with NaN, if a consumer gave up waiting.  out: [n_heads * head_dim].
+ * Round 4: the new token is folded in AFTER the merge of the slab keys' partials (rounding class of dl_attn_decode_rope, not its bits; the
+ * projection row, the residual stream and the appended K/V row stay bit-identical).  n_splits (1..4): attention workgroups per head; with more than one,
+ * every workgroup takes 128 of the head's slab keys (the last one the rest) -- its whole share is in registers before q arrives -- and the head's
+ * first workgroup merges the others' (M, L, O) partials, handed over as granules, in split order before it folds the new token in. */
 int64_t dl_gemv_qkv_attn_workspace_bytes(int n_heads, int n_kv_heads, int head_dim);
 int dl_gemv_qkv_attn(const void* W, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* qkv,
                      const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base, const int32_t* kv_len, void* k_slab,
                      void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, void* granules, int call_tag,
-                     int32_t* err_flag, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
+                     int32_t* err_flag, int n_splits, int n_heads, int n_kv_heads, int head_dim, int dtype, int grid_cap, void* stream);
 
 /* ---- the gate|up projection of layer `sparse_layer` at decode batch 1 (dl_gemv ADDNORM | OUT_SILU_PAIR: DML:1289 + DML:134-139 + DML:328) AND the
  * text predictor (dl_text_predictor_decide: DML:1385-1387, 2388-2391) on the residual stream entering that layer -- the h_in of this launch --

@@ -736,6 +736,17 @@ def test_gemv_qkv_attn_bit_identical_to_the_two_launches(ops, dtype, nH, nKV, d,
                 assert e_f <= max(2 * e_r, 2 * ulp * float(ref32.abs().max())), (step, e_f, e_r)
             else:
                 assert torch.equal(out_f, first), "the fused launch must be repeatable bit for bit (other call tag, same inputs)"
+        # several attention workgroups per head (128 slab keys each, partials merged by the head's first workgroup): everything bit-identical
+        # except the attention output, which stays in the rounding class; rows shorter than a workgroup's share leave some workgroups empty
+        for ns_ in (2, 3, 4):
+            k_f, v_f = k0.clone(), v0.clone()
+            qkv_f, ho_f, out_f = torch.zeros_like(qkv_r), torch.zeros_like(ho_r), torch.zeros_like(out_r)
+            ops.gemv_qkv_attn(W, qkv_f, h0, ho_f, delta, nw, eps, cos, sin, pos, lens, k_f, v_f, out_f, gran, 50 + 8 * ns_ + step, nH, nKV, d, err=err, n_splits=ns_)
+            assert torch.equal(qkv_f, qkv_r) and torch.equal(k_f, k_r) and torch.equal(v_f, v_r), (step, ns_)
+            diff = float((out_f.float() - out_r.float()).abs().max())
+            assert diff <= 2 * ulp * float(out_r.float().abs().max()), (step, ns_, diff)
+            e_f = float((out_f.float() - ref32).abs().max())
+            assert e_f <= max(2 * e_r, 2 * ulp * float(ref32.abs().max())), (step, ns_, e_f, e_r)
         k0, v0 = k_r, v_r  # the appended row stays for the next step
     assert int(err.item()) == 0
 

@@ -182,7 +182,7 @@ def test_generate_schedule_follows_observed_lengths_and_matches_reference_golden
         np.testing.assert_array_equal(out.cpu().numpy()[0], g["ids"][:, 0])
         np.testing.assert_array_equal(model.last_cache[1][-1].numpy(), g["len_last"][n - 1])
         np.testing.assert_array_equal(model.last_cache[1][0].numpy(), g["len_first"][n - 1])
-        splits = sorted({k[2] for k in model._dstate.graphs})  # (layers < sparse_layer, layer sparse_layer, last layer) split factors of each captured step
+        splits = sorted({k[2] for k in model._dstate.graphs})  # (k[3]: attention workgroups per head inside the fused launch)  # (layers < sparse_layer, layer sparse_layer, last layer) split factors of each captured step
         assert any(s[2] == 1 for s in splits) and any(s[2] > 1 for s in splits), f"one call must have replayed both schedules: {splits}"
         print(f"sync_every={sync_every}: captured decode graphs by split factors {splits}")
     # the same request again: same observations -> same schedule -> bit-identical

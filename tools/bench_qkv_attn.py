@@ -64,9 +64,11 @@ for T in ([int(a) for a in sys.argv[1:]] or [200, 250, 60]):
         i = it[0] = (it[0] + 1) % NB
         ops.gemv(ws[i], qkv, mode=ops.GEMV_ADDNORM, h_in=h0, h_out=ho, delta=delta, norm_w=nw, eps=1e-5)
 
-    def fused():
-        i = it[0] = (it[0] + 1) % NB
-        tagc[0] = (tagc[0] + 1) % 251
-        ops.gemv_qkv_attn(ws[i], qkv, h0, ho, delta, nw, 1e-5, cos, sin, lens, lens, ks[i], vs[i], out, gran, tagc[0], nH, nH, d)
+    def fused(ns=1):
+        def f():
+            i = it[0] = (it[0] + 1) % NB
+            tagc[0] = (tagc[0] + 1) % 251
+            ops.gemv_qkv_attn(ws[i], qkv, h0, ho, delta, nw, 1e-5, cos, sin, lens, lens, ks[i], vs[i], out, gran, tagc[0], nH, nH, d, n_splits=ns)
+        return f
 
-    print(f"T={T}: q|k|v gemv alone {timed(gemv_only):6.2f} us | + attention (4 waves) {timed(two(64)):6.2f} us | + attention (8 waves) {timed(two(128)):6.2f} us | one launch {timed(fused):6.2f} us | + split attention (n_splits = min(256 // nH, ceil(T / 64)) = {max(1, min(256 // nH, -(-T // 64)))}, in-kernel merge) {timed(two_split(max(1, min(256 // nH, -(-T // 64))))):6.2f} us", flush=True)
+    print(f"T={T}: q|k|v gemv alone {timed(gemv_only):6.2f} us | + attention (4 waves) {timed(two(64)):6.2f} us | + attention (8 waves) {timed(two(128)):6.2f} us | one launch, 1 / 2 / 3 / 4 attention workgroups per head {timed(fused(1)):6.2f} / {timed(fused(2)):6.2f} / {timed(fused(3)):6.2f} / {timed(fused(4)):6.2f} us | + split attention (n_splits = min(256 // nH, ceil(T / 64)) = {max(1, min(256 // nH, -(-T // 64)))}, in-kernel merge) {timed(two_split(max(1, min(256 // nH, -(-T // 64))))):6.2f} us", flush=True)

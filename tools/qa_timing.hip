@@ -9,7 +9,7 @@
 #include <vector>
 
 int main(int argc, char** argv) {
-  const int T = argc > 1 ? atoi(argv[1]) : 200, nH = argc > 2 ? atoi(argv[2]) : 32, D = 128;
+  const int T = argc > 1 ? atoi(argv[1]) : 200, nH = argc > 2 ? atoi(argv[2]) : 32, D = 128, NS = argc > 3 ? atoi(argv[3]) : 1;
   const int H = nH * D, N = 3 * H, K = H, T_cap = T + 16, NBUF = 4;
   std::vector<void*> ws(NBUF), ks(NBUF), vs(NBUF);
   for (int i = 0; i < NBUF; ++i) {
@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   hipMalloc(&qkv, N * 2); hipMalloc(&out, H * 2);
   hipMalloc(&cs, (size_t)(T_cap + 8) * D * 2); hipMemset(cs, 0x3c, (size_t)(T_cap + 8) * D * 2);
   hipMalloc(&sn, (size_t)(T_cap + 8) * D * 2); hipMemset(sn, 0x3c, (size_t)(T_cap + 8) * D * 2);
-  hipMalloc(&gran, (size_t)N * 8); hipMemset(gran, 0, (size_t)N * 8);
+  hipMalloc(&gran, (size_t)dl_gemv_qkv_attn_workspace_bytes(nH, nH, D)); hipMemset(gran, 0, (size_t)dl_gemv_qkv_attn_workspace_bytes(nH, nH, D));
   hipMalloc(&lens, 4); hipMalloc(&err, 4); hipMemset(err, 0, 4);
   const int tl = T - 1;
   hipMemcpy(lens, &tl, 4, hipMemcpyHostToDevice);
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     hipStreamSynchronize(st);
     hipEventRecord(e0, st);
     int rc = dl_gemv_qkv_attn(ws[it % NBUF], K, h, h2, dl, nw, 1e-5f, qkv, cs, sn, T_cap + 8, lens, lens, ks[it % NBUF], vs[it % NBUF], (int64_t)nH * T_cap * D, (int64_t)T_cap * D, T_cap,
-                              out, gran, it + 1, err, nH, nH, D, DL_BF16, 0, st);
+                              out, gran, it + 1, err, NS, nH, nH, D, DL_BF16, 0, st);
     hipEventRecord(e1, st);
     hipStreamSynchronize(st);
     if (rc) { printf("error: %s\n", dl_last_error()); return 1; }
@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     hipStreamSynchronize(st);
     float ms2 = 0; hipEventElapsedTime(&ms2, e0, e2);
     if (it < 7) continue;
-    const int grid = 1024, n_gemv = grid - nH;
+    const int grid = 1024, n_gemv = grid - nH * NS;
     long long t0 = s[0];
     for (int b = 0; b < grid; ++b) t0 = std::min(t0, s[b * 8]);
     auto us = [&](long long x) { return (x - t0) * 0.01; };
@@ -87,8 +87,8 @@ int main(int argc, char** argv) {
       for (int i = 0; i <= 10; ++i) printf(" %.1f", end[std::min(end.size() - 1, end.size() * i / 10)]);
       printf("\n");
     }
-    printf("T=%d heads=%d: launch %.2f us by events (plain q|k|v dl_gemv: %.2f) | streaming workgroups start %.2f..%.2f (median %.2f), end median %.2f, p90 %.2f, last %.2f | attention workgroups start %.2f..%.2f, q arrived %.2f..%.2f, "
-           "slab keys merged by %.2f, heads done %.2f..%.2f us\n", T, nH, ms * 1e3, ms2 * 1e3, start.front(), start.back(), start[start.size() / 2], end[end.size() / 2], end[end.size() * 9 / 10], end.back(), a0, a0m, qm, q, slab, donem, done);
+    printf("T=%d heads=%d splits=%d: launch %.2f us by events (plain q|k|v dl_gemv: %.2f) | streaming workgroups start %.2f..%.2f (median %.2f), end median %.2f, p90 %.2f, last %.2f | attention workgroups start %.2f..%.2f, q arrived %.2f..%.2f, "
+           "slab keys merged by %.2f, heads done %.2f..%.2f us\n", T, nH, NS, ms * 1e3, ms2 * 1e3, start.front(), start.back(), start[start.size() / 2], end[end.size() / 2], end[end.size() * 9 / 10], end.back(), a0, a0m, qm, q, slab, donem, done);
   }
   return 0;
 }
