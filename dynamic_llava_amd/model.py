@@ -1102,6 +1102,26 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             return (576 if big else 384), (576 if big else 384)
         return (768 if big else 704), (576 if big else 256)
 
+    def _width_bucket(self, W: int, n_feat: int) -> int:
+        """Prompt-width bucket of the device-layout prefill: the smallest width >= W whose COMPACTED row count (W - 1 + kept image tokens: the
+        M of 30 of the 32 layers' GEMMs) is a multiple of `prefill_width_bucket` -- 16 by default, one MFMA tile of rows, so a bucket never
+        adds a row tile to those GEMMs that the true width would not have needed.  0 / 1 disables bucketing."""
+        g = int(self.prefill_width_bucket or 0)
+        if g <= 1:
+            return W
+        sc = self.config.sparse_config
+        kept = int(n_feat * sc["vision_keep_rate"]) if (sc["use_vision_predictor"] and sc["sparse_layer"] < self.config.num_hidden_layers) else n_feat
+        rows = W - 1 + kept
+        return W + (-rows) % g
+
+    def _evict_prefill_entries(self):
+        """Bound the prefill-shape cache: at most `max_prefill_graphs` captured graphs and as many seen-once entries (oldest first)."""
+        cap = self.max_prefill_graphs
+        graphs = [k for k, e in self._prefill_graphs.items() if e["graph"] is not None]
+        seen = [k for k, e in self._prefill_graphs.items() if e["graph"] is None]
+        for k in graphs[: max(0, len(graphs) - cap + 1)] + seen[: max(0, len(seen) - cap + 1)]:
+            self._prefill_graphs.pop(k)
+
     def _get_dstate(self, B, out_cap):
         st = self._dstate
         if st is None or st.B != B or st.out_ids.shape[1] < out_cap:
