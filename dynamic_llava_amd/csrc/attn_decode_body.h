@@ -409,10 +409,6 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
 //   fetch_kv(d, dpar, k_own, k_par, v): called by the threads vtid < D after the slab merge -- returns the raw k[d], k[dpar], v[d] of the new token
 //          (dl_gemv_qkv_attn polls the projection's granules there: three requests per thread in one round trip, no LDS staging, no barrier).
 //   red  : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains TWO __syncthreads().
-// "These values must be in registers NOW": an empty asm that claims to modify them.  Without it the compiler is free to sink a load below a later
-// polling loop (nothing orders a plain load against relaxed atomic loads), which turns a prefetch into a cold round trip on the critical path.
-__device__ __forceinline__ void pin_reg(uint4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
-__device__ __forceinline__ void pin_reg(float& x) { asm volatile("" : "+v"(x)); }
 template <typename T, int D, int NW, int U>
 __device__ __forceinline__ void attn_split_pin_prefetched(AttnSplitState<T, D, NW, U>& s) {
 #pragma unroll

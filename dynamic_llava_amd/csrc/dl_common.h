@@ -200,6 +200,11 @@ __device__ __forceinline__ float row8_sum(float v) {  // aligned groups of 8 lan
 }
 // whole wave (all 64 lanes active): DPP inside the four 16-lane rows, then the four row results through v_readlane (scalar
 // registers, wave-uniform) -- no LDS crossbar at all.  Every lane gets the same value.
+// "These values must be in registers NOW": an empty asm that claims to modify them.  Without it the compiler is free to sink a load below a later
+// polling loop (nothing orders a plain load against relaxed atomic loads), which turns a prefetch into a cold round trip on the critical path.
+__device__ __forceinline__ void pin_reg(uint4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+__device__ __forceinline__ void pin_reg(float& x) { asm volatile("" : "+v"(x)); }
+
 __device__ __forceinline__ float wave_lane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

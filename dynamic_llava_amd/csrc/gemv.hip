@@ -692,6 +692,8 @@ extern "C" int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void
     a.gran = reinterpret_cast<u64_t*>(granules); a.err = err_flag; a.D = d_model; a.call_tag = call_tag;
     const int side = (d_model + 7) / 8 + (d_model / 2 + 7) / 8 + 1;
     const int groups = (N / 2 + 3) / 4;
+    if (grid_cap > 2 * side) grid_cap -= side;  // projection + predictor workgroups together stay within what is resident at once (as dl_gemv_qkv_attn): with
+                                                // 1024 + 97 the last 97 streaming workgroups ran as a second round behind the others (+9 us on the launch)
     const int grid = (groups < grid_cap ? groups : grid_cap) + side;
     size_t smem = (size_t)K * sizeof(float);  // stage 1 stages the row in fp32; the projection needs K elements of the model dtype
     if (smem < (size_t)2 * d_model * sizeof(float)) smem = (size_t)2 * d_model * sizeof(float);

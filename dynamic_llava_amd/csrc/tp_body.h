@@ -221,7 +221,18 @@ __device__ __forceinline__ void tp_stage2b_body(const float* __restrict__ a1g, c
         bq[ps][j] = load1<T>(b5, n);
       }
   };
-  if (pre) request(0);
+  if (pre) {
+    request(0);
+    // really requested NOW (the compiler may otherwise sink these loads below wait_input()'s polling loop -- what "requests its weights before it
+    // waits" was written to avoid; found with the fused attention launch, tools/qa_timing.hip)
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pin_reg(wq[ps][j]);
+        pin_reg(bq[ps][j]);
+      }
+  }
   wait_input();
   for (int i = threadIdx.x; i < D / 2; i += blockDim.x) a1[i] = a1g[(int64_t)b * (D / 2) + i];
   __syncthreads();
