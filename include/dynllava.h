@@ -320,9 +320,9 @@ int dl_linear_splitk(const void* A, int64_t lda, const void* W, float* parts, in
 
 /* ---- a batch-1 decode layer's q|k|v projection (DML:1011-1013, with the residual add + input RMSNorm prologue of dl_gemv's ADDNORM mode)
  * AND the attention that consumes it (dl_attn_decode_rope with one split: RoPE DML:260-285, KV append CU:109-268, ragged attention
- * DML:1061-1122) in ONE launch.  The attention workgroups (one per head) are the first blocks of the grid: they request their K/V rows at once
+ * DML:1061-1122) in ONE launch.  The attention workgroups (n_splits per head) are the last blocks of the grid: they request their K/V rows at once
  * and then wait for their 3 x head_dim projection outputs, which the weight-streaming workgroups publish as 8-byte {tag, value} granules
- * beside the ordinary stores to `qkv`.  Bit-identical to dl_gemv(ADDNORM) + dl_attn_decode_rope(n_splits = 1).  B = 1 only.
+ * beside the ordinary stores to `qkv`.  B = 1 only.
  * W: [(n_heads + 2 n_kv_heads) head_dim, K].  granules: dl_gemv_qkv_attn_workspace_bytes() bytes, zeroed once per request (tags are made of
  * pos_base[0] and call_tag, 0..255: distinct for every (step, layer) of a request).  err_flag (may be NULL): bit 0 is set, and the output poisoned
  * with NaN, if a consumer gave up waiting.  out: [n_heads * head_dim].
