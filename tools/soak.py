@@ -20,8 +20,8 @@ for B, n in ((1, 1500), (3, 300), (8, 300), (16, 200), (32, 100)):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     lens = [t.clone() for t in model.last_cache[1]]
     model.use_hip_graph = False
-    # same max_new_tokens: the split-KV factor of the decode attention derives from the requested capacity (KVSlabCache.logical_cap), so only
-    # runs with equal capacity are bit-comparable
+    # (round 4: the decode schedule -- split-KV factor, attention workgroups per head of the fused launch -- follows the lengths observed chunk by
+    # chunk, by a deterministic rule: the same request replays the same kernels with and without hipGraph)
     b = model.generate(ids, image_features=f, max_new_tokens=n, eos_token_id=None)
     same = torch.equal(a, b)
     first = [int((a[0] != a[i]).nonzero()[0]) if not torch.equal(a[0], a[i]) else -1 for i in range(B)]
