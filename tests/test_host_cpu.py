@@ -203,3 +203,24 @@ def test_split_factor_follows_the_bounds_not_the_capacity():
     assert c.n_splits(3, 40) == 1 and c.n_splits(0, 40) == 6
     c.set_bounds(None, None)
     assert c.n_splits(3, 40) == 6
+
+
+def test_width_bucket_rule():
+    """The prefill's width bucket: the smallest width >= W whose COMPACTED row count (W - 1 + kept image tokens) is a multiple of 16 -- never more
+    than 15 extra rows, idempotent, monotone, and the identity when bucketing is off or nothing is compacted to a multiple."""
+    from oracle import fixtures as fx
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+    from dynamic_llava_amd.model import DynamicLlavaLlamaForCausalLM
+
+    cfg = DynamicLlavaConfig.from_namespace(fx.tiny_config())
+    m = DynamicLlavaLlamaForCausalLM(cfg, with_vision_tower=False)
+    n_feat = 576
+    kept = int(n_feat * cfg.sparse_config["vision_keep_rate"])
+    prev = 0
+    for W in range(2, 200):
+        Wb = m._width_bucket(W, n_feat)
+        assert W <= Wb < W + 16 and (Wb - 1 + kept) % 16 == 0 and m._width_bucket(Wb, n_feat) == Wb and Wb >= prev
+        prev = Wb
+    assert len({m._width_bucket(W, n_feat) for W in range(44, 101)}) == 5  # the eval stream's 57 widths (35 + 1 + U[8,64]) share five graphs
+    m.prefill_width_bucket = 0
+    assert all(m._width_bucket(W, n_feat) == W for W in (3, 57, 100))
