@@ -405,10 +405,10 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
 // and after the wait the D threads that hold (M, L, O[d]) fold the new token in themselves: RoPE of their own element of k, one 128-term dot product
 // (wave reduction + one LDS word per wave), one softmax update, the slab append, the normalised output.  Same mathematics; the new token's term is
 // added after the slab merge instead of before it, so the last bits may differ from attn_split_finish (kernel tests: noise class, not bits).
-//   rows : LDS, the raw (un-rotated) q vector of this head, D elements.
+//   rows : LDS, the raw (un-rotated) q vector of this head, D elements; q_rot_lds: LDS, D elements (receives the rotated query).
 //   fetch_kv(d, dpar, k_own, k_par, v): called by the threads vtid < D after the slab merge -- returns the raw k[d], k[dpar], v[d] of the new token
 //          (dl_gemv_qkv_attn polls the projection's granules there: three requests per thread in one round trip, no LDS staging, no barrier).
-//   red  : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains TWO __syncthreads().
+//   red  : LDS scratch, >= NW floats.   out: the head's attention output for threads vtid < D.   Contains THREE __syncthreads().
 template <typename T, int D, int NW, int U>
 __device__ __forceinline__ void attn_split_pin_prefetched(AttnSplitState<T, D, NW, U>& s) {
 #pragma unroll
@@ -431,8 +431,7 @@ __device__ __forceinline__ void attn_split_pin_prefetched(AttnSplitState<T, D, N
 // inside attn_split_finish_newlast it sat on the launch's critical path, right after q's arrival -- tools/qa_timing.hip)
 template <typename T>
 struct AttnRopeRow {
-  float cs[Elem<T>::kVec], sn[Elem<T>::kVec];  // this lane's slice (columns c % (D/2) ...)
-  float cs1, sn1;                              // the finishing thread's own element
+  float cs1, sn1;  // cos / sin of the finishing thread's own element
 };
 template <typename T, int D, int NW, int U>
 __device__ __forceinline__ void attn_newlast_preload(const AttnSplitState<T, D, NW, U>& s, int vtid, const void* cos_, const void* sin_, int n_pos, int pos,
@@ -443,16 +442,9 @@ __device__ __forceinline__ void attn_newlast_preload(const AttnSplitState<T, D, 
   p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
   const S* cos_row = reinterpret_cast<const S*>(cos_) + (int64_t)p * D;  // table = cat(freqs, freqs)
   const S* sin_row = reinterpret_cast<const S*>(sin_) + (int64_t)p * D;
-  load16<T>(cos_row + (s.c % HALF), r.cs);
-  load16<T>(sin_row + (s.c % HALF), r.sn);
   const int d = vtid < D ? vtid : 0;
   r.cs1 = Elem<T>::to_f(cos_row[d % HALF]);
   r.sn1 = Elem<T>::to_f(sin_row[d % HALF]);
-#pragma unroll
-  for (int i = 0; i < Elem<T>::kVec; ++i) {
-    pin_reg(r.cs[i]);
-    pin_reg(r.sn[i]);
-  }
   pin_reg(r.cs1);
   pin_reg(r.sn1);
 }
@@ -465,7 +457,7 @@ struct AttnSlabWhole {
 };
 template <typename T, int D, int NW, int U, typename FetchKV, typename AfterSlab = AttnSlabWhole>
 __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, NW, U>& s, int vtid, const typename Elem<T>::storage* rows, const AttnRopeRow<T>& rope,
-                                                          float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
+                                                          typename Elem<T>::storage* q_rot_lds, float scale, bool write_kv, int T_cap, float* sm_m, float* sm_l,
                                                           float* sm_o, float* red, float& out, FetchKV fetch_kv, AfterSlab after_slab = AfterSlab()) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
@@ -473,14 +465,17 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
   constexpr int HALF = D / 2;
   static_assert(D % 64 == 0 && D / 64 <= NW, "the D finishing threads are whole waves of this workgroup");
   const int c = s.c;
-  const int cpar = c < HALF ? c + HALF : c - HALF;
+  // the rotated query: each of the D finishing threads rotates ITS element (DML:283-284, the roundings of rope16) and publishes it in LDS; every lane
+  // then reads its 16-byte slice.  (Rotating the slices lane by lane needed the table row in 16 more registers per lane, held across the wait for q --
+  // registers this kernel does not have: it must stay within 128 to keep the grid resident.)
+  const int d = vtid < D ? vtid : 0, dpar = d < HALF ? d + HALF : d - HALF;
+  const float cs1 = rope.cs1, sn1 = rope.sn1;
+  const float q_own = Elem<T>::to_f(rows[d]), q_par = Elem<T>::to_f(rows[dpar]);
+  const float q_rot = Elem<T>::round(Elem<T>::round(q_own * cs1) + Elem<T>::round((d < HALF ? -q_par : q_par) * sn1));
+  if (vtid < D) q_rot_lds[d] = Elem<T>::from_f(q_rot);
+  __syncthreads();
   float qv[V];
-  {
-    float own[V], par[V];
-    load16<T>(rows + c, own);
-    load16<T>(rows + cpar, par);
-    if (c < HALF) rope16<T, false>(own, par, rope.cs, rope.sn, qv); else rope16<T, true>(own, par, rope.cs, rope.sn, qv);
-  }
+  load16<T>(q_rot_lds + c, qv);
   DL_QSTAMP(4);  // q rotated
   float m, l, o[V];
   attn_split_keys<T, D, NW, U>(s, qv, scale, m, l, o);
@@ -490,11 +485,6 @@ __device__ __forceinline__ void attn_split_finish_newlast(AttnSplitState<T, D, N
   DL_QSTAMP(2);  // slab keys merged
   out = 0.f;
   if (!after_slab(M, L, O)) return;
-  // this thread's own element of the rotated query (needs q only: done before the wait)
-  const int d = vtid < D ? vtid : 0, dpar = d < HALF ? d + HALF : d - HALF;
-  const float cs1 = rope.cs1, sn1 = rope.sn1;
-  const float q_own = Elem<T>::to_f(rows[d]), q_par = Elem<T>::to_f(rows[dpar]);
-  const float q_rot = Elem<T>::round(Elem<T>::round(q_own * cs1) + Elem<T>::round((d < HALF ? -q_par : q_par) * sn1));  // DML:283-284, as rope16
   float part = 0.f, k_rot = 0.f, vv = 0.f;
   S v_raw = S();
   if (vtid < D) {

@@ -500,10 +500,11 @@ __global__ __launch_bounds__(kGemvThreads) __attribute__((amdgpu_waves_per_eu(4,
   // the slab keys' partials are merged while the projection still streams; the new token is folded in by the D finishing threads, each of which
   // receives its three values (k[d], k[d +- D/2], v[d]: the projection's last outputs) straight from the granules: attn_split_finish_newlast
   __shared__ float red[NW];
+  __shared__ __attribute__((aligned(16))) S q_rot_lds[D];
   float o_head;
   const u64_t* gk = a.gran + (int64_t)(a.n_heads + kvh) * D;
   const u64_t* gv = a.gran + (int64_t)(a.n_heads + a.n_kv_heads + kvh) * D;
-  attn_split_finish_newlast<T, D, NW, U>(st, tid, rows, rope, 1.0f / sqrtf((float)D), h % n_rep == 0, a.T_cap, sm_m, sm_l,
+  attn_split_finish_newlast<T, D, NW, U>(st, tid, rows, rope, q_rot_lds, 1.0f / sqrtf((float)D), h % n_rep == 0, a.T_cap, sm_m, sm_l,
                                          sm_o, red, o_head, [&](int d, int dpar, S& k_own, S& k_par, S& v_new) {
                                            u64_t g0 = 0, g1 = 0, g2 = 0;
                                            for (int spins = 0;; ++spins) {  // the three requests travel together; repeated until all carry this step's tag
