@@ -322,6 +322,52 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_kernel(const void*
   }
 }
 
+// The same for rows too long for one lane set (K > 12288: the 13B down_proj, K = 13824): a row is shared by the two waves of a pair, each
+// keeping ITS half of x in registers (XB * 8 chunks per lane) and streaming its half of the row; the pair's partial sums meet in LDS and
+// the even wave adds them low half first (fixed order).  Two rows per workgroup pass.
+template <typename T, int XB>
+__global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_halves_kernel(const void* __restrict__ W_, int N, int K, const void* __restrict__ x_,
+                                                                            void* __restrict__ y_) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  __shared__ float part[kGemvThreads / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int half = wid & 1, pr = wid >> 1;
+  const int nvec = K / V;
+  const int hv = ((nvec + 1) / 2 + 63) / 64 * 64;  // chunks of the low half (whole lane sets)
+  const int v0 = half * hv, v1 = half ? nvec : (hv < nvec ? hv : nvec);
+  const S* W = reinterpret_cast<const S*>(W_);
+  const S* x = reinterpret_cast<const S*>(x_);
+  constexpr int RPW = kGemvThreads / 128;  // rows per workgroup pass
+  const int groups = (N + RPW - 1) / RPW;
+  uint4 xr[XB * 8];
+#pragma unroll
+  for (int c = 0; c < XB * 8; ++c) {
+    const int v = v0 + lane + 64 * c;
+    xr[c] = v < v1 ? *reinterpret_cast<const uint4*>(x + (int64_t)v * V) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    int n = grp * RPW + pr;
+    const bool live = n < N;
+    n = live ? n : N - 1;
+    const S* wp = W + (int64_t)n * K;
+    uint4 w[XB * 8];
+#pragma unroll
+    for (int c = 0; c < XB * 8; ++c) {
+      const int v = v0 + lane + 64 * c;
+      w[c] = v < v1 ? ldg_nt(wp + (int64_t)v * V) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < XB * 8; ++c) acc = dot16<T>(w[c], xr[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0 && half) part[wid] = acc;
+    __syncthreads();
+    if (lane == 0 && !half && live) store1<T>(y_, n, acc + part[wid + 1]);
+    __syncthreads();
+  }
+}
+
 // workgroup cap (per call: `grid_cap` of dl_gemv, 0 = this default; no process-global state)
 // tools/bench_gemv.py sweep (after the prologue became one round trip): 4 workgroups per CU beat 2 on the add+norm shapes (qkv 19.6 ->
 // 17.3 us, gate|up 31.6 -> 29.2 us, vocabulary projection 45.2 -> 40.9 us); o / down have only 512 neuron groups
@@ -373,6 +419,16 @@ static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, i
       if (xb <= 1) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 1>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
       else if (xb == 2) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 2>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
       else hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 3>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      return DL_OK;
+    }
+    if (K / 8 <= 2 * 64 * 16) {  // 12288 < K <= 16384 (13B down_proj): a row per wave PAIR, each wave half of x in registers
+      // whole passes over a grid of up to 5/4 of the cap (13B down_proj: 2560 row pairs = 2 passes of 1280 workgroups, 23.0 us against 23.3 with
+      // 1024 and 2.5 passes; tools/bench_gemv.py MODEL=13b)
+      const int groups = (N + 1) / 2;
+      const int wide = grid_cap + grid_cap / 4;
+      const int passes = (groups + wide - 1) / wide;
+      const int grid = (groups + passes - 1) / passes;
+      hipLaunchKernelGGL((gemv_b1_plain_halves_kernel<T, 2>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
       return DL_OK;
     }
   }

@@ -12,6 +12,10 @@ from dynamic_llava_amd import hip_ops as ops
 dev, dt = "cuda", torch.bfloat16
 SHAPES = [("qkv  addnorm", 12288, 4096, ops.GEMV_ADDNORM), ("o    plain", 4096, 4096, ops.GEMV_PLAIN), ("gu   addnorm+pair", 22016, 4096, ops.GEMV_ADDNORM | ops.GEMV_OUT_SILU_PAIR),
           ("down plain", 4096, 11008, ops.GEMV_PLAIN), ("gu   addnorm", 22016, 4096, ops.GEMV_ADDNORM), ("down silumul", 4096, 11008, ops.GEMV_SILUMUL), ("lm_head addnorm", 32000, 4096, ops.GEMV_ADDNORM)]
+if os.environ.get("MODEL") == "13b":  # LLaVA-1.5-13B (configs[4]): MODEL=13b python tools/bench_gemv.py
+    SHAPES = [("qkv  addnorm", 15360, 5120, ops.GEMV_ADDNORM), ("o    plain", 5120, 5120, ops.GEMV_PLAIN), ("gu   addnorm+pair", 27648, 5120, ops.GEMV_ADDNORM | ops.GEMV_OUT_SILU_PAIR),
+              ("down plain", 5120, 13824, ops.GEMV_PLAIN)]
+CAPS = [int(c) for c in os.environ.get("CAPS", "512,1024,2048,4096").split(",")]
 B = int(os.environ.get("B", "1"))
 NW = 8
 
@@ -48,7 +52,7 @@ for name, N, K, mode in SHAPES:
     nw = torch.ones(K, device=dev, dtype=dt)
     best = None
     for variant in (0,):
-        for cap in (512, 1024, 2048, 4096):
+        for cap in CAPS:
             if (mode & 3) == ops.GEMV_ADDNORM:
                 fns = [lambda w=w: ops.gemv(w, y, mode=mode, h_in=h, h_out=h2, delta=dl, norm_w=nw, eps=1e-5, grid_cap=cap) for w in ws]
             else:
