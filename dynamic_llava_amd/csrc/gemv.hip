@@ -322,10 +322,10 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_kernel(const void*
   }
 }
 
-// The same for rows too long for one lane set (K > 12288: the 13B down_proj, K = 13824): a row is shared by the two waves of a pair, each
-// keeping ITS half of x in registers (XB * 8 chunks per lane) and streaming its half of the row; the pair's partial sums meet in LDS and
+// The same for long rows (8192 < K <= 16384: down_proj, K = 11008 / 13824): a row is shared by the two waves of a pair, each
+// keeping ITS half of x in registers (C chunks per lane) and streaming its half of the row; the pair's partial sums meet in LDS and
 // the even wave adds them low half first (fixed order).  Two rows per workgroup pass.
-template <typename T, int XB>
+template <typename T, int C>
 __global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_halves_kernel(const void* __restrict__ W_, int N, int K, const void* __restrict__ x_,
                                                                             void* __restrict__ y_) {
   constexpr int V = Elem<T>::kVec;
@@ -340,9 +340,9 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_halves_kernel(cons
   const S* x = reinterpret_cast<const S*>(x_);
   constexpr int RPW = kGemvThreads / 128;  // rows per workgroup pass
   const int groups = (N + RPW - 1) / RPW;
-  uint4 xr[XB * 8];
+  uint4 xr[C];
 #pragma unroll
-  for (int c = 0; c < XB * 8; ++c) {
+  for (int c = 0; c < C; ++c) {
     const int v = v0 + lane + 64 * c;
     xr[c] = v < v1 ? *reinterpret_cast<const uint4*>(x + (int64_t)v * V) : make_uint4(0u, 0u, 0u, 0u);
   }
@@ -351,15 +351,15 @@ __global__ __launch_bounds__(kGemvThreads) void gemv_b1_plain_halves_kernel(cons
     const bool live = n < N;
     n = live ? n : N - 1;
     const S* wp = W + (int64_t)n * K;
-    uint4 w[XB * 8];
+    uint4 w[C];
 #pragma unroll
-    for (int c = 0; c < XB * 8; ++c) {
+    for (int c = 0; c < C; ++c) {
       const int v = v0 + lane + 64 * c;
       w[c] = v < v1 ? ldg_nt(wp + (int64_t)v * V) : make_uint4(0u, 0u, 0u, 0u);
     }
     float acc = 0.f;
 #pragma unroll
-    for (int c = 0; c < XB * 8; ++c) acc = dot16<T>(w[c], xr[c], acc);
+    for (int c = 0; c < C; ++c) acc = dot16<T>(w[c], xr[c], acc);
     acc = wave_sum(acc);
     if (lane == 0 && half) part[wid] = acc;
     __syncthreads();
@@ -411,24 +411,24 @@ static int gemv_variant(bool pair, const void* W, int N, int K, const void* x, i
   // 2.709 -> 2.675 ms).  Otherwise one row x 8 chunks per wave, which doubles the neuron groups of these 4096-row projections so that
   // they also reach 4 workgroups per CU (o 7.70 -> 7.42 us, down 19.0 -> 18.3 us).
   if constexpr (B == 1 && MODE == 0 && Elem<T>::kVec == 8) {
-    if (K / 8 <= 64 * 24) {  // x fits the register file: 8 / 16 / 24 chunks per lane (K <= 12288)
+    if (K / 8 <= 64 * 16) {  // x fits the register file: 8 / 16 chunks per lane (K <= 8192)
       const int groups = (N + 3) / 4;
       const int cap = grid_cap / 2 > 0 ? grid_cap / 2 : 1;  // two rows per wave reuse the x registers
       const int grid = groups < cap ? groups : cap;
-      const int xb = (K / 8 + 511) / 512;
-      if (xb <= 1) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 1>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
-      else if (xb == 2) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 2>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
-      else hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 3>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      if (K / 8 <= 512) hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 1>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      else hipLaunchKernelGGL((gemv_b1_plain_kernel<T, 2>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
       return DL_OK;
     }
-    if (K / 8 <= 2 * 64 * 16) {  // 12288 < K <= 16384 (13B down_proj): a row per wave PAIR, each wave half of x in registers
-      // whole passes over a grid of up to 5/4 of the cap (13B down_proj: 2560 row pairs = 2 passes of 1280 workgroups, 23.0 us against 23.3 with
-      // 1024 and 2.5 passes; tools/bench_gemv.py MODEL=13b)
+    if (K / 8 <= 2 * 64 * 16) {
+      // 8192 < K <= 16384 (down_proj: K = 11008 / 13824): a row per wave PAIR, each wave half of x in registers (12 / 16 chunks per lane), whole
+      // passes over a grid of up to 5/4 of the cap.  tools/bench_gemv.py: 7B down 17.5 (one wave per row, 24 chunks) -> 16.7 us, 13B down (which
+      // did not fit one wave's registers and ran the generic LDS kernel) -> 23.0 us = 6.16 TB/s (2560 row pairs = 2 passes of 1280 workgroups)
       const int groups = (N + 1) / 2;
       const int wide = grid_cap + grid_cap / 4;
       const int passes = (groups + wide - 1) / wide;
       const int grid = (groups + passes - 1) / passes;
-      hipLaunchKernelGGL((gemv_b1_plain_halves_kernel<T, 2>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      if (((K / 8 + 1) / 2 + 63) / 64 <= 12) hipLaunchKernelGGL((gemv_b1_plain_halves_kernel<T, 12>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
+      else hipLaunchKernelGGL((gemv_b1_plain_halves_kernel<T, 16>), dim3((unsigned)grid), dim3(kGemvThreads), 0, st, W, N, K, x, y);
       return DL_OK;
     }
   }

@@ -353,7 +353,7 @@ def test_linear_epilogues(ops, dtype, M, N, K, flags):
 @pytest.mark.parametrize("B", [1, 3])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (22016, 4096), (4096, 11008), (1000, 256), (37, 512),
                                  (15360, 5120), (5120, 5120), (27648, 5120), (5120, 13824),  # these four: LLaVA-1.5-13B (configs[4])
-                                 (33, 12296), (70, 16384), (12, 16392)])  # a row per wave pair (12288 < K <= 16384): ragged halves, odd N, largest K; beyond: generic kernel
+                                 (33, 12296), (70, 16384), (12, 16392), (9, 8200), (21, 12288)])  # a row per wave pair (8192 < K <= 16384): ragged halves, odd N, largest K; beyond: generic kernel
 def test_gemv_modes(ops, dtype, B, N, K):
     """dl_gemv against the eager op sequence it replaces (fp32 evaluation of the same rounded operands)."""
     g = torch.Generator().manual_seed(16)
