@@ -25,49 +25,79 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_
   const int nvec = H / V;
   float x[kMaxVecPerThread][V];
   float ss = 0.f;
+  if constexpr (ADD == 2) {
+    // Vectors are taken in PAIRS and every request of a pair -- the residual rows and all slices of a batch, for both vectors -- is issued
+    // before the first addition (H = 4096 in a 2-byte type is exactly one pair per thread).  Vector by vector, the second one's slices were
+    // requested only after the first one's additions: a second dependent memory round trip in a launch that is nothing but latency
+    // (prefill M = 170: 8.9 us per launch, twice per layer).  The additions keep their slice order: bit-identical.
 #pragma unroll
-  for (int i = 0; i < kMaxVecPerThread; ++i) {
-    const int v = threadIdx.x + i * kThreads;
-    if (v < nvec) {
-      load16<T>(h + v * V, x[i]);
-      if constexpr (ADD == 1) {
-        float d[V];
-        load16<T>(delta + v * V, d);
+    for (int i0 = 0; i0 < kMaxVecPerThread; i0 += 2) {
+      int vv[2];
+      bool ok[2];
 #pragma unroll
-        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
-        store16<T>(h + v * V, x[i]);
+      for (int e = 0; e < 2; ++e) {
+        const int v = threadIdx.x + (i0 + e) * kThreads;
+        ok[e] = v < nvec;
+        vv[e] = ok[e] ? v : 0;  // out-of-range lanes re-read vector 0 (always there) so that the loads stay unconditional
       }
-      if constexpr (ADD == 2) {
-        float d[V];
+      if (i0 * kThreads >= nvec) break;  // (uniform) no thread of the workgroup has this pair
+      float d[2][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) d[j] = 0.f;
-        // all slices of a batch are requested before the first is added (a rolled load -> add loop paid one memory round trip per slice:
-        // 10 us per launch at 8 slices); the additions stay in slice order
-        for (int s0 = 0; s0 < n_slices; s0 += kPartsBatch) {
-          float4 pv[kPartsBatch][V / 4];
+      for (int e = 0; e < 2; ++e) {
+        load16<T>(h + vv[e] * V, x[i0 + e]);
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[e][j] = 0.f;
+      }
+      for (int s0 = 0; s0 < n_slices; s0 += kPartsBatch) {
+        float4 pv[2][kPartsBatch][V / 4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int s = 0; s < kPartsBatch; ++s)
 #pragma unroll
             for (int q = 0; q < V / 4; ++q)
-              pv[s][q] = *reinterpret_cast<const float4*>(parts + (s0 + s < n_slices ? s0 + s : s0) * slice_stride + v * V + q * 4);
+              pv[e][s][q] = *reinterpret_cast<const float4*>(parts + (s0 + s < n_slices ? s0 + s : s0) * slice_stride + vv[e] * V + q * 4);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int s = 0; s < kPartsBatch; ++s)
             if (s0 + s < n_slices) {
 #pragma unroll
               for (int q = 0; q < V / 4; ++q) {
-                d[q * 4] += pv[s][q].x;
-                d[q * 4 + 1] += pv[s][q].y;
-                d[q * 4 + 2] += pv[s][q].z;
-                d[q * 4 + 3] += pv[s][q].w;
+                d[e][q * 4] += pv[e][s][q].x;
+                d[e][q * 4 + 1] += pv[e][s][q].y;
+                d[e][q * 4 + 2] += pv[e][s][q].z;
+                d[e][q * 4 + 3] += pv[e][s][q].w;
               }
             }
-        }
-#pragma unroll
-        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + Elem<T>::round(d[j]));
-        store16<T>(h + v * V, x[i]);
       }
 #pragma unroll
-      for (int j = 0; j < V; ++j) ss += x[i][j] * x[i][j];
+      for (int e = 0; e < 2; ++e) {
+        if (ok[e]) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) x[i0 + e][j] = Elem<T>::round(x[i0 + e][j] + Elem<T>::round(d[e][j]));
+          store16<T>(h + vv[e] * V, x[i0 + e]);
+#pragma unroll
+          for (int j = 0; j < V; ++j) ss += x[i0 + e][j] * x[i0 + e][j];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kMaxVecPerThread; ++i) {
+      const int v = threadIdx.x + i * kThreads;
+      if (v < nvec) {
+        load16<T>(h + v * V, x[i]);
+        if constexpr (ADD == 1) {
+          float d[V];
+          load16<T>(delta + v * V, d);
+#pragma unroll
+          for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
+          store16<T>(h + v * V, x[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) ss += x[i][j] * x[i][j];
+      }
     }
   }
   if (w_ == nullptr) return;  // residual add only

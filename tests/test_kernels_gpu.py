@@ -653,7 +653,7 @@ def test_compact_rows_by_mask(ops, dtype, total, span0, n_span, H):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K,s", [(170, 4096, 11008, 8), (117, 4096, 4096, 4), (1, 256, 1024, 2), (192, 320, 1088, 8), (200, 512, 2048, 4), (631, 4096, 1024, 1), (33, 256, 128, 1)])
+@pytest.mark.parametrize("M,N,K,s", [(170, 4096, 11008, 8), (117, 4096, 4096, 4), (1, 256, 1024, 2), (192, 320, 1088, 8), (200, 512, 2048, 4), (631, 4096, 1024, 1), (33, 256, 128, 1), (40, 5120, 1024, 4), (9, 6144, 512, 3)])
 def test_linear_splitk(ops, dtype, M, N, K, s):
     """Split-K projection: the slices summed in order == F.linear with fp32 accumulation (both tilings: all rows in one tile up to 192 rows,
     64x64 beyond), ragged M / N / K tails, strided A, deterministic; with dl_add_rmsnorm_parts == library GEMM + dl_add_rmsnorm up to rounding."""
