@@ -252,6 +252,45 @@ def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
         assert err < tol, f"row {b} len {lens[b]}: max err {err} > {tol}"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n_splits", [1, 8, 32])
+def test_attn_at_max_context(ops, dtype, n_splits):
+    """Maximum sizes: LLaVA-1.5's max_position_embeddings = 4096.  Decode attention over 4095 cached keys + the new one (next to a short and an
+    EMPTY row of the same batch), and the causal prefill attention of one 4096-token row (the software-pipelined kernel's longest K/V loop),
+    both against an fp32 SDPA of the same 16-bit inputs."""
+    nH, nKV, d, T_cap = 4, 2, 128, 4096
+    g = torch.Generator().manual_seed(23)
+    kv_len = [4095, 0, 2049, 63]
+    B = len(kv_len)
+    k_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    v_slab = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    q = torch.randn(B, nH * d, generator=g).to(dtype)
+    out = torch.full((B, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ws = ops.attn_decode_workspace(B, nH, d, n_splits, "cuda")
+    ops.attn_decode(q.cuda(), k_slab.cuda(), v_slab.cuda(), torch.tensor(kv_len, dtype=torch.int32).cuda(), 1, out, ws, n_splits, nH, nKV, d)
+    out = out.cpu().float().view(B, nH, d)
+    assert torch.isfinite(out).all()
+    for b in range(B):
+        T = kv_len[b] + 1
+        ref = _sdpa_ref(q[b].view(1, nH, d), k_slab[b, :, :T].transpose(0, 1), v_slab[b, :, :T].transpose(0, 1), False)[0]
+        err = float((out[b] - ref).abs().max())
+        assert err < 3 * ULP[dtype], f"decode row {b} T={T}: max err {err}"
+    if n_splits != 1:
+        return  # the prefill half does not depend on the split factor
+    L = 4096
+    W = (nH + 2 * nKV) * d
+    qkv = torch.randn(L, W, generator=g).to(dtype)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    dev = qkv.cuda()
+    o = torch.full((L, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_prefill(dev[:, : nH * d], dev[:, nH * d : (nH + nKV) * d], dev[:, (nH + nKV) * d :], o, cu.cuda(), L, nH, nKV, d, True)
+    o = o.cpu().float().view(L, nH, d)
+    ref = _sdpa_ref(qkv[:, : nH * d].view(-1, nH, d), qkv[:, nH * d : (nH + nKV) * d].view(-1, nKV, d), qkv[:, (nH + nKV) * d :].view(-1, nKV, d), True)
+    assert torch.isfinite(o).all()
+    err = float((o - ref).abs().max())
+    assert err < 6 * ULP[dtype], f"prefill L={L}: max err {err}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("nH,nKV,d", [(32, 32, 128), (8, 2, 128), (4, 4, 64)])
 @pytest.mark.parametrize("n_splits", [1, 4, 32])
