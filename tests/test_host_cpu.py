@@ -224,3 +224,26 @@ def test_width_bucket_rule():
     assert len({m._width_bucket(W, n_feat) for W in range(44, 101)}) == 5  # the eval stream's 57 widths (35 + 1 + U[8,64]) share five graphs
     m.prefill_width_bucket = 0
     assert all(m._width_bucket(W, n_feat) == W for W in (3, 57, 100))
+
+
+def test_profile_tools_name_kernels_the_library_really_contains():
+    """The evidence under profiles/ is produced by tools that pick dispatches BY KERNEL NAME (tools/pmc_report.py chunks the probe's main
+    launches; bench.py names the dominant kernel): a kernel that was renamed or replaced (round 4: down_proj moved to
+    gemv_b1_plain_halves_kernel and the PMC report silently lost a case) must fail here, not on the GPU box."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = open(os.path.join(root, "dynamic_llava_amd", "libdynllava_hip.so"), "rb").read()
+    src = open(os.path.join(root, "tools", "pmc_report.py")).read()
+    m = re.search(r"for k in \(([^)]*)\)", src)
+    assert m, "pmc_report.py: kernel filter not found"
+    names = re.findall(r'"([a-z0-9_]+)"', m.group(1))
+    assert len(names) >= 6
+    for n in names:
+        assert n.encode() in blob, f"tools/pmc_report.py filters on `{n}`, which is not a kernel of the built library"
+    # every weight-streaming kernel the batch-1 decode step can launch is covered by that filter
+    for n in ("gemv_kernel", "gemv_b1_plain_kernel", "gemv_b1_plain_halves_kernel", "gemv_qkv_attn_kernel", "gemv_gu_tp_kernel"):
+        assert n in names and n.encode() in blob
+    probe = open(os.path.join(root, "tools", "pmc_probe.py")).read()
+    for n in set(re.findall(r'"kernel": "([a-z0-9_]+)"', probe)):
+        assert n.encode() in blob, f"tools/pmc_probe.py plans a case on `{n}`, which is not a kernel of the built library"
