@@ -829,9 +829,9 @@ static int attn_prefill_impl(const char* who, const void* q, const void* k, cons
                              void* out, int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen, int max_kv_len, int n_heads,
                              int n_kv_heads, int head_dim, int causal, int dtype, void* stream, const int32_t* kv_len, int64_t kv_sb,
                              int64_t kv_sh) {
-  DL_REQUIRE(q && k && v && out && cu_seqlens, "%s: NULL pointer", who);
   DL_REQUIRE(B > 0 && max_seqlen >= 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "%s: bad shape", who);
-  if (max_seqlen == 0) return DL_OK;
+  if (max_seqlen == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(q && k && v && out && cu_seqlens, "%s: NULL pointer", who);
   hipStream_t st = as_stream(stream);
   const int n_rep = n_heads / n_kv_heads;
   if (dtype == DL_F32) {

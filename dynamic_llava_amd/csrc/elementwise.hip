@@ -269,9 +269,9 @@ __global__ __launch_bounds__(kThreads) void silu_mul_parts_kernel(const float* _
 using namespace dl;
 
 extern "C" int dl_rmsnorm(const void* x, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream) {
-  DL_REQUIRE(x && w && out, "dl_rmsnorm: NULL pointer");
   DL_REQUIRE(rows >= 0 && H > 0, "dl_rmsnorm: bad shape rows=%lld H=%d", (long long)rows, H);
-  if (rows == 0) return DL_OK;
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(x && w && out, "dl_rmsnorm: NULL pointer");
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_rmsnorm: unsupported H=%d", H);
     hipLaunchKernelGGL((rmsnorm_kernel<T, 0>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), const_cast<void*>(x),
@@ -283,10 +283,10 @@ extern "C" int dl_rmsnorm(const void* x, const void* w, void* out, int64_t rows,
 
 extern "C" int dl_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t rows, int H, float eps, int dtype,
                               void* stream) {
+  DL_REQUIRE(rows >= 0 && H > 0, "dl_add_rmsnorm: bad shape");
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
   DL_REQUIRE(h && delta, "dl_add_rmsnorm: NULL pointer");
   DL_REQUIRE((w == nullptr) == (out == nullptr), "dl_add_rmsnorm: w and out must both be given or both be NULL");
-  DL_REQUIRE(rows >= 0 && H > 0, "dl_add_rmsnorm: bad shape");
-  if (rows == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm: unsupported H=%d", H);
     hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, delta, w, out, H,
@@ -298,10 +298,10 @@ extern "C" int dl_add_rmsnorm(void* h, const void* delta, const void* w, void* o
 
 extern "C" int dl_add_rmsnorm_parts(void* h, const float* parts, int n_slices, const void* w, void* out, int64_t rows, int H, float eps,
                                     int dtype, void* stream) {
+  DL_REQUIRE(rows >= 0 && H > 0 && ((uintptr_t)parts & 15) == 0, "dl_add_rmsnorm_parts: bad shape / alignment");
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
   DL_REQUIRE(h && parts && n_slices >= 1, "dl_add_rmsnorm_parts: bad arguments");
   DL_REQUIRE((w == nullptr) == (out == nullptr), "dl_add_rmsnorm_parts: w and out must both be given or both be NULL");
-  DL_REQUIRE(rows >= 0 && H > 0 && ((uintptr_t)parts & 15) == 0, "dl_add_rmsnorm_parts: bad shape / alignment");
-  if (rows == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H % 4 == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm_parts: unsupported H=%d", H);
     hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, parts, w, out, H, eps, n_slices,
@@ -313,9 +313,9 @@ extern "C" int dl_add_rmsnorm_parts(void* h, const float* parts, int n_slices, c
 
 extern "C" int dl_layernorm(const void* x, const int32_t* row_index, const void* w, const void* b, void* out, int64_t rows, int H,
                             float eps, int dtype, void* stream) {
-  DL_REQUIRE(x && w && b && out, "dl_layernorm: NULL pointer");
   DL_REQUIRE(rows >= 0 && H > 0, "dl_layernorm: bad shape");
-  if (rows == 0) return DL_OK;
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(x && w && b && out, "dl_layernorm: NULL pointer");
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_layernorm: unsupported H=%d", H);
     hipLaunchKernelGGL((layernorm_kernel<T, false>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), x, row_index, nullptr, w,
@@ -327,10 +327,10 @@ extern "C" int dl_layernorm(const void* x, const int32_t* row_index, const void*
 
 extern "C" int dl_add_layernorm(void* h, const void* delta, const void* w, const void* b, void* out, int64_t rows, int H, float eps,
                                 int dtype, void* stream) {
+  DL_REQUIRE(rows >= 0 && H > 0, "dl_add_layernorm: bad shape");
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
   DL_REQUIRE(h && delta, "dl_add_layernorm: NULL pointer");
   DL_REQUIRE((w == nullptr) == (out == nullptr) && (w == nullptr) == (b == nullptr), "dl_add_layernorm: w, b and out must all be given or all be NULL");
-  DL_REQUIRE(rows >= 0 && H > 0, "dl_add_layernorm: bad shape");
-  if (rows == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(H % Elem<T>::kVec == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_layernorm: unsupported H=%d", H);
     hipLaunchKernelGGL((layernorm_kernel<T, true>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, nullptr, delta, w, b,
@@ -341,9 +341,9 @@ extern "C" int dl_add_layernorm(void* h, const void* delta, const void* w, const
 }
 
 extern "C" int dl_quick_gelu(const void* x, void* out, int64_t n, int dtype, void* stream) {
-  DL_REQUIRE(x && out, "dl_quick_gelu: NULL pointer");
   DL_REQUIRE(n >= 0, "dl_quick_gelu: bad size");
-  if (n == 0) return DL_OK;
+  if (n == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(x && out, "dl_quick_gelu: NULL pointer");
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(n % Elem<T>::kVec == 0, "dl_quick_gelu: n must be a multiple of %d", Elem<T>::kVec);
     const int64_t nvec = n / Elem<T>::kVec;
@@ -356,9 +356,9 @@ extern "C" int dl_quick_gelu(const void* x, void* out, int64_t n, int dtype, voi
 }
 
 extern "C" int dl_silu_mul_parts(const float* parts, int n_slices, void* out, int64_t rows, int I, int dtype, void* stream) {
-  DL_REQUIRE(parts && out && n_slices >= 1, "dl_silu_mul_parts: bad arguments");
   DL_REQUIRE(rows >= 0 && I > 0 && I % 4 == 0 && ((uintptr_t)parts & 15) == 0, "dl_silu_mul_parts: bad shape / alignment");
-  if (rows == 0) return DL_OK;
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(parts && out && n_slices >= 1, "dl_silu_mul_parts: bad arguments");
   DL_DISPATCH_DTYPE(dtype, T, {
     const int64_t total = rows * (I / 4);
     const int64_t blocks = (total + kThreads - 1) / kThreads;
@@ -370,9 +370,9 @@ extern "C" int dl_silu_mul_parts(const float* parts, int n_slices, void* out, in
 }
 
 extern "C" int dl_silu_mul(const void* gate_up, void* out, int64_t rows, int I, int dtype, void* stream) {
-  DL_REQUIRE(gate_up && out, "dl_silu_mul: NULL pointer");
   DL_REQUIRE(rows >= 0 && I > 0, "dl_silu_mul: bad shape");
-  if (rows == 0) return DL_OK;
+  if (rows == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(gate_up && out, "dl_silu_mul: NULL pointer");
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(I % Elem<T>::kVec == 0, "dl_silu_mul: I=%d must be a multiple of %d", I, Elem<T>::kVec);
     const int64_t total = rows * (I / Elem<T>::kVec);

@@ -391,11 +391,11 @@ extern "C" int dl_linear_splitk(const void* A, int64_t lda, const void* W, float
 
 extern "C" int dl_linear(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, const void* R, int64_t ldr,
                          int M, int N, int K, int flags, int dtype, void* stream) {
-  DL_REQUIRE(A && W && C, "dl_linear: NULL pointer");
   DL_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0, "dl_linear: bad shape M=%d N=%d K=%d lda=%lld", M, N, K, (long long)lda);
-  DL_REQUIRE(!(flags & DL_EPI_RESIDUAL) || R, "dl_linear: residual requested but R is NULL");
   DL_REQUIRE(dtype == DL_F32 || dtype == DL_F16 || dtype == DL_BF16, "dl_linear: unsupported dtype %d", dtype);
-  if (M == 0) return DL_OK;
+  if (M == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
+  DL_REQUIRE(A && W && C, "dl_linear: NULL pointer");
+  DL_REQUIRE(!(flags & DL_EPI_RESIDUAL) || R, "dl_linear: residual requested but R is NULL");
   linear_launch(A, lda, W, bias, C, ldc, R, ldr, M, N, K, flags, dtype, as_stream(stream));
   DL_CHECK_LAUNCH("dl_linear");
   return DL_OK;

@@ -88,10 +88,10 @@ extern "C" int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_
                                 const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base, void* k_slab, void* v_slab,
                                 int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, int B, int total, int n_heads,
                                 int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(B > 0 && total >= 0 && n_heads > 0 && n_kv_heads > 0 && n_pos > 0, "dl_rope_kv_write: bad shape");
+  if (total == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
   DL_REQUIRE(qkv && cos_tab && sin_tab && cu_seqlens && kv_base && k_slab && v_slab, "dl_rope_kv_write: NULL pointer");
   DL_REQUIRE(pos || pos_base, "dl_rope_kv_write: one of pos / pos_base is required");
-  DL_REQUIRE(B > 0 && total >= 0 && n_heads > 0 && n_kv_heads > 0 && n_pos > 0, "dl_rope_kv_write: bad shape");
-  if (total == 0) return DL_OK;
   DL_DISPATCH_DTYPE(dtype, T, {
     DL_REQUIRE(head_dim > 0 && (head_dim / 2) % Elem<T>::kVec == 0, "dl_rope_kv_write: head_dim=%d unsupported", head_dim);
     const int items = (n_heads + n_kv_heads) * (head_dim / 2 / Elem<T>::kVec) + n_kv_heads * (head_dim / Elem<T>::kVec);

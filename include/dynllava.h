@@ -16,6 +16,9 @@
  *     calls are hipGraph-capturable.  The caller owns every buffer including workspaces.
  *   - return value: 0 = enqueued, <0 = DL_ERR_* (nothing was enqueued); dl_last_error() returns a
  *     thread-local message for the last failing call on this host thread.
+ *   - empty inputs: the row kernels, dl_linear, dl_rope_kv_write and dl_attn_prefill{,_cached} return DL_OK without enqueueing anything
+ *     when their row / token count (rows, n, M, total, max_seqlen) is 0 -- also when the data pointers of such an empty buffer are
+ *     NULL (an empty torch tensor has no storage), as the eager ops they replace are no-ops on empty tensors.
  *   - "packed varlen": B sequences concatenated along the token axis, row b = tokens
  *     [cu_seqlens[b], cu_seqlens[b+1]); cu_seqlens is int32[B+1] on the device.
  *   - KV slab layout (one K and one V slab per layer): [B][n_kv_heads][T_cap][head_dim], element

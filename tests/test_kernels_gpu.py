@@ -252,6 +252,34 @@ def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
         assert err < tol, f"row {b} len {lens[b]}: max err {err} > {tol}"
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_empty_inputs_are_no_ops(ops, dtype):
+    """Empty inputs (zero rows / tokens; an empty torch tensor has a NULL data pointer): every row kernel, dl_linear, dl_rope_kv_write and
+    dl_attn_prefill return DL_OK and touch nothing, like the eager ops they replace; a NEGATIVE count is still an argument error."""
+    H, I, nH, d = 256, 512, 2, 128
+    e = lambda *shape: torch.empty(*shape, dtype=dtype, device="cuda")
+    w, b = torch.ones(H, dtype=dtype, device="cuda"), torch.zeros(H, dtype=dtype, device="cuda")
+    assert ops.rmsnorm(e(0, H), w, 1e-5).shape == (0, H)
+    assert ops.add_rmsnorm(e(0, H), e(0, H), w, 1e-5).shape == (0, H)
+    assert ops.layernorm(e(0, H), w, b, 1e-5).shape == (0, H)
+    assert ops.silu_mul(e(0, 2 * I)).shape == (0, I)
+    assert ops.quick_gelu(e(0, H)).shape == (0, H)
+    assert ops.linear(e(0, H), torch.ones(I, H, dtype=dtype, device="cuda")).shape == (0, I)
+    cu = torch.zeros(2, dtype=torch.int32, device="cuda")
+    zeros_b = torch.zeros(1, dtype=torch.int32, device="cuda")
+    k_slab = torch.full((1, nH, 8, d), 7.0, dtype=dtype, device="cuda")
+    v_slab = k_slab.clone()
+    cos, sin = torch.ones(16, d, dtype=dtype, device="cuda"), torch.zeros(16, d, dtype=dtype, device="cuda")
+    ops.rope_kv_write(e(0, 3 * nH * d), cos, sin, cu, None, zeros_b, zeros_b, k_slab, v_slab, nH, nH, d)
+    assert bool((k_slab == 7.0).all()) and bool((v_slab == 7.0).all())
+    qkv = e(0, 3 * nH * d)
+    out = e(0, nH * d)
+    ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : 2 * nH * d], qkv[:, 2 * nH * d :], out, cu, 0, nH, nH, d, True)
+    torch.cuda.synchronize()
+    rc = ops.lib().dl_rmsnorm(None, None, None, -1, H, 1e-5, ops.dtype_code(dtype), None)
+    assert rc != 0 and b"bad shape" in ops.lib().dl_last_error()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n_splits", [1, 8, 32])
 def test_attn_at_max_context(ops, dtype, n_splits):
