@@ -39,6 +39,23 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ach
 N_SYS, N_Q, N_IMG = 35, 20, 576
 
 
+METRIC = "prefill+decode tokens/s/GPU, LLaVA-1.5-7B @ vision_keep_rate=0.2, 1 img"
+
+
+class BenchAbort(Exception):
+    """A run that must not report a number.  main() turns it into ONE JSON line with an "error" key (what a driver parses), then exits non-zero."""
+
+    def __init__(self, msg, **detail):
+        super().__init__(msg)
+        self.detail = detail
+
+
+def abort_line(msg, detail, partial):
+    """The JSON line of an aborted run: same leading keys as a result line (so that a parser finds `metric` / `n_gpus`), `value` null, the reason, the
+    per-rank detail and whatever was measured before the abort."""
+    return json.dumps({"metric": METRIC, "value": None, "unit": "tokens/s", "error": msg, "detail": detail, "partial": partial})
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -455,7 +472,7 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
         if detail["rows_with_different_ids"] and detail["max_abs_prefill_logit_diff"] == 0.0:
             # identical prefill (every K/V row of every layer feeds those logits) but different tokens: the DECODE diverged between two devices
             # running the same kernels on the same data -- a bug (round 3's packed-fp32 anomaly looked exactly like this), never a rounding matter
-            raise SystemExit(f"configs[3]: rank {r}'s gathered rows differ from rank 0's re-run of the same chunk after a bit-identical prefill: {detail}")
+            raise BenchAbort(f"configs[3]: rank {r}'s gathered rows differ from rank 0's re-run of the same chunk after a bit-identical prefill", **detail)
         # a last-bit difference of the prefill logits (another device's library GEMM picked another kernel) can legitimately flip a near-tied
         # argmax later: reported in rerun_detail, not fatal
     n_tok_all = sum(35 + 576 + q for q in n_q) + n_req * new_tokens
@@ -466,6 +483,15 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
 
 def main():
     args = parse()
+    partial = {"n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "rank": int(os.environ.get("RANK", "0"))}
+    try:
+        _main(args, partial)
+    except BenchAbort as e:
+        print(abort_line(str(e), e.detail, partial), flush=True)
+        sys.exit(2)
+
+
+def _main(args, partial):
     from dynamic_llava_amd import dist as dd
     from dynamic_llava_amd.builder import build_random_model
     from dynamic_llava_amd.config import DynamicLlavaConfig
@@ -473,12 +499,23 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (the reference forks one process per GPU from a shell loop,
         # run/dynamic_eval/eval_for_vqav2.sh:11-21); rank 0 of the child job prints the JSON line on the inherited stdout
-        raise SystemExit(dd.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        try:
+            rc = dd.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        except dd.LaunchError as e:
+            raise BenchAbort(str(e), visible_gpus=(torch.cuda.device_count() if torch.cuda.is_available() else 0), gpus=args.gpus)
+        if rc != 0:  # the child job has printed its own line if it got far enough to know why; this one says that the job as a whole failed
+            raise BenchAbort(f"the {args.gpus}-rank child job exited with code {rc}", child_exit_code=rc)
+        return
     rank, world, local = dd.init_distributed()
+    partial.update(rank=rank, world_size=world, local_rank=local)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)")
+        if rank == 0:
+            raise BenchAbort(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)", world_size=world, gpus=args.gpus)
+        sys.exit(2)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    dist_view = dd.describe(device)  # backend / world size / device per rank as the process group reports them (one all_gather_object, untimed)
+    partial.update(dist=dist_view)
     dtype = torch.bfloat16
     cfg = DynamicLlavaConfig(num_hidden_layers=args.layers)  # LLaVA-1.5-7B defaults, sparse_layer=2, keep 0.2
     model = build_random_model(cfg, dtype=dtype, device=device, seed=0, predictor_gain=args.predictor_gain)
@@ -506,6 +543,7 @@ def main():
     torch.cuda.synchronize()
     dd.barrier()
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
+    partial.update(ms_per_step=round(elapsed * 1e3 / args.steps, 3), value_if_valid=round(world * (n_prompt + T_new) * args.steps / elapsed, 2))
     model.check_device_errors()  # a launch with in-kernel hand-offs that gave up would have poisoned its output: never report such a run
     end_lens = model.last_cache.lens.cpu().tolist()  # KV lengths at the end of a full step (before the pooled slab is reset)
     dp_consistent = None
@@ -518,7 +556,11 @@ def main():
         lg_mag = float(gathered["logits"][0].float().abs().max())
         dp_consistent = bool(ids_same and lg_diff == 0.0)
         if not ids_same or lg_diff > 2e-2 * max(lg_mag, 1.0):
-            raise SystemExit(f"rank {rank}: data-parallel ranks produced different results for identical requests (ids equal: {ids_same}, max logit diff {lg_diff:.3e})")
+            per_rank = [{"rank": r, "ids_equal_rank0": bool(torch.equal(gathered["ids"][0], gathered["ids"][r])), "first_new_tokens": gathered["ids"][r][:8].tolist(),
+                         "max_abs_logit_diff_vs_rank0": float((gathered["logits"][0].float() - gathered["logits"][r].float()).abs().max())} for r in range(gathered["ids"].shape[0])]
+            if rank == 0:  # every rank holds the same gathered tensors: one line, from rank 0
+                raise BenchAbort("data-parallel ranks produced different results for identical requests", ids_equal=ids_same, max_logit_diff=lg_diff, logit_magnitude=lg_mag, per_rank=per_rank)
+            sys.exit(2)
         c3 = configs3_leg(model, cfg, dd, rank, world, device, dtype)
 
     if rank != 0:
@@ -577,13 +619,13 @@ def main():
              "note": "all weights streamed by one decode step + the K/V rows its attention reads (at the final lengths), over decode_ms_per_token of the timed generate() "
                      "calls: includes every launch of the step's graph, launch boundaries and the host loop"}
     res = {
-        "metric": "prefill+decode tokens/s/GPU, LLaVA-1.5-7B @ vision_keep_rate=0.2, 1 img",
+        "metric": METRIC,
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random-init LLaVA-1.5-7B + CLIP ViT-L/14-336 weights, randn 336x336 image, random token ids)",
         "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
                                f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
-                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dp_rows_identical": dp_consistent, "dp_max_abs_logit_diff": (lg_diff if world > 1 else None), "hip_graph_decode": model.use_hip_graph,
+                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dist": dist_view, "dp_rows_identical": dp_consistent, "dp_max_abs_logit_diff": (lg_diff if world > 1 else None), "hip_graph_decode": model.use_hip_graph,
                    "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib,
                    "parity_note": "ids / kept sets / KV lengths bit-exact vs the oracle; logits: 1e-3 asserted literally in fp32, bf16 held to the reference's own "
                                   "eager-bf16 noise class against an fp32 truth (DESIGN.md section 5)"},

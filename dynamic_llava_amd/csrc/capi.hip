@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace dl
 
-extern "C" int dl_version(void) { return 1; }
+extern "C" int dl_version(void) { return DL_ABI_VERSION; }
 extern "C" const char* dl_last_error(void) { return dl::g_err; }
 extern "C" int dl_device_check(void) {
   int dev = 0;

@@ -233,6 +233,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// dl_linear_packed's activation order (include/dynllava.h, dl_pack_x_tiles): element offset of the 16-byte chunk k8 = k / 8 of `row` when the
+// matrix has n_tiles 16-row tiles -- Xp[step = k / 64][tile][k half][lane = 16 ((k % 32) / 8) + row % 16][8].  2-byte element types only.
+__device__ __forceinline__ int64_t lp_x_chunk_offset(int64_t row, int k8, int n_tiles) {
+  const int step = k8 >> 3, half = (k8 >> 2) & 1, lg = k8 & 3;
+  return ((((int64_t)step * n_tiles + (row >> 4)) * 2 + half) * 64 + lg * 16 + (row & 15)) * 8;
+}
+static inline int lp_x_tiles(int64_t rows) { return (int)((((rows + 15) / 16 + 3) / 4) * 4); }
+
 // dtype dispatch on the host
 #define DL_DISPATCH_DTYPE(dtype, T, ...)                 \
   switch (dtype) {                                       \

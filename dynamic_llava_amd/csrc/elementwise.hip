@@ -14,7 +14,7 @@ constexpr int kPartsBatch = 8;  // split-K slices whose loads are in flight toge
 template <typename T, int ADD>
 __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_, const void* __restrict__ delta_,
                                                             const void* __restrict__ w_, void* __restrict__ out_, int H,
-                                                            float eps, int n_slices = 0, int64_t slice_stride = 0) {
+                                                            float eps, int n_slices = 0, int64_t slice_stride = 0, int out_tiles = 0) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   __shared__ float red[4];
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(kThreads) void rmsnorm_kernel(void* __restrict__ h_
       load16<T>(w + v * V, wv);
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = wv[j] * Elem<T>::round(x[i][j] * rstd);  // cast, THEN weight
-      store16<T>(out + v * V, o);
+      if (out_tiles > 0)  // the consumer is dl_linear_packed: the row's chunks go where its matrix-core fragments expect them
+        store16<T>(reinterpret_cast<S*>(out_) + lp_x_chunk_offset(row, v, out_tiles), o);
+      else
+        store16<T>(out + v * V, o);
     }
   }
 }
@@ -308,6 +311,49 @@ extern "C" int dl_add_rmsnorm_parts(void* h, const float* parts, int n_slices, c
                        (int64_t)rows * H);
   });
   DL_CHECK_LAUNCH("dl_add_rmsnorm_parts");
+  return DL_OK;
+}
+
+// ---- the same three launches with the normalised rows written in dl_linear_packed's activation order (dl_pack_x_tiles): 2-byte types, H % 64 == 0 ----
+#define DL_PACKED_NORM_CHECKS(name)                                                                                                              \
+  DL_REQUIRE(rows >= 0 && rows <= 256 && H > 0 && H % 64 == 0, name ": rows=%lld (<= 256), H=%d (multiple of 64)", (long long)rows, H);          \
+  if (rows == 0) return DL_OK;                                                                                                                   \
+  DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, name ": bf16 / fp16 only");                                                                    \
+  DL_REQUIRE(w && out && ((uintptr_t)out & 15) == 0, name ": NULL / unaligned pointer")
+
+extern "C" int dl_rmsnorm_packed(const void* x, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream) {
+  DL_PACKED_NORM_CHECKS("dl_rmsnorm_packed");
+  DL_REQUIRE(x && x != out, "dl_rmsnorm_packed: x is NULL or aliases out");
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_rmsnorm_packed: unsupported H=%d", H);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, 0>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), const_cast<void*>(x), nullptr, w, out, H, eps, 0, (int64_t)0,
+                       lp_x_tiles(rows));
+  });
+  DL_CHECK_LAUNCH("dl_rmsnorm_packed");
+  return DL_OK;
+}
+
+extern "C" int dl_add_rmsnorm_packed(void* h, const void* delta, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream) {
+  DL_PACKED_NORM_CHECKS("dl_add_rmsnorm_packed");
+  DL_REQUIRE(h && delta && h != out, "dl_add_rmsnorm_packed: NULL pointer / out aliases h");
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm_packed: unsupported H=%d", H);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, delta, w, out, H, eps, 0, (int64_t)0, lp_x_tiles(rows));
+  });
+  DL_CHECK_LAUNCH("dl_add_rmsnorm_packed");
+  return DL_OK;
+}
+
+extern "C" int dl_add_rmsnorm_parts_packed(void* h, const float* parts, int n_slices, const void* w, void* out, int64_t rows, int H, float eps, int dtype,
+                                           void* stream) {
+  DL_PACKED_NORM_CHECKS("dl_add_rmsnorm_parts_packed");
+  DL_REQUIRE(h && parts && n_slices >= 1 && ((uintptr_t)parts & 15) == 0 && h != out, "dl_add_rmsnorm_parts_packed: bad arguments");
+  DL_DISPATCH_DTYPE(dtype, T, {
+    DL_REQUIRE(H % 4 == 0 && H <= kThreads * kMaxVecPerThread * Elem<T>::kVec, "dl_add_rmsnorm_parts_packed: unsupported H=%d", H);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3((unsigned)rows), dim3(kThreads), 0, as_stream(stream), h, parts, w, out, H, eps, n_slices, (int64_t)rows * H,
+                       lp_x_tiles(rows));
+  });
+  DL_CHECK_LAUNCH("dl_add_rmsnorm_parts_packed");
   return DL_OK;
 }
 

@@ -57,6 +57,24 @@ def init_distributed(backend: str | None = None, force: bool = False):
     return rank, world, local
 
 
+class LaunchError(RuntimeError):
+    """self_launch cannot start the ranks it was asked for (fewer visible GPUs than ranks and no test hook)."""
+
+
+def describe(device=None) -> dict:
+    """What the process group looks like FROM the collective library's side, for the bench line's `config`: backend, world size
+    and, per rank, the device it drives -- gathered with one all_gather_object outside any timed region.  World size 1 without a group: a stub."""
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+          "device": (str(device) if device is not None else None),
+          "device_name": (torch.cuda.get_device_name(device) if device is not None and torch.cuda.is_available() else None)}
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "ranks": [me]}
+    ranks = [None] * dist.get_world_size()
+    dist.all_gather_object(ranks, me)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+            "distinct_devices": len({(r["device"]) for r in ranks}), "collective": "one all_gather_into_tensor per request batch (gather_results)"}
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -72,8 +90,8 @@ def self_launch(script: str, argv: Sequence[str], n_procs: int) -> int:
     env = dict(os.environ)
     if n_dev < n_procs:
         if "DL_FORCE_DEVICE" not in env:
-            raise SystemExit(f"--gpus {n_procs} but only {n_dev} visible GPU(s): one rank per GPU is the contract (set DL_FORCE_DEVICE=<dev> to put "
-                             f"every rank on one device over gloo -- a functional test hook, not a measurement)")
+            raise LaunchError(f"--gpus {n_procs} but only {n_dev} visible GPU(s): one rank per GPU is the contract (set DL_FORCE_DEVICE=<dev> to put "
+                              f"every rank on one device over gloo -- a functional test hook, not a measurement)")
         env.setdefault("DL_DIST_BACKEND", "gloo")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_procs) // n_procs)))

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdynllava_hip.so")
 
 DL_F32, DL_F16, DL_BF16 = 0, 1, 2
+ABI_VERSION = 3  # include/dynllava.h DL_ABI_VERSION: a library built from another header is refused at load
 EPI_GELU, EPI_RESIDUAL = 1, 2
 _DTYPES = {torch.float32: DL_F32, torch.float16: DL_F16, torch.bfloat16: DL_BF16}
 
@@ -106,6 +107,15 @@ SIGNATURES = {
     "dl_silu_mul_parts": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dl_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "dl_quick_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "dl_rmsnorm_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_add_rmsnorm_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_add_rmsnorm_parts_packed": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "dl_packed_weight_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dl_pack_weight_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_packed_x_bytes": (c_int64, [c_int, c_int]),
+    "dl_pack_x_tiles": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dl_linear_packed_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dl_linear_packed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
@@ -130,6 +140,8 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.dl_version() != ABI_VERSION:  # argument lists changed between versions: a stale .so would read pointers as integers
+        raise HipOpsError(f"{path} reports ABI version {lib.dl_version()}, this binding is written for {ABI_VERSION}: rebuild (`__graft_entry__.build()`)")
     _lib = lib
     return lib
 
@@ -176,20 +188,41 @@ def _dev(t, *more):
 # ------------------------------------------------------------------------------------------------
 # thin op wrappers (shapes documented in include/dynllava.h)
 # ------------------------------------------------------------------------------------------------
-def rmsnorm(x, w, eps, out=None):
+def _packed_out(rows, H, like, out):
+    """Flat buffer for a [rows, H] activation in dl_linear_packed's fragment order (pack_x_tiles / the *_packed norm launches)."""
+    need = int(lib().dl_packed_x_bytes(rows, H))
+    if need < 0:
+        raise HipOpsError(f"packed activations: unsupported shape [{rows},{H}] (rows <= 256, H % 64 == 0)")
+    if out is None:
+        out = torch.empty(need // like.element_size(), dtype=like.dtype, device=like.device)
+    assert out.is_contiguous() and out.dtype == like.dtype and out.numel() * out.element_size() >= need
+    return out
+
+
+def rmsnorm(x, w, eps, out=None, packed=False):
+    """packed: the result goes out in dl_linear_packed's activation order (a flat tensor; feed it with x_packed_mk=(rows, H))."""
     _dev(x, w)
     assert x.is_contiguous() and x.dtype == w.dtype
     H = x.shape[-1]
+    if packed:
+        out = _packed_out(x.numel() // H, H, x, out)
+        _check(lib().dl_rmsnorm_packed(_p(x), _p(w), _p(out), x.numel() // H, H, eps, dtype_code(x.dtype), _stream()), "dl_rmsnorm_packed")
+        return out
     out = torch.empty_like(x) if out is None else out
     _check(lib().dl_rmsnorm(_p(x), _p(w), _p(out), x.numel() // H, H, eps, dtype_code(x.dtype), _stream()), "dl_rmsnorm")
     return out
 
 
-def add_rmsnorm(h, delta, w, eps, out=None):
-    """h += delta (in place, rounded); returns rmsnorm(h) (or None when w is None)."""
+def add_rmsnorm(h, delta, w, eps, out=None, packed=False):
+    """h += delta (in place, rounded); returns rmsnorm(h) (or None when w is None).  packed: see rmsnorm."""
     _dev(h, delta, w)
     assert h.is_contiguous() and delta.is_contiguous() and h.shape == delta.shape and h.dtype == delta.dtype
     H = h.shape[-1]
+    if packed:
+        assert w is not None
+        out = _packed_out(h.numel() // H, H, h, out)
+        _check(lib().dl_add_rmsnorm_packed(_p(h), _p(delta), _p(w), _p(out), h.numel() // H, H, eps, dtype_code(h.dtype), _stream()), "dl_add_rmsnorm_packed")
+        return out
     if w is not None and out is None:
         out = torch.empty_like(h)
     _check(lib().dl_add_rmsnorm(_p(h), _p(delta), _p(w), _p(out) if w is not None else None, h.numel() // H, H, eps, dtype_code(h.dtype), _stream()), "dl_add_rmsnorm")
@@ -576,6 +609,86 @@ def linear_splitk(a, w, parts, n_slices):
     return parts[: n_slices * M * N].view(n_slices, M, N)
 
 
+LP_STORE, LP_SILU_PAIR, LP_RESID = 0, 1, 2
+LP_MAX_ROWS = 256
+
+
+def linear_packed_ok(M, N, K, dtype):
+    """Shapes dl_linear_packed takes."""
+    return dtype in (torch.bfloat16, torch.float16) and 0 < M <= LP_MAX_ROWS and N % 16 == 0 and K % 64 == 0
+
+
+def pack_weight_tiles(w, gate_up_pairs=False, out=None):
+    """Copy of w [N,K] (nn.Linear layout) in matrix-core operand order for linear_packed (include/dynllava.h).  gate_up_pairs: w = [gate; up],
+    gate / up tiles interleaved for the SiLU * up epilogue."""
+    _dev(w, out)
+    assert w.dim() == 2 and w.is_contiguous()
+    N, K = w.shape
+    need = int(lib().dl_packed_weight_bytes(N, K, dtype_code(w.dtype)))
+    if need < 0:
+        raise HipOpsError(f"dl_pack_weight_tiles: unsupported shape / dtype [{N},{K}] {w.dtype}")
+    if out is None:
+        out = torch.empty(N * K, dtype=w.dtype, device=w.device)
+    assert out.numel() * out.element_size() >= need and out.is_contiguous()
+    _check(lib().dl_pack_weight_tiles(_p(w), _p(out), N, K, int(bool(gate_up_pairs)), dtype_code(w.dtype), _stream()), "dl_pack_weight_tiles")
+    return out
+
+
+def pack_x_tiles(x, out=None):
+    """x [M,K] in dl_linear_packed's fragment order (include/dynllava.h); returns a flat tensor."""
+    _dev(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    need = int(lib().dl_packed_x_bytes(M, K))
+    if need < 0:
+        raise HipOpsError(f"dl_pack_x_tiles: unsupported shape [{M},{K}]")
+    if out is None:
+        out = torch.empty(need // x.element_size(), dtype=x.dtype, device=x.device)
+    assert out.numel() * out.element_size() >= need and out.is_contiguous()
+    _check(lib().dl_pack_x_tiles(_p(x), x.stride(0), _p(out), M, K, dtype_code(x.dtype), _stream()), "dl_pack_x_tiles")
+    return out
+
+
+def linear_packed_workspace(M, N, K, device, epilogue=LP_STORE, units_per_workgroup=0, k_split=1):
+    """Zeroed hand-over workspace of a k_split > 1 call (flag words + fp32 tiles); None for k_split == 1.  One workspace serves every call that needs
+    at most its size (calls in one stream run one after the other and leave the flag words zero)."""
+    need = int(lib().dl_linear_packed_workspace_bytes(M, N, K, int(epilogue), int(units_per_workgroup), int(k_split)))
+    if need < 0:
+        raise HipOpsError(f"dl_linear_packed_workspace_bytes: unsupported shape / split M={M} N={N} K={K} k_split={k_split}")
+    return torch.zeros(max(need, 256), dtype=torch.uint8, device=device) if need else None
+
+
+def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_workgroup=0, k_split=1, workspace=None, err=None, x_packed_mk=None, _ablate=0):
+    """out = x [M,K] @ W^T on the packed copy wp of W [N,K] (pack_weight_tiles).  epilogue LP_SILU_PAIR: out [M, N/2] = silu(gate) * up
+    (wp packed with gate_up_pairs); LP_RESID: out = resid + x W^T (resid may be out).  x_packed_mk=(M, K): x is pack_x_tiles' output.
+    k_split > 1: that many workgroups share each unit set's k range (linear_packed_workspace)."""
+    _dev(x, wp, out, resid, workspace, err)
+    if x_packed_mk is None:
+        assert x.dim() == 2 and x.stride(1) == 1
+        M, K = x.shape
+        ldx = x.stride(0)
+    else:
+        M, K = x_packed_mk
+        ldx = K
+        assert x.is_contiguous() and x.numel() * x.element_size() >= int(lib().dl_packed_x_bytes(M, K))
+    assert wp.numel() == N * K and wp.dtype == x.dtype
+    n_out = N // 2 if epilogue == LP_SILU_PAIR else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    assert out.dim() == 2 and out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == x.dtype
+    if epilogue == LP_RESID:
+        assert resid is not None and resid.shape == (M, N) and resid.stride(1) == 1 and resid.dtype == x.dtype
+    if k_split > 1:
+        need = int(lib().dl_linear_packed_workspace_bytes(M, N, K, int(epilogue), int(units_per_workgroup), int(k_split)))
+        assert workspace is not None and workspace.numel() * workspace.element_size() >= need, "linear_packed: workspace missing / too small"
+    _check(
+        lib().dl_linear_packed(_p(x), ldx, int(x_packed_mk is not None), _p(wp), _p(out), out.stride(0), _p(resid), 0 if resid is None else resid.stride(0), M, N, K,
+                               int(epilogue) | (int(_ablate) << 8), int(units_per_workgroup), int(k_split), _p(workspace), _p(err), dtype_code(x.dtype), _stream()),
+        "dl_linear_packed",
+    )
+    return out
+
+
 def gemm_smallm_ok(M, N, K, dtype):
     """Shapes dl_gemm_smallm takes (callers use the library GEMM otherwise)."""
     return dtype in (torch.bfloat16, torch.float16) and 0 < M <= 32 and K % 256 == 0 and N % 4 == 0
@@ -617,11 +730,16 @@ def gemm_smallm_parts(x, w, workspace, n_slices=0, variant=0):
     return workspace[: s * M * N].view(s, M, N), s
 
 
-def add_rmsnorm_parts(h, parts, w=None, eps=1e-6, out=None):
-    """h += cast(sum_s parts[s]) in place, then RMSNorm(h) * w -> out (w None: the add only).  parts: [slices, rows, H] fp32."""
+def add_rmsnorm_parts(h, parts, w=None, eps=1e-6, out=None, packed=False):
+    """h += cast(sum_s parts[s]) in place, then RMSNorm(h) * w -> out (w None: the add only).  parts: [slices, rows, H] fp32.  packed: see rmsnorm."""
     _dev(h, parts, w, out)
     assert h.is_contiguous() and parts.is_contiguous() and parts.dtype == torch.float32 and parts.shape[1:] == h.shape
     rows, H = h.shape
+    if packed:
+        assert w is not None
+        out = _packed_out(rows, H, h, out)
+        _check(lib().dl_add_rmsnorm_parts_packed(_p(h), _p(parts), parts.shape[0], _p(w), _p(out), rows, H, eps, dtype_code(h.dtype), _stream()), "dl_add_rmsnorm_parts_packed")
+        return out
     if w is not None and out is None:
         out = torch.empty_like(h)
     _check(lib().dl_add_rmsnorm_parts(_p(h), _p(parts), parts.shape[0], _p(w), _p(out) if w is not None else None, rows, H, eps, dtype_code(h.dtype), _stream()), "dl_add_rmsnorm_parts")

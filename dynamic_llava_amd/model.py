@@ -84,8 +84,12 @@ class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-123
         self.post_attention_layernorm = _Norm(cfg.hidden_size)
         self.w_qkv = None  # fused [nH*d + 2*nKV*d, H]; q/k/v_proj.weight become views of it (no extra memory)
         self.w_gu = None  # fused [2*I, H]
+        # round 5: second copies of the two wide projections in matrix-core operand order for dl_linear_packed (the prefill GEMMs at <= 256 packed
+        # rows); gate|up with gate / up tiles interleaved for the SiLU * up epilogue.  +281 MB per 7B layer of 288 GB; the state dict is untouched.
+        self.wp_qkv = None
+        self.wp_gu = None
 
-    def pack(self):
+    def pack(self, operand_copies: bool = False):
         a, m = self.self_attn, self.mlp
         self.w_qkv = torch.cat([a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data], dim=0).contiguous()
         nq, nk = a.q_proj.weight.shape[0], a.k_proj.weight.shape[0]
@@ -96,6 +100,10 @@ class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-123
         I = m.gate_proj.weight.shape[0]
         m.gate_proj.weight.data = self.w_gu[:I]
         m.up_proj.weight.data = self.w_gu[I:]
+        self.wp_qkv = self.wp_gu = None
+        if operand_copies and self.w_qkv.dtype in (torch.bfloat16, torch.float16) and self.w_qkv.shape[1] % 64 == 0 and self.w_qkv.shape[0] % 16 == 0 and I % 16 == 0:
+            self.wp_qkv = ops.pack_weight_tiles(self.w_qkv)
+            self.wp_gu = ops.pack_weight_tiles(self.w_gu, gate_up_pairs=True)
 
 
 class _TransformerBlock(nn.Module):  # custom_transformer_layer.py:276-318 (parameters only)
@@ -456,6 +464,12 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
         # 9.35 -> 9.17 ms (A/B on one box); DL_SPLITK_O=0 restores the library GEMM
         self.splitk_o_proj = os.environ.get("DL_SPLITK_O", "1") == "1"
+        # round 5: q|k|v and gate|up (+ SiLU * up) of prefill layers with <= 256 packed rows on dl_linear_packed (operand-order weight copies made by
+        # finalize(), activations handed over in fragment order by the norm launch that produces them).  tools/bench_linear_packed.py, M = 170:
+        # q|k|v 36.2 us (two k ranges per unit set) vs the library's 41.4, gate|up + SiLU * up 57.2 vs 64.1.  DL_PACKED_GEMM=0: library GEMMs.
+        self.packed_prefill_gemm = os.environ.get("DL_PACKED_GEMM", "1") == "1"
+        self._lp_ws = None   # hand-over workspace of the k-split launches (zeroed once; the kernel leaves its flag words zero)
+        self._lp_err = None  # bit 3: a reducing wave of dl_linear_packed gave up waiting
         # split-K slices of the two WIDE projections (q|k|v, gate|up: 768 / 1376 sixteen-neuron wave tiles without any split) on dl_gemm_smallm; 0 = the
         # kernel's own choice (8 / 4).  Round 4 measured the review's proposal -- fewer slices, so the consumers re-read fewer fp32 partial slabs --
         # and it LOSES at every batch: 2 slices 4.09 / 4.39 / 4.65 / 4.94 ms per step at B = 8 / 16 / 24 / 32 against 3.71 / 4.04 / 4.60 / 4.87 (library
@@ -497,7 +511,19 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if self.device.type != "cuda":
             raise ops.HipOpsError("the model must live on the GPU (no CPU path exists)")
         for l in self.model.layers:
-            l.pack()
+            l.pack(operand_copies=self.packed_prefill_gemm)  # (weights replaced later: call finalize() again -- the operand-order copies are made here)
+        self._lp_err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._lp_ws = None
+        if any(l.wp_qkv is not None for l in self.model.layers):
+            # hand-over workspace of the k-split launches, sized for the largest call this model makes (256 rows, the wider of the two projections);
+            # allocated HERE, once: a captured prefill must never allocate it
+            cfg = self.config
+            need = 256
+            for n_, pr in (((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim, False), (2 * cfg.intermediate_size, True)):
+                nu_, ks_ = self._lp_config(n_ // 16, pr)
+                ws_ = ops.linear_packed_workspace(256, n_, cfg.hidden_size, self.device, ops.LP_SILU_PAIR if pr else ops.LP_STORE, nu_, ks_)
+                need = max(need, 0 if ws_ is None else ws_.numel())
+            self._lp_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         if self.get_vision_tower() is not None:
             self.get_vision_tower().pack()
         self._packed = True
@@ -761,7 +787,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         elif h.data_ptr() == embeds.data_ptr():
             h = h.clone()  # the residual stream is updated in place; never touch the caller's tensor
         rec = self.debug_records
-        x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps)
+        # dl_linear_packed for q|k|v and gate|up of the layers whose packed row count fits its one tile (<= 256 rows: the post-compaction layers of a
+        # B = 1 request).  `x_pk`: x is in fragment order (written that way by the norm launch that produced it).
+        lp_ok = lambda rows_, layer_: (self.packed_prefill_gemm and layer_.wp_qkv is not None and 0 < rows_ <= ops.LP_MAX_ROWS and dt in (torch.bfloat16, torch.float16))
+        x_pk = lp_ok(total, self.model.layers[0]) and not (SL == 0 and (vision_on or p["instruct_on"] or p["nocache"]))
+        x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps, packed=x_pk)
         for i, layer in enumerate(self.model.layers):
             if i == SL and vision_on:
                 # ---- F1..F5: predictor -> top-k -> compaction (DML:1826-1994) on the un-normed residual stream ----
@@ -853,29 +883,39 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 p["nocache_lens"] = [L_new] * B
                 if rec is not None:
                     rec.update(position_ids=pos, cu_after=cu)
+            use_lp = lp_ok(total, layer)
             if i == SL and vision_on and not p["instruct_on"] and not p["nocache"]:
-                x = x_fused
+                # (the compaction launch normalises the rows it moves; for the packed GEMM they are normalised again into fragment order: one ~5 us
+                # launch at one layer buys that layer's two GEMMs)
+                x, x_pk = (ops.rmsnorm(h, layer.input_layernorm.weight, eps, packed=True), True) if use_lp else (x_fused, False)
             elif i == SL and (vision_on or p["instruct_on"] or p["nocache"]):
-                x = ops.rmsnorm(h, layer.input_layernorm.weight, eps)
-            qkv = F.linear(x, layer.w_qkv)
+                x_pk = use_lp
+                x = ops.rmsnorm(h, layer.input_layernorm.weight, eps, packed=x_pk)
+            use_lp = use_lp and x_pk
+            qkv = self._lp_linear(x, total, layer.wp_qkv, layer.w_qkv.shape[0], h.shape[1]) if use_lp else F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
             attn = torch.empty((total, nH * d), dtype=dt, device=dev)
             ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : (nH + nKV) * d], qkv[:, (nH + nKV) * d :], attn, cu, max_len, nH, nKV, d, True)
             if self.splitk_o_proj and dt in (torch.bfloat16, torch.float16) and attn.shape[0] <= 192 and attn.shape[1] >= 1024 and attn.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
-                x = ops.add_rmsnorm_parts(h, ops.linear_splitk(attn, layer.self_attn.o_proj.weight, self._splitk_ws(h.shape[1]), 8), layer.post_attention_layernorm.weight, eps)
+                x = ops.add_rmsnorm_parts(h, ops.linear_splitk(attn, layer.self_attn.o_proj.weight, self._splitk_ws(h.shape[1]), 8), layer.post_attention_layernorm.weight, eps, packed=use_lp)
             else:
                 o = F.linear(attn, layer.self_attn.o_proj.weight)
-                x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
-            act = ops.silu_mul(F.linear(x, layer.w_gu))
+                x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps, packed=use_lp)
+            if use_lp:  # gate|up with silu(gate) * up in the epilogue: one launch, no [rows, 2 I] round trip
+                act = self._lp_linear(x, total, layer.wp_gu, layer.w_gu.shape[0], h.shape[1], ops.LP_SILU_PAIR)
+            else:
+                act = ops.silu_mul(F.linear(x, layer.w_gu))
             nw_next = self.model.norm.weight if i + 1 == L else (None if i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"])  # residual add only: layer SL's norm runs after compaction
                                                                else self.model.layers[i + 1].input_layernorm.weight)
+            pk_next = nw_next is not None and i + 1 < L and lp_ok(total, self.model.layers[i + 1])  # the next layer's q|k|v reads this norm's output
             if dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024 and act.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
                 # down_proj at <= 192 packed rows (the compacted layers at B=1): the library streams [H, I] at 1.8 TB/s there; dl_linear_splitk
                 # cuts K into 8 slices and the residual-add / RMSNorm launch adds them in order (tools/bench_linear_splitk.py: 44 vs 54 us)
-                x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(h.shape[1]), 8), nw_next, eps)
+                x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(h.shape[1]), 8), nw_next, eps, packed=pk_next)
             else:
-                x_new = ops.add_rmsnorm(h, F.linear(act, layer.mlp.down_proj.weight), nw_next, eps)
+                x_new = ops.add_rmsnorm(h, F.linear(act, layer.mlp.down_proj.weight), nw_next, eps, packed=pk_next)
             x = x if nw_next is None else x_new
+            x_pk = pk_next if nw_next is not None else x_pk
         cache.lens.copy_(p["lens_dev"])  # layers < SL hold the full prompt, layers >= SL the compacted one
         if p.get("instruct_dev") is not None:  # device-side instruct compaction (B == 1): kept rows / last row index live on the device
             cache.lens[1].copy_(p["instruct_dev"][:1])
@@ -887,6 +927,25 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if last_only:
             x = x.index_select(0, p["last_rows"] - p["instruct_drop"])
         return x
+
+    @staticmethod
+    def _lp_config(n_units: int, pairs: bool):
+        """(units per workgroup, k ranges) of a dl_linear_packed launch: one workgroup per CU; two k ranges per unit set where that still leaves at
+        most 8 units per workgroup (q|k|v: every CU then pulls half of X through its L1 beside the weight stream -- the bound of this kernel,
+        DESIGN.md section 4), else one (gate|up at 7B / 13B: 6 / 8 units, no hand-over)."""
+        for ks in (2, 1):
+            for nu in (1, 2, 3, 4, 6, 8):
+                if pairs and nu % 2:
+                    continue
+                if -(-n_units // nu) * ks <= 256:
+                    return nu, ks
+        return 8, 1
+
+    def _lp_linear(self, x_pk, rows, wp, N, K, epilogue=ops.LP_STORE):
+        """x [rows, K] in fragment order @ W^T on the operand-order copy wp."""
+        nu, ks = self._lp_config(N // 16, epilogue == ops.LP_SILU_PAIR)
+        return ops.linear_packed(x_pk, wp, N, epilogue=epilogue, units_per_workgroup=nu, k_split=ks, workspace=self._lp_ws if ks > 1 else None, err=self._lp_err,
+                                 x_packed_mk=(rows, K))
 
     def _splitk_ws(self, H):
         """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
@@ -937,6 +996,12 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     def check_device_errors(self):
         """Raises if a launch with in-kernel hand-offs (dl_gemv_qkv_attn, dl_gemv_gu_tp) gave up on a wait since the last check (such a launch
         poisons its output instead of hanging).  Costs one device->host copy: call it where a sync is acceptable."""
+        if self._lp_err is not None and self._lp_ws is not None:
+            code = int(self._lp_err.item())
+            if code != 0:
+                self._lp_err.zero_()
+                self._lp_ws.zero_()
+                raise ops.HipOpsError("in-kernel hand-off aborted: dl_linear_packed (a k range's partial tiles never arrived)")
         st = self._dstate
         if st is not None:
             code = int(st.blk_err.item())

@@ -37,11 +37,14 @@ extern "C" {
 #define DL_F16 1
 #define DL_BF16 2
 
+#define DL_ABI_VERSION 3
+
 #define DL_OK 0
 #define DL_ERR_ARG (-1)     /* bad argument (NULL pointer, unsupported size / dtype) */
 #define DL_ERR_LAUNCH (-2)  /* hipLaunchKernel failed; see dl_last_error() */
 
-int dl_version(void);               /* ABI version, currently 1 */
+int dl_version(void);               /* ABI version: 3 (round 5: + dl_pack_weight_tiles / dl_linear_packed; 2 = the round-4 signature changes of
+                                       * dl_gemv_qkv_attn / dl_prompt_layout, dl_decode_block* removed).  hip_ops.load_library() refuses any other value. */
 const char* dl_last_error(void);    /* thread-local, never NULL */
 int dl_device_check(void);          /* 0 if the current HIP device is gfx950, else DL_ERR_ARG */
 
@@ -349,6 +352,38 @@ int64_t dl_gemv_gu_tp_workspace_bytes(int d_model);
 int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void* h_out, const void* delta, const void* norm_w, float eps, void* y,
                   const dl_tp_weights* tp, int d_model, void* tp_workspace, float* logits_out, int32_t* decision, const int32_t* pos_base,
                   void* granules, int call_tag, int32_t* err_flag, int dtype, int grid_cap, void* stream);
+
+/* ---- weight-streaming projection on a PRE-PACKED weight copy (round 5): the decoder's nn.Linear calls at a few hundred rows or fewer -- DML:1011-1013
+ * (q|k|v), DML:1127 (o_proj), DML:328 (gate / up / down) in the post-compaction prefill layers (M = N' = 117..192) and decode steps of 25..32 rows.
+ * dl_pack_weight_tiles writes W [N,K] (nn.Linear layout, contiguous) once in matrix-core operand order: 16-neuron x 32-k fragments of one contiguous
+ * KiB each, Wp[((u S + s) 64 + lane) 8 + j] = W[16 u + lane % 16][32 s + 8 (lane / 16) + j], S = K / 32 (u: unit, s: slab); with gate_up_pairs != 0,
+ * W = [gate; up] ([2 I, K]) and unit 2 j holds gate neurons [16 j, 16 j + 16), unit 2 j + 1 the matching up neurons.  N % 16 == 0, K % 64 == 0; bf16 / f16;
+ * Wp: dl_packed_weight_bytes(N, K, dtype) bytes (= N K 2; -1 for unsupported shapes), 16-byte aligned, not aliasing W.
+ * dl_pack_x_tiles: the activations in the same order -- Xp[step][tile][k half][lane][8], step = k / 64, tile = row / 16, lane = 16 ((k % 32) / 8) + row % 16,
+ * 4 ceil(ceil(M / 16) / 4) tiles (rows past M repeat row M - 1) -- so that a consumer wave's fragment is one contiguous KiB too; dl_packed_x_bytes(M, K) bytes.
+ * dl_linear_packed: Y[M,N] = X[M,K] W^T, fp32 accumulation, M <= 256.  x_packed: 0 = X row-major [M,K] with row stride ldx >= K elements (16-byte aligned
+ * rows), 1 = dl_pack_x_tiles layout (ldx ignored).
+ *   k_split (1..8): that many workgroups share a set of units, each a contiguous k range; all but the last hand their fp32 tiles to the last through
+ *   `workspace` (dl_linear_packed_workspace_bytes bytes, 256-byte aligned, ZEROED ONCE by the caller: the kernel leaves its flag words zero), which adds
+ *   them in range order and runs the epilogue -- a fixed summation order for a given (units_per_workgroup, k_split): deterministic, one rounding per
+ *   output.  err_flag (may be NULL): bit 3 is set if a reducing wave gave up waiting (never on a healthy launch).
+ *   epilogue 0: Y[m][n] = cast(acc); 1 (gate_up_pairs packing): Y[m][i] = cast(cast(silu(cast(gate_i))) * cast(up_i)), Y: [M, N / 2] (DML:328, the
+ *   roundings of F.linear followed by dl_silu_mul); 2: Y[m][n] = cast(resid[m][n] + cast(acc)) (DML:1289 / 1295; resid may alias Y).
+ *   units_per_workgroup: 0 = chosen here (one workgroup per CU), else 1, 2, 3, 4, 6, 8. */
+/* dl_rmsnorm / dl_add_rmsnorm / dl_add_rmsnorm_parts with `out` written in dl_pack_x_tiles order (dl_packed_x_bytes(rows, H) bytes): the producer of a
+ * dl_linear_packed(x_packed = 1) call writes its rows where the consumer's fragments expect them -- no separate packing launch.  rows <= 256,
+ * H % 64 == 0, bf16 / f16; w and out are required (the residual-only form has no output to pack); same arithmetic, same roundings. */
+int dl_rmsnorm_packed(const void* x, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream);
+int dl_add_rmsnorm_packed(void* h, const void* delta, const void* w, void* out, int64_t rows, int H, float eps, int dtype, void* stream);
+int dl_add_rmsnorm_parts_packed(void* h, const float* parts, int n_slices, const void* w, void* out, int64_t rows, int H, float eps, int dtype,
+                                void* stream);
+int64_t dl_packed_weight_bytes(int N, int K, int dtype);
+int dl_pack_weight_tiles(const void* W, void* Wp, int N, int K, int gate_up_pairs, int dtype, void* stream);
+int64_t dl_packed_x_bytes(int M, int K);
+int dl_pack_x_tiles(const void* X, int64_t ldx, void* Xp, int M, int K, int dtype, void* stream);
+int64_t dl_linear_packed_workspace_bytes(int M, int N, int K, int epilogue, int units_per_workgroup, int k_split);
+int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N, int K,
+                     int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,25 +38,29 @@ def _worker(rank, world, port, items, q):
     one_lg, one_ids = dd.gather_results(logits, ids, max_rows=per, max_new_tokens=5, pad_token_id=-1)
     bounded = dd.all_gather_rows(ids, pad_value=-1, max_shape=(per, 5))
     t = dd.max_over_ranks(float(rank + 1), "cpu")
+    view = dd.describe()
     dd.barrier()
     if rank == 0:
+        assert view["backend"] == "gloo" and view["world_size"] == w and [r_["rank"] for r_ in view["ranks"]] == list(range(w)), view
         q.put((all_ids.numpy(), all_logits.numpy(), t, bool(  # by value: a shared-memory tensor handle dies with this process
             torch.equal(one_lg, all_logits) and torch.equal(one_ids, all_ids) and torch.equal(bounded, all_ids))))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items", [7, 4, 1])
-def test_dp_equals_single_process(n_items):
+@pytest.mark.parametrize("n_items,world", [(7, 2), (4, 2), (1, 2), (29, 8), (256, 8), (5, 8)])
+def test_dp_equals_single_process(n_items, world):
+    """world 8 = the reference's eight forked processes (run/dynamic_eval/eval_for_vqav2.sh:11-21): 256 requests -> 32 per rank (configs[3]); 29 -> a
+    ragged last chunk; 5 -> ranks past the end get nothing and still take part in the collective."""
     items = list(range(10, 10 + n_items))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, items, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, items, q)) for r in range(world)]
     for p in procs:
         p.start()
-    all_ids, all_logits, t, one_message_same = q.get(timeout=120)
+    all_ids, all_logits, t, one_message_same = q.get(timeout=300)
     all_ids, all_logits = torch.from_numpy(all_ids), torch.from_numpy(all_logits)
     for p in procs:
         p.join(timeout=60)
@@ -67,7 +71,7 @@ def test_dp_equals_single_process(n_items):
         assert torch.equal(all_ids[i, : tok.numel()], tok)
         assert (all_ids[i, tok.numel() :] == -1).all()
         assert torch.equal(all_logits[i], lg)
-    assert t == 2.0
+    assert t == float(world)
     assert one_message_same, "gather_results / bounded all_gather_rows (one collective) must equal the two-collective gather"
 
 
@@ -130,3 +134,32 @@ def test_get_chunk_matches_reference_rule():
     assert split_list(lst, 4) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
     assert get_chunk(lst, 4, 3) == [9] and get_chunk(lst, 8, 7) == []
     assert sum((list(get_chunk(lst, 3, k)) for k in range(3)), []) == lst
+
+
+def test_bench_abort_is_one_json_line():
+    """a multi-rank run that must not report a number still prints ONE parseable line: the metric, value null, the reason, the
+    per-rank detail and the partial timings."""
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    line = bench.abort_line("data-parallel ranks produced different results for identical requests", {"per_rank": [{"rank": 0}, {"rank": 1, "ids_equal_rank0": False}]},
+                            {"n_gpus": 2, "ms_per_step": 161.3, "dist": {"backend": "nccl", "world_size": 2}})
+    assert "\n" not in line
+    d = json.loads(line)
+    assert d["metric"] == bench.METRIC and d["value"] is None and "different results" in d["error"]
+    assert d["detail"]["per_rank"][1]["ids_equal_rank0"] is False and d["partial"]["dist"]["backend"] == "nccl"
+
+
+def test_bench_refuses_more_ranks_than_gpus_with_a_json_line():
+    """`python bench.py --gpus 2` on a box without GPUs: exit code 2 and an "error" line instead of a bare SystemExit string."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DL_FORCE_DEVICE")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1500:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["value"] is None and "visible GPU" in d["error"] and d["detail"]["gpus"] == 2 and d["partial"]["n_gpus"] == 2

@@ -851,3 +851,115 @@ def test_gemv_gu_tp_bit_identical_to_the_separate_launches(ops, dtype, H, I, D):
         assert torch.equal(lg_f, lg_r) and torch.equal(dec_f, dec_r) and torch.equal(ws_f, ws_r), (step, lg_f, lg_r)
         decs.append(int(dec_r))
     assert int(err.item()) == 0
+
+
+# ---- round 5: dl_linear_packed (operand-order weights, LDS-DMA loaders + MFMA consumers, k ranges shared between workgroups) ----
+def _lp_ref(x, w):
+    return F.linear(x.float(), w.float())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize(
+    "M,N,K,nu,ks",
+    [(170, 12288, 4096, 6, 2), (170, 12288, 4096, 3, 1), (117, 4096, 4096, 2, 2), (192, 4096, 11008, 4, 4), (25, 2048, 1024, 0, 1), (32, 6144, 512, 2, 2), (1, 256, 128, 1, 2),
+     (256, 512, 2048, 8, 8), (200, 1040, 320, 3, 1), (16, 48, 64, 1, 1), (170, 15360, 5120, 8, 2), (64, 320, 1088, 4, 1)],
+)
+def test_linear_packed_vs_fp32_every_layout(ops, dtype, M, N, K, nu, ks):
+    """Y = X W^T on the operand-order weight copy against an fp32 product of the same rounded inputs: row-major and fragment-order X, strided rows,
+    every units / k-range split, ragged last workgroup (N / 16 not a multiple of the units per workgroup), ragged row tiles; bit-identical between
+    the two X layouts and from call to call (fixed summation order); dl_pack_x_tiles == the layout the header states."""
+    g = torch.Generator().manual_seed(5)
+    x_full = torch.randn(M, K + 40, generator=g).to(dtype).cuda()
+    x = x_full[:, :K]
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).cuda()
+    wp = ops.pack_weight_tiles(w)
+    # the weight layout of include/dynllava.h, restated
+    S = K // 32
+    wp_ref = w.view(N // 16, 16, S, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    assert torch.equal(wp, wp_ref)
+    xp = ops.pack_x_tiles(x)
+    tiles = 4 * -(-(-(-M // 16)) // 4)
+    xpad = torch.cat([x, x[-1:].expand(tiles * 16 - M, K)]) if tiles * 16 > M else x
+    assert torch.equal(xp, xpad.reshape(tiles, 16, K // 64, 2, 4, 8).permute(2, 0, 3, 4, 1, 5).contiguous().view(-1))
+    ws = ops.linear_packed_workspace(M, N, K, "cuda", ops.LP_STORE, nu, ks)
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    kw = dict(units_per_workgroup=nu, k_split=ks, workspace=ws, err=err)
+    ref = _lp_ref(x, w)
+    y_row = ops.linear_packed(x, wp, N, **kw)
+    y_pk = ops.linear_packed(xp, wp, N, x_packed_mk=(M, K), **kw)
+    assert y_row.shape == (M, N) and torch.equal(y_row, y_pk)
+    assert torch.equal(y_pk, ops.linear_packed(xp, wp, N, x_packed_mk=(M, K), **kw)), "a k-split launch must leave its workspace ready for the next one"
+    ulp = ULP[dtype]
+    assert float((y_pk.float() - ref).abs().max()) <= (0.5 * ulp + 3e-5 * math.sqrt(K / 1024 + 1)) * max(1.0, float(ref.abs().max())) * 1.01
+    assert int(err.item()) == 0
+    if ws is not None:  # (the flag words lead the workspace, padded to 256 bytes)
+        assert int(ws[:256].view(torch.int32).abs().sum()) == 0, "flag words must be zero after a launch"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,H,I,ks", [(170, 4096, 11008, 1), (117, 1024, 2816, 2), (32, 512, 1536, 1), (192, 5120, 13824, 1)])
+def test_linear_packed_epilogues_bit_equal_the_separate_launches(ops, dtype, M, H, I, ks):
+    """SiLU(gate) * up on the gate / up interleaved packing == dl_silu_mul applied to the ROUNDED plain output of the same kernel (DML:328: the
+    projection is rounded, silu is rounded, the product is rounded); residual epilogue == rounded output added to the residual by torch
+    (DML:1289 / 1295)."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(M, H, generator=g).to(dtype).cuda()
+    w_gu = (torch.randn(2 * I, H, generator=g) / math.sqrt(H)).to(dtype).cuda()
+    cands = [ops.linear_packed_workspace(M, 2 * I, H, "cuda", e, 0, ks) for e in (ops.LP_SILU_PAIR, ops.LP_STORE)]  # (the chosen units per workgroup differ)
+    ws = max((c for c in cands if c is not None), key=lambda c: c.numel(), default=None)
+    plain = ops.linear_packed(x, ops.pack_weight_tiles(w_gu), 2 * I, k_split=ks, workspace=ws)  # same k order -> same fp32 sums whatever the unit order
+    fused = ops.linear_packed(x, ops.pack_weight_tiles(w_gu, gate_up_pairs=True), 2 * I, epilogue=ops.LP_SILU_PAIR, k_split=ks, workspace=ws)
+    assert fused.shape == (M, I)
+    assert torch.equal(fused, ops.silu_mul(plain))
+    w_o = (torch.randn(H, H, generator=g) / math.sqrt(H)).to(dtype).cuda()
+    wp_o = ops.pack_weight_tiles(w_o)
+    res = torch.randn(M, H, generator=g).to(dtype).cuda()
+    ws2 = ops.linear_packed_workspace(M, H, H, "cuda", ops.LP_RESID, 0, 2)
+    y = ops.linear_packed(x, wp_o, H, k_split=2, workspace=ws2)
+    h = res.clone()
+    ops.linear_packed(x, wp_o, H, out=h, epilogue=ops.LP_RESID, resid=h, k_split=2, workspace=ws2)  # in place on the residual stream
+    assert torch.equal(h, (res.float() + y.float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,H", [(170, 4096), (1, 64), (117, 5120), (256, 1024), (33, 128)])
+def test_packed_norm_outputs_are_the_row_major_ones_in_fragment_order(ops, dtype, rows, H):
+    """dl_rmsnorm_packed / dl_add_rmsnorm_packed / dl_add_rmsnorm_parts_packed: same values as the row-major launches, stored where dl_pack_x_tiles
+    would put them (rows past the last one are not written: compared on the rows that exist)."""
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(rows, H, generator=g) * 2).to(dtype).cuda()
+    d = torch.randn(rows, H, generator=g).to(dtype).cuda()
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype).cuda()
+    parts = torch.randn(3, rows, H, generator=g).cuda()
+    tiles = 4 * -(-(-(-rows // 16)) // 4)
+
+    def unpack(p):
+        return p[: tiles * 16 * H].view(H // 64, tiles, 2, 4, 16, 8).permute(1, 4, 0, 2, 3, 5).reshape(tiles * 16, H)[:rows]
+
+    assert torch.equal(unpack(ops.rmsnorm(x, w, 1e-5, packed=True)), ops.rmsnorm(x, w, 1e-5))
+    h1, h2 = x.clone(), x.clone()
+    assert torch.equal(unpack(ops.add_rmsnorm(h1, d, w, 1e-5, packed=True)), ops.add_rmsnorm(h2, d, w, 1e-5)) and torch.equal(h1, h2)
+    h1, h2 = x.clone(), x.clone()
+    assert torch.equal(unpack(ops.add_rmsnorm_parts(h1, parts, w, 1e-5, packed=True)), ops.add_rmsnorm_parts(h2, parts, w, 1e-5)) and torch.equal(h1, h2)
+
+
+def test_linear_packed_rejects_bad_arguments(ops):
+    x = torch.zeros(8, 128, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 128, dtype=torch.bfloat16, device="cuda")
+    wp = ops.pack_weight_tiles(w)
+    with pytest.raises(ops.HipOpsError):
+        ops.pack_weight_tiles(torch.zeros(60, 128, dtype=torch.bfloat16, device="cuda"))  # N % 16
+    with pytest.raises(ops.HipOpsError):
+        ops.pack_weight_tiles(torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda"))  # K % 64
+    with pytest.raises(ops.HipOpsError):
+        ops.pack_weight_tiles(torch.zeros(64, 128, device="cuda"))  # fp32
+    with pytest.raises(ops.HipOpsError):
+        ops.linear_packed(x, wp, 64, units_per_workgroup=5)
+    with pytest.raises(ops.HipOpsError):
+        ops.linear_packed(x, wp, 64, k_split=3, workspace=torch.zeros(1 << 20, dtype=torch.uint8, device="cuda"))  # K / 64 = 2 steps
+    with pytest.raises((ops.HipOpsError, AssertionError)):
+        ops.linear_packed(x, wp, 64, k_split=2)  # no workspace
+    big = torch.zeros(300, 128, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ops.HipOpsError):
+        ops.linear_packed(big, wp, 64)  # more than one tile of rows
+    assert ops.linear_packed(x[:0], wp, 64).shape == (0, 64)  # empty input: a no-op

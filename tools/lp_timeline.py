@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Per-wave timeline of one dl_linear_packed launch (s_memtime stamps written by the kernel when the measurement hook is set): entry -> first
+ring step landed -> k loop done -> hand-over done -> stores done, as medians / maxima over workgroups, per role.
+  python tools/lp_timeline.py --shape qkv --nu 6 --ks 2"""
+import argparse, ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dynamic_llava_amd import hip_ops as ops
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="qkv"); ap.add_argument("--nu", type=int, default=3); ap.add_argument("--ks", type=int, default=1); ap.add_argument("--m", type=int, default=170)
+ap.add_argument("--rowx", action="store_true")
+a = ap.parse_args()
+H, I = 4096, 11008
+N, K = {"qkv": (3 * H, H), "o": (H, H), "gate|up": (2 * I, H), "down": (H, I)}[a.shape]
+dev, dt = "cuda", torch.bfloat16
+lib = ops.lib()
+lib.dl_linear_packed_set_stamps.argtypes = [ctypes.c_void_p]; lib.dl_linear_packed_set_stamps.restype = None
+ws = [torch.randn(N, K, device=dev, dtype=dt) / K**0.5 for _ in range(4)]
+wps = [ops.pack_weight_tiles(w) for w in ws]
+x = torch.randn(a.m, K, device=dev, dtype=dt); xpk = ops.pack_x_tiles(x)
+wsb = ops.linear_packed_workspace(a.m, N, K, dev, 0, a.nu, a.ks)
+n_wg = -(-(N // 16) // a.nu) * a.ks
+st = torch.zeros(n_wg * 6 * 8, dtype=torch.int64, device=dev)
+xin, mk = (x, None) if a.rowx else (xpk, (a.m, K))
+for wp in wps: ops.linear_packed(xin, wp, N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
+torch.cuda.synchronize()
+lib.dl_linear_packed_set_stamps(ctypes.c_void_p(st.data_ptr()))
+ops.linear_packed(xin, wps[0], N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
+torch.cuda.synchronize()
+lib.dl_linear_packed_set_stamps(None)
+s = st.view(n_wg, 6, 8).cpu().double()
+t0 = s[:, :, 0].min()
+n_sets = n_wg // a.ks
+us = lambda c: c / 100.0  # s_memtime ticks at 100 MHz (constant clock)
+print(f"{a.shape} M={a.m} nu={a.nu} ks={a.ks} workgroups={n_wg}; s_memtime ticks -> us assuming 100 MHz")
+for role, sel in (("partner", torch.arange(n_wg) < n_sets * (a.ks - 1)), ("reducer/last", torch.arange(n_wg) >= n_sets * (a.ks - 1))):
+    if sel.sum() == 0: continue
+    r = s[sel]
+    for wname, wsel in (("loader", slice(0, 2)), ("consumer", slice(2, 6))):
+        rr = r[:, wsel, :]
+        line = f"  {role:13s} {wname:8s}:"
+        for k, lab in enumerate(("entry", "first step", "loop done", "handover", "end")):
+            v = rr[:, :, k] - t0
+            v = v[rr[:, :, k] > 0]
+            if v.numel(): line += f" {lab} med {us(v.median()):6.2f} max {us(v.max()):6.2f} |"
+        print(line)
