@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--predictor-gain", type=float, default=50.0, help="'trained-like' predictor scaling (no score ties); 1.0 = plain random init")
     ap.add_argument("--no-calibrate", action="store_true", help="leave the random-init output-text predictor as is (it then keeps or evicts everything)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed configs[2] / configs[4] legs and the measured ceilings (N = 1 only; they add ~2 minutes)")
     return ap.parse_args()
 
 
@@ -454,9 +455,17 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
     run(ids, am, imgs)  # warm-up (graph capture, allocator)
     dd.barrier()
     torch.cuda.synchronize()
+    import torch.distributed as tdist
+
+    n_coll = []
+    real_ag = tdist.all_gather_into_tensor if tdist.is_initialized() else None
+    if real_ag is not None:  # count what the batch's gather really issues (one collective per batch, asserted by the 8-rank test)
+        tdist.all_gather_into_tensor = lambda *a, **k: (n_coll.append(1), real_ag(*a, **k))[1]
     t0 = time.perf_counter()
     out, lg = run(ids, am, imgs)
     all_lg, all_ids = dd.gather_results(lg, out, max_rows=per, max_new_tokens=new_tokens)  # one all_gather_into_tensor: logits + ids + shapes
+    if real_ag is not None:
+        tdist.all_gather_into_tensor = real_ag
     torch.cuda.synchronize()
     dd.barrier()
     el = dd.max_over_ranks(time.perf_counter() - t0, device)
@@ -477,8 +486,107 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
         # argmax later: reported in rerun_detail, not fatal
     n_tok_all = sum(35 + 576 + q for q in n_q) + n_req * new_tokens
     return {"workload": f"BASELINE configs[3]: {n_req} ragged requests ({per} per rank, question lengths ~U[8,64]), {new_tokens} new tokens each, one all-gather",
-            "tokens_per_s": round(n_tok_all / el, 1), "seconds": round(el, 4), "gathered_rows": int(all_ids.shape[0]), "dp_equals_rerun_of_last_rank": ok,
+            "tokens_per_s": round(n_tok_all / el, 1), "seconds": round(el, 4), "gathered_rows": int(all_ids.shape[0]), "collectives_per_batch": len(n_coll),
+            "rows_per_rank": [len(dd.get_chunk(list(range(n_req)), world, r_)) for r_ in range(world)], "dp_equals_rerun_of_last_rank": ok,
             "rerun_detail": detail, "max_prompt_tokens_per_rank": int(tot)}
+
+
+def _wall(fn, n=2):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def measured_ceilings(device):
+    """SURVEY 8d / BASELINE.md section 4: the two ceilings every roofline fraction of this line is priced against, MEASURED on this box beside the
+    datasheet values -- a float4 device-to-device copy (bytes read + bytes written over the time) and a large square bf16 GEMM on hipBLASLt."""
+    n = 1 << 30  # 1 GiB source, 1 GiB destination: far past the 256 MB Infinity Cache
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    ms_copy = min(event_time_ms(lambda: dst.copy_(src), 10, 3) for _ in range(2))
+    N = 8192
+    a = torch.randn(N, N, device=device, dtype=torch.bfloat16)
+    b = torch.randn(N, N, device=device, dtype=torch.bfloat16)
+    c = torch.empty(N, N, device=device, dtype=torch.bfloat16)
+    ms_gemm = min(event_time_ms(lambda: torch.mm(a, b, out=c), 10, 3) for _ in range(2))
+    return {"hbm_copy_GBps": round(2 * n / ms_copy / 1e6, 1), "hbm_copy": "torch copy_ of 1 GiB (uint8, 16-byte accesses): (read + written bytes) / time",
+            "hbm_spec_GBps": HBM_PEAK_GBS, "hbm_copy_frac_of_spec": round(2 * n / ms_copy / 1e6 / HBM_PEAK_GBS, 3),
+            "bf16_gemm_TFLOPs": round(2 * N**3 / ms_gemm / 1e9, 1), "bf16_gemm": f"torch.mm {N}x{N}x{N} bf16 (hipBLASLt)", "bf16_dense_spec_TFLOPs": 2500.0,
+            "bf16_gemm_frac_of_spec": round(2 * N**3 / ms_gemm / 1e9 / 2500.0, 3)}
+
+
+def _weight_stream_bytes(model):
+    return sum(p.numel() * p.element_size() for n, p in model.named_parameters() if ".layers." in n or n.startswith("lm_head"))
+
+
+def configs2_leg(model, cfg, device, dtype, new_tokens=128):
+    """BASELINE configs[2], untimed by the driver but IN the driver's line: the bench's own 7B model, 32 ragged requests in one packed batch (question
+    lengths ~U[8,64], seed 1), 128 greedy tokens each.  whole_step: (all streamed weights + the K/V rows the batch's attention reads at the final
+    lengths) per decode step over the measured time per step, against the HBM spec."""
+    g = torch.Generator().manual_seed(1)
+    B = 32
+    n_q = torch.randint(8, 65, (B,), generator=g).tolist()
+    W = 35 + 1 + max(n_q)
+    ids = torch.zeros(B, W, dtype=torch.long)
+    am = torch.zeros(B, W, dtype=torch.long)
+    for b in range(B):
+        row = torch.cat([torch.tensor([1]), torch.randint(3, cfg.vocab_size, (34,), generator=g), torch.tensor([-200]), torch.randint(3, cfg.vocab_size, (n_q[b],), generator=g)])
+        ids[b, : row.numel()] = row
+        am[b, : row.numel()] = 1
+    images = torch.randn(B, 3, 336, 336, generator=g).to(dtype).to(device)
+    ids, am = ids.to(device), am.to(device)
+    n_prompt = sum(35 + N_IMG + q for q in n_q)
+    t_full = _wall(lambda: model.generate(ids, attention_mask=am, images=images, max_new_tokens=new_tokens, eos_token_id=None))
+    lens = model.last_cache.lens.cpu()
+    t_pre = _wall(lambda: model.generate(ids, attention_mask=am, images=images, max_new_tokens=1, eos_token_id=None))
+    model.check_device_errors()
+    dec_ms = (t_full - t_pre) / (new_tokens - 1) * 1e3
+    SL, L, H = cfg.sparse_config["sparse_layer"], cfg.num_hidden_layers, cfg.hidden_size
+    kv = sum(2 * int(lens[0 if i < SL else 1][b]) * H * 2 for i in range(L) for b in range(B))
+    step_bytes = _weight_stream_bytes(model) + kv
+    return {"workload": f"BASELINE configs[2]: LLaVA-1.5-7B bf16, B={B} images in one packed ragged batch (question lengths ~U[8,64]), {new_tokens} greedy tokens per row, 1 GPU",
+            "tokens_per_s": round((n_prompt + B * new_tokens) / t_full, 1), "step_ms": round(t_full * 1e3, 2), "prefill_ms": round(t_pre * 1e3, 2),
+            "prefill_tokens_per_s": round(n_prompt / t_pre, 1), "decode_ms_per_step": round(dec_ms, 3), "decode_tokens_per_s": round(B * 1e3 / dec_ms, 1),
+            "kv_len_full_max": int(lens[0].max()), "kv_len_sparse_min_max": [int(lens[1].min()), int(lens[1].max())],
+            "whole_step": {"bytes_per_step": int(step_bytes), "achieved": round(step_bytes / dec_ms / 1e6, 1), "frac": round(step_bytes / dec_ms / 1e6 / HBM_PEAK_GBS, 4), "unit": "GB/s",
+                           "note": "all decoder + lm_head weights + the K/V rows the 32 rows' attention reads (final lengths) per decode step / decode_ms_per_step"}}
+
+
+def configs4_leg(device, dtype, predictor_gain):
+    """BASELINE configs[4]: LLaVA-1.5-13B bf16 (40 layers, random init), B=1, prompt 35 + 576 + 29 = 640 tokens -> 179 after layer 2, decoded to a
+    total length of 2048 (1408 steps) with output-text KV eviction, the predictor calibrated like the headline's (about half of the tokens evicted)."""
+    from dynamic_llava_amd.builder import build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    cfg = DynamicLlavaConfig(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40)
+    model = build_random_model(cfg, dtype=dtype, device=device, seed=0, predictor_gain=predictor_gain)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.cat([torch.tensor([1]), torch.randint(3, cfg.vocab_size, (34,), generator=g), torch.tensor([-200]), torch.randint(3, cfg.vocab_size, (29,), generator=g)])[None].to(device)
+    images = torch.randn(1, 3, 336, 336, generator=g).to(dtype).to(device)
+    T_new = 2048 - 640
+    calib = calibrate_text_predictor(model, ids, images, 64)
+    t_full = _wall(lambda: model.generate(ids, images=images, max_new_tokens=T_new, eos_token_id=None), 1)
+    lens = model.last_cache.lens.cpu().tolist()
+    t_pre = _wall(lambda: model.generate(ids, images=images, max_new_tokens=1, eos_token_id=None), 3)
+    model.check_device_errors()
+    dec_ms = (t_full - t_pre) / (T_new - 1) * 1e3
+    SL, L, H = cfg.sparse_config["sparse_layer"], cfg.num_hidden_layers, cfg.hidden_size
+    # K/V read per token, averaged over the run: layers < SL grow 640 -> 2047, the evicting layers 179 -> final
+    kv_avg = sum(2 * ((640 + lens[0][0]) / 2 if i < SL else (179 + lens[1][0]) / 2) * H * 2 for i in range(L))
+    step_bytes = _weight_stream_bytes(model) + kv_avg
+    res = {"workload": "BASELINE configs[4]: LLaVA-1.5-13B bf16, B=1, prompt 640 (-> 179 after layer 2) + 1408 greedy tokens = 2048, output-text KV eviction on, 1 GPU",
+           "tokens_per_s": round((640 + T_new) / t_full, 1), "step_ms": round(t_full * 1e3, 1), "prefill_ms": round(t_pre * 1e3, 2), "decode_ms_per_token": round(dec_ms, 4),
+           "decode_tokens_per_s": round(1e3 / dec_ms, 1), "kv_len_layers_0_1": lens[0][0], "kv_len_layers_ge2": lens[1][0], "kept_of_generated": lens[1][0] - 179,
+           "text_predictor_calibrated_keep_fraction": calib,
+           "whole_step": {"bytes_per_token": int(step_bytes), "achieved": round(step_bytes / dec_ms / 1e6, 1), "frac": round(step_bytes / dec_ms / 1e6 / HBM_PEAK_GBS, 4), "unit": "GB/s",
+                          "note": "all decoder + lm_head weights + the K/V rows one step's attention reads (run average) / decode_ms_per_token"}}
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -626,7 +734,7 @@ def _main(args, partial):
         "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
                                f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
                    "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dist": dist_view, "dp_rows_identical": dp_consistent, "dp_max_abs_logit_diff": (lg_diff if world > 1 else None), "hip_graph_decode": model.use_hip_graph,
-                   "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib,
+                   "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib, "knobs": model.knobs(),
                    "parity_note": "ids / kept sets / KV lengths bit-exact vs the oracle; logits: 1e-3 asserted literally in fp32, bf16 held to the reference's own "
                                   "eager-bf16 noise class against an fp32 truth (DESIGN.md section 5)"},
         "phases": {"prefill_ms": round(pre_ms, 3), "clip_projector_ms": round(clip_ms, 3), "clip_projector_graph_ms": (None if clip_graph_ms is None else round(clip_graph_ms, 3)), "decode_ms_per_token": round(dec_ms, 4),
@@ -658,6 +766,19 @@ def _main(args, partial):
             res["cpu_baseline"] = cpu_baseline(model, prompt, images, T_new)
         except Exception as e:
             res["cpu_baseline"] = {"error": repr(e)}
+    if world == 1 and not args.no_extra_legs and args.layers == 32:
+        # the other single-GPU BASELINE configs and the box's measured ceilings, OUTSIDE the timed region of the headline: reported
+        # in the driver-visible line, never part of `value`
+        for key, leg in (("measured_ceilings", lambda: measured_ceilings(device)), ("configs2", lambda: configs2_leg(model, cfg, device, dtype)),
+                         ("configs4", lambda: configs4_leg(device, dtype, args.predictor_gain))):
+            try:
+                res[key] = leg()
+            except Exception as e:  # a reported leg must never take the measurement down
+                res[key] = {"error": repr(e)}
+        if isinstance(res.get("measured_ceilings"), dict) and "hbm_copy_GBps" in res["measured_ceilings"]:
+            m = res["measured_ceilings"]["hbm_copy_GBps"]
+            res["roofline"]["frac_of_measured_copy"] = round(res["roofline"]["achieved"] / m, 4)
+            res["roofline"]["whole_step"]["frac_of_measured_copy"] = round(whole["achieved"] / m, 4)
     print(json.dumps(res))
 
 

@@ -108,21 +108,40 @@ def load_pretrained_model(model_path, model_base=None, model_name=None, load_8bi
         raise RuntimeError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:5]}")
     vt_path = cfg.mm_vision_tower
     image_processor = None
-    if vt_path and os.path.isdir(str(vt_path)):
+    cache_dir = kwargs.get("cache_dir")
+    if vt_path:
+        # BLD:237-242 + clip_encoder.py:22-38: the tower (and its image processor) is loaded BY NAME -- a local directory or a hub id such as
+        # "openai/clip-vit-large-patch14-336" (what the released checkpoints' config.json says).  There is no network here, so a hub id must resolve from
+        # the local HF cache (`local_files_only=True`; `cache_dir=` / HF_HOME select it); a checkpoint that carries the tower's tensors itself is accepted too.
         from transformers import CLIPImageProcessor, CLIPVisionModel
 
-        clip = CLIPVisionModel.from_pretrained(vt_path)
-        model.model.vision_tower.vision_tower.load_state_dict(clip.state_dict())
-        model.model.vision_tower.to(device=device, dtype=dtype)
-        image_processor = CLIPImageProcessor.from_pretrained(vt_path)
+        local = os.path.isdir(str(vt_path))
+        try:
+            clip = CLIPVisionModel.from_pretrained(vt_path, local_files_only=not local, cache_dir=cache_dir)
+            image_processor = CLIPImageProcessor.from_pretrained(vt_path, local_files_only=not local, cache_dir=cache_dir)
+        except Exception as e:  # noqa: BLE001 -- re-raised below unless the checkpoint itself holds the tower
+            if not any("vision_tower" in k for k in seen):
+                raise FileNotFoundError(
+                    f"vision tower {vt_path!r} (config.mm_vision_tower) is neither a local directory nor present in the local Hugging Face cache "
+                    f"(cache_dir={cache_dir!r}, HF_HOME={os.environ.get('HF_HOME')!r}); there is no network to fetch it from, and the checkpoint holds no vision_tower tensors") from e
+            clip = None
+        if clip is not None:
+            model.model.vision_tower.vision_tower.load_state_dict(clip.state_dict())
+            model.model.vision_tower.to(device=device, dtype=dtype)
     elif not any("vision_tower" in k for k in seen):
-        raise FileNotFoundError(f"vision tower weights not found: config.mm_vision_tower={vt_path!r} is not a local directory (no network here)")
-    tokenizer = None
-    try:
-        from transformers import AutoTokenizer
+        raise FileNotFoundError("vision tower weights not found: config.mm_vision_tower is empty and the checkpoint holds no vision_tower tensors")
+    # BLD:45-49 (AutoTokenizer.from_pretrained(model_path, use_fast=False)): a checkpoint without a usable tokenizer is an error in the reference and here.
+    # require_tokenizer=False (tests / weight-only checkpoints): the failure becomes a warning and `tokenizer` is None.
+    from transformers import AutoTokenizer
 
+    try:
         tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
-    except Exception:
+    except Exception as e:  # noqa: BLE001
+        if kwargs.get("require_tokenizer", True):
+            raise
+        import warnings
+
+        warnings.warn(f"load_pretrained_model: no tokenizer could be loaded from {model_path!r} ({type(e).__name__}: {e}); returning tokenizer=None", RuntimeWarning)
         tokenizer = None
     model.finalize()
     context_len = cfg.extra.get("max_sequence_length", 2048)

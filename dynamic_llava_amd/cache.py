@@ -156,7 +156,7 @@ class KVSlabCache:
         bound = self.key_bound(self.group(layer_idx))
         if bound <= self.fused_single_keys:
             return 1
-        return max(1, min(max_splits, -(-bound // 128)))
+        return max(1, min(max_splits, 4, -(-bound // 128)))  # (4 = the kernel's kQaMaxSplits, whatever the caller asks for)
 
     def set_bounds(self, full_bound, sparse_bound):
         self.full_bound = None if full_bound is None else int(full_bound)

@@ -1,7 +1,9 @@
 // Body of the split-KV decode attention (F9 decode + F11: RoPE of q / new key, KV-slab append, ragged attention over an evicted
-// slab), shared by the launch path (attn_decode.hip: one 256-thread workgroup per (split, head, row)) and by the persistent decode
-// step (decode_persistent.hip: a 512-thread workgroup runs two such splits side by side).  Sharing the code is what makes the two
-// paths bit-identical: same key -> lane-group dealing, same online-softmax batching, same merge orders.
+// slab), shared by the stand-alone launch (attn_decode.hip: one 256-thread workgroup per (split, head, row)) and by the attention workgroups
+// of the fused batch-1 q|k|v launch (gemv.hip, dl_gemv_qkv_attn: 1..4 workgroups per head fed their q / k / v rows as granules).  Sharing the
+// code keeps the two paths in one arithmetic: same key -> lane-group dealing, same online-softmax batching, same merge orders (the fused
+// launch folds the new token in after the slab merge -- attn_split_finish_newlast -- so its output is in the same rounding class, not the
+// same bits; projection row, residual stream and appended K/V are bit-identical).
 //
 // Two parts, so that a caller can have the K/V rows in flight before the query exists:
 //   attn_split_issue  -- needs only kv_len / the slab: key range of the split, first K/V rows requested

@@ -458,7 +458,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
         self.fuse_gu_tp = os.environ.get("DL_FUSE_GU_TP", "1") == "1"
         # attention workgroups per head inside the fused launch: up to this many, one per 128 keys of the scheduled bound (DL_QA_SPLITS=1: always one)
-        self.fused_attn_max_splits = int(os.environ.get("DL_QA_SPLITS", "4"))
+        self.fused_attn_max_splits = max(1, min(4, int(os.environ.get("DL_QA_SPLITS", "4"))))  # the kernel takes 1..4 (kQaMaxSplits)
         self.gu_grid_cap = int(os.environ.get("DL_GU_GRID", "0"))  # workgroups of the batch-1 gate|up launch (0: the kernel's default, 1024)
         self.qkv_attn_grid_cap = int(os.environ.get("DL_QA_GRID", "0"))  # workgroups of the fused q|k|v + attention launch (0: the kernel's default)
         # o_proj of the post-compaction prefill layers (<= 192 rows) on dl_linear_splitk like down_proj: 17.3 vs 18.4-22 us per layer, prefill
@@ -625,7 +625,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     def _assemble(self, lay, dev_idx, input_ids, image_features):
         """Device-only: packed embeds [total,H] from token ids + projector output (index_copy, no host sync)."""
         H = self.config.hidden_size
-        embeds = torch.empty((lay["total"], H), dtype=self.dtype, device=self.device)
+        # zeros, not empty: with a width bucket `total` exceeds the rows the layout writes, and the rows past the last sequence travel through every
+        # row-wise launch of the prefill (ADVICE r4: they must hold finite values whatever the allocator handed out)
+        embeds = torch.zeros((lay["total"], H), dtype=self.dtype, device=self.device)
         ids = input_ids.reshape(-1).index_select(0, dev_idx["text_src"])
         if lay["sig"][0] == "dev":
             # device layout (speculative: every row is ASSUMED to hold one image token).  A row with several leaves IMAGE_TOKEN_INDEX (-200)
@@ -792,6 +794,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         lp_ok = lambda rows_, layer_: (self.packed_prefill_gemm and layer_.wp_qkv is not None and 0 < rows_ <= ops.LP_MAX_ROWS and dt in (torch.bfloat16, torch.float16))
         x_pk = lp_ok(total, self.model.layers[0]) and not (SL == 0 and (vision_on or p["instruct_on"] or p["nocache"]))
         x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps, packed=x_pk)
+        attn_buf = None
         for i, layer in enumerate(self.model.layers):
             if i == SL and vision_on:
                 # ---- F1..F5: predictor -> top-k -> compaction (DML:1826-1994) on the un-normed residual stream ----
@@ -894,7 +897,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             use_lp = use_lp and x_pk
             qkv = self._lp_linear(x, total, layer.wp_qkv, layer.w_qkv.shape[0], h.shape[1]) if use_lp else F.linear(x, layer.w_qkv)
             ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
-            attn = torch.empty((total, nH * d), dtype=dt, device=dev)
+            if attn_buf is None or attn_buf.shape[0] != total:
+                # one zero-filled buffer per row count, shared by the layers (the attention launch writes the rows of real sequences only: padding rows
+                # of a width bucket stay zero instead of holding whatever the allocator handed out -- ADVICE r4)
+                attn_buf = torch.zeros((total, nH * d), dtype=dt, device=dev)
+            attn = attn_buf
             ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : (nH + nKV) * d], qkv[:, (nH + nKV) * d :], attn, cu, max_len, nH, nKV, d, True)
             if self.splitk_o_proj and dt in (torch.bfloat16, torch.float16) and attn.shape[0] <= 192 and attn.shape[1] >= 1024 and attn.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
                 x = ops.add_rmsnorm_parts(h, ops.linear_splitk(attn, layer.self_attn.o_proj.weight, self._splitk_ws(h.shape[1]), 8), layer.post_attention_layernorm.weight, eps, packed=use_lp)
@@ -993,6 +1000,21 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
+    def knobs(self) -> dict:
+        """The resolved values of every tuning knob and test hook that decides WHICH kernels a request runs on (constructor defaults, DL_* environment
+        values, attributes set later) -- recorded in the bench line so that a run can be reproduced.  The last three are test hooks:
+        they must be None / 0 outside tests/."""
+        return {
+            "use_hip_graph": self.use_hip_graph, "attn_inkernel_combine": self.attn_inkernel_combine, "device_prompt_layout": self.device_prompt_layout,
+            "tp_side_stream": self.tp_side_stream, "gemv_max_decode_batch": self.gemv_max_decode_batch, "smallm_max_decode_batch": self.smallm_max_decode_batch,
+            "fuse_qkv_attn": self.fuse_qkv_attn, "fuse_gu_tp": self.fuse_gu_tp, "fused_attn_max_splits": self.fused_attn_max_splits, "gu_grid_cap": self.gu_grid_cap,
+            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm,
+            "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
+            "max_prefill_graphs": self.max_prefill_graphs,
+            "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,
+            "test_hook_min_keys_per_split": getattr(self, "min_keys_per_split", None),
+        }
+
     def check_device_errors(self):
         """Raises if a launch with in-kernel hand-offs (dl_gemv_qkv_attn, dl_gemv_gu_tp) gave up on a wait since the last check (such a launch
         poisons its output instead of hanging).  Costs one device->host copy: call it where a sync is acceptable."""
@@ -1248,7 +1270,14 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     ):
         """dynamic_llava_llama.py:68-115 + dynamic_modeling_llama.py:2631-2813 (inference; no labels / loss).
         logits: fp32 [B, N', V] for ALL positions like the reference (DML:2709-2710); rows are right-padded with
-        zeros when their lengths differ."""
+        zeros when their lengths differ.
+
+        Host synchronisation of DECODE steps (a one-token call on a non-empty cache): the step's launches are scheduled by the same rule generate()
+        follows, which reads the evicted layers' longest row back from the device ONCE PER CHUNK of steps -- steps 1, 5, 9, then every
+        `decode_sync_every` (8) steps block on a device->host copy and check the error word of the fused launches (check_device_errors()).  All other
+        steps enqueue and return.  A caller that captures forward() steps in its own hipGraph / stream pipeline sets `model.decode_sync_every = 0`:
+        then no decode step ever reads the device (launches are sized for the longest possible rows; logits in the same rounding class, not
+        bit-identical to generate()'s), and calling check_device_errors() at a convenient sync point is the caller's job."""
         self._check_ready()
         if labels is not None:
             raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
@@ -1276,13 +1305,22 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._eos, self._pad = -1, 0
             # the decode schedule (KVSlabCache.sched_*): the same rule generate() follows, evaluated step by step -- a forward()-driven loop
             # replays the same kernels as generate() on the same request.  Costs one device->host copy of the lengths per CHUNK of steps
-            if not cache.sched_active():  # a cache of unknown history (imported legacy tuple, a chunk appended): start from what is there now
-                cache.sched_begin(max(cache.full_len_host), int(cache.lens[1].max()), self.decode_sync_every)
-            if cache.sched_at_boundary():
-                if cache._sch["chunks"] > 0:
-                    cache.sched_observe(cache._sch["produced"], int(cache.lens[1].max()))
-                    self.check_device_errors()  # the queue has just been drained anyway: a fused launch that gave up must not go unnoticed in a forward() loop either
-                cache.sched_chunk()
+            if self.decode_sync_every <= 0:
+                # sync-free decode steps: nothing is read back from the device -- the launches are scheduled from the host-known dense
+                # length (every row of the evicting layers is at most that long).  For callers that capture forward() steps in their own graph or
+                # pipeline; the kernels chosen are the ones for the LONGEST possible rows, so a request decoded this way and through generate()
+                # may differ in the last bits of its logits (same rounding class).  check_device_errors() is then the caller's job.
+                if cache.sched_active():
+                    cache.sched_drop()
+                cache.set_bounds(max(cache.full_len_host) + 1, max(cache.full_len_host) + 1)
+            else:
+                if not cache.sched_active():  # a cache of unknown history (imported legacy tuple, a chunk appended): start from what is there now
+                    cache.sched_begin(max(cache.full_len_host), int(cache.lens[1].max()), self.decode_sync_every)
+                if cache.sched_at_boundary():
+                    if cache._sch["chunks"] > 0:
+                        cache.sched_observe(cache._sch["produced"], int(cache.lens[1].max()))
+                        self.check_device_errors()  # the queue has just been drained anyway: a fused launch that gave up must not go unnoticed in a forward() loop either
+                    cache.sched_chunk()
             st.attn_ws.zero_()  # callers may interleave caches at equal positions on this state: clear the merge granules every call (see generate())
             if st.qa_gran is not None:
                 st.qa_gran.zero_()
@@ -1301,7 +1339,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             cache.lens[1] += dec_
             cache.full_len_host = [n + 1 for n in cache.full_len_host]
             cache.seen_tokens += 1
-            cache.sched_advance(1)
+            if cache.sched_active():
+                cache.sched_advance(1)
             if self.debug_records is not None:
                 self.debug_records.update(text_decision=st.decision.clone() if use_tp else None, text_logit=st.tp_logits.clone())
             logits = st.logits.to(torch.float32, copy=True).unsqueeze(1)  # never alias the persistent step buffer

@@ -272,3 +272,26 @@ def make_forced_tokens(cfg, steps, batch, seed=0):
     """Teacher-forced decode inputs [steps, B] (the reference's long-text bench feeds label ids the same way)."""
     g = torch.Generator().manual_seed(3000 + seed)
     return torch.randint(3, cfg.vocab_size, (steps, batch), generator=g)
+
+
+# ---- keep / evict decisions on the boundary (tests only) -------------------------------------------------------------------------------------
+# DML:2385-2391 decides `logit[keep] > logit[evict]` on raw logits.  Two correct evaluations of the predictor in a 16-bit dtype differ by a few units in
+# the last place OF THE LOGITS' MAGNITUDE (the gained final layer sums O(100) products of that size), so a pair whose gap is inside that band may fall
+# either way; outside it a different decision is an error.  The band is stated in ulps of the larger logit, not as an absolute number, and the tests
+# assert how many steps of a run needed it (VERDICT r4 item 3): a regression that flips many near-boundary decisions fails.
+BOUNDARY_ULPS = {torch.bfloat16: 8.0, torch.float16: 8.0, torch.float32: 4096.0}  # fp32: 4096 ulp = 5e-4 relative, the literal 1e-3 logit budget at |logit| ~ 2
+_ULP = {torch.bfloat16: 2.0**-7, torch.float16: 2.0**-10, torch.float32: 2.0**-23}
+MAX_FORCED_DECISIONS = 2  # per compared row and run
+
+
+def boundary_band(text_logit_pair, dtype) -> float:
+    """Width of the band around zero inside which a keep / evict gap may legitimately change sign: BOUNDARY_ULPS ulps of max(|keep|, |evict|, 1)."""
+    t = torch.as_tensor(text_logit_pair).float().abs().reshape(-1)
+    return BOUNDARY_ULPS[dtype] * _ULP[dtype] * max(1.0, float(t.max()))
+
+
+def decision_may_differ(pair_a, dtype_a, pair_b, dtype_b) -> bool:
+    """True if at least one side's gap lies inside its own boundary band (each side in the dtype IT computed the logits in)."""
+    ga = abs(float(torch.as_tensor(pair_a).float().reshape(-1)[0] - torch.as_tensor(pair_a).float().reshape(-1)[1]))
+    gb = abs(float(torch.as_tensor(pair_b).float().reshape(-1)[0] - torch.as_tensor(pair_b).float().reshape(-1)[1]))
+    return ga <= boundary_band(pair_a, dtype_a) or gb <= boundary_band(pair_b, dtype_b)

@@ -24,7 +24,8 @@ def _build(cfg_ns, sd, dtype):
 def _b1_step_following(model, tok, pkv, dec_batched, gap_batched, where):
     """One B=1 decode step whose keep/evict BOOKKEEPING follows the batched run's decision (model.force_text_decision), so that a logit pair on
     the decision boundary -- which the two GEMM paths may legitimately round to different sides -- never ends the comparison: every later
-    step is still compared.  The step's own decision is still checked: away from the boundary (|gap| > 0.5 on both sides) it must agree.
+    step is still compared.  The step's own decision is still checked: outside the boundary band (fixtures.boundary_band: a few ulps of the logits'
+    magnitude) it must agree; the callers bound how many steps may need the band.
     Returns (output, True if the B=1 run's own decision differed and was overridden)."""
     model.force_text_decision = torch.tensor([int(dec_batched)])
     o1 = model(tok, past_key_values=pkv)
@@ -33,7 +34,8 @@ def _b1_step_following(model, tok, pkv, dec_batched, gap_batched, where):
     tl = model.debug_records["text_logit"].cpu()
     gap1 = float((tl[0, 0] - tl[0, 1]).abs())
     if own != int(dec_batched):
-        assert min(gap1, float(gap_batched)) <= 0.5, f"{where}: eviction decision differs away from the boundary (B=1 gap {gap1}, batched gap {float(gap_batched)})"
+        band = fx.boundary_band(tl[0], torch.bfloat16)  # (both runs are this model in bf16: their logits have the same magnitude)
+        assert min(gap1, float(gap_batched)) <= band, f"{where}: eviction decision differs away from the boundary (B=1 gap {gap1}, batched gap {float(gap_batched)}, band {band:.3g})"
         return o1, True
     return o1, False
 
@@ -97,6 +99,7 @@ def test_c3_batch32_ragged_rows_equal_b1_and_oracle():
             assert float((o1.logits[0, -1].cpu() - hist[b][j + 1]).abs().max()) <= 8 * ulp * float(hist[b][j + 1].abs().max()), f"row {b} step {j}"
         assert int(p1[1][-1][0]) == int(pkv[1][-1][b]) and int(p1[1][0][0]) == int(pkv[1][0][b]), f"row {b}: KV lengths after 6 steps"
         print(f"C3 row {b}: 7 of 7 logit vectors compared with its B=1 run, {n_forced} boundary decisions followed")
+        assert n_forced <= fx.MAX_FORCED_DECISIONS, f"row {b}: {n_forced} of 6 decisions had to be followed: more than a boundary effect"
     model.debug_records = None
     # oracle on two rows (B=1 reference semantics), prefill logits
     for b in (0, 17):
@@ -174,7 +177,8 @@ def test_c5_13b_width_long_decode_with_eviction():
             tl_ = orc.records["text_logit"]
             gap_ = float((tl_[0, 0, 0] - tl_[0, 0, 1]).abs())
             if int(orc.records["text_decision"][0, 0]) != dec[j]:
-                assert min(gap_, gap_hip[j]) <= 0.5, f"eviction decision differs away from the boundary, step {j}: oracle gap {gap_}, hip gap {gap_hip[j]}"
+                band = fx.boundary_band(tl_[0, 0], orc.dtype) if orc.dtype != torch.float32 else fx.boundary_band(tl_[0, 0], torch.bfloat16)  # (the HIP side is bf16)
+                assert min(gap_, gap_hip[j]) <= band, f"eviction decision differs away from the boundary, step {j}: oracle gap {gap_}, hip gap {gap_hip[j]}, band {band:.3g}"
                 orc.force_text_decision = torch.tensor([[dec[j]]])
                 l_, p_ = orc.forward(a[:, j : j + 1].cpu(), past_key_values=pkv_)
                 orc.force_text_decision = None
@@ -192,6 +196,7 @@ def test_c5_13b_width_long_decode_with_eviction():
                 n_forced += f1 + f2
         assert int(p_ref[1][-1][0]) == 179 + sum(dec[:n_oracle]), "oracle KV length after the compared steps"
         print(f"C5: {n_oracle + 1} of {n_oracle + 1} logit vectors compared with the oracle, {n_forced} boundary decisions forced")
+        assert n_forced <= 2 * fx.MAX_FORCED_DECISIONS, f"{n_forced} decisions of {n_oracle} steps x 2 oracles had to be forced: more than a boundary effect"
 
 
 @pytest.mark.parametrize("B", [4, 7, 16, 20, 24])
@@ -243,6 +248,7 @@ def test_mid_batch_decode_smallm_rows_equal_b1(B):
         assert int(lens_b[-1][b]) == 35 + 115 + n_q[b] + kept and int(lens_b[0][b]) == 35 + 576 + n_q[b] + 8
         assert int(p1[1][-1][0]) == int(lens_b[-1][b])
         print(f"B={B} row {b}: 8 of 8 steps compared with its B=1 run, {n_forced} boundary decisions followed")
+        assert n_forced <= fx.MAX_FORCED_DECISIONS, f"B={B} row {b}: {n_forced} of 8 decisions had to be followed: more than a boundary effect"
     model.debug_records = None
     # generate(): hipGraph replay == eager launches on this path too
     model.use_hip_graph = True

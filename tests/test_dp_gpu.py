@@ -164,3 +164,28 @@ def test_bench_self_launches_two_ranks_without_torchrun():
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
     assert res["config"]["dp_rows_identical"] is True
     assert res["configs3"]["gathered_rows"] == 64 and res["configs3"]["dp_equals_rerun_of_last_rank"] is True
+
+
+def test_bench_self_launches_eight_ranks_on_one_gpu():
+    """the shape of the 8-GPU run the driver will make -- `python bench.py --gpus 8` -- with all eight ranks on the one GPU of the test
+    box (DL_FORCE_DEVICE hook, gloo; on the 8-GPU node the same call is one rank per GPU over RCCL).  Two decoder layers keep it short (bench.py marks
+    the line INVALID itself).  Checked: the line's view of the process group (backend, world size, eight ranks, one device), identical results on all
+    ranks, configs[3] with 256 requests split 32 per rank by the reference's chunk rule, ONE collective for the batch, gathered rows == a re-run."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, DL_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--layers", "2", "--new-tokens", "4",
+                        "--no-cpu-baseline", "--no-ref-gpu"], capture_output=True, text=True, env=env, timeout=2400, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 8 and res["config"]["parallelism"] == "dp8" and "error" not in res
+    d = res["config"]["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and [x["rank"] for x in d["ranks"]] == list(range(8)) and d["distinct_devices"] == 1
+    assert res["config"]["dp_rows_identical"] is True
+    c3 = res["configs3"]
+    assert c3["gathered_rows"] == 256 and c3["rows_per_rank"] == [32] * 8 and c3["collectives_per_batch"] == 1
+    assert c3["dp_equals_rerun_of_last_rank"] is True, c3

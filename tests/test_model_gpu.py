@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -277,25 +278,49 @@ def test_full_width_slice_vs_oracle(dtype):
             diff = set(keep[0].tolist()) ^ set(keep_ref[0].tolist())
             # index sets may differ only inside the k-th-score rounding band of the 16-bit scores
             assert all(abs(float(score[i] - kth)) <= 4 * ULP[dtype] * max(1.0, abs(float(kth))) for i in diff), diff
-        pkv, pr, p32 = out.past_key_values, p_ref, p_32
+        pkv = out.past_key_values
         if dtype != torch.float32 and not same_set:
-            return  # different (tied) kept sets: logits are not comparable beyond this point
+            # a kept set that differs inside the rounding band of the k-th score: both oracles continue on the HIP path's set (test hook), so that
+            # every later step is still compared -- no silent exit
+            o.force_keep_index = keep
+            l_ref, p_ref = o.forward(ids, image_features=feats.to(dtype))
+            o32.force_keep_index = keep
+            l_32, p_32 = o32.forward(ids, image_features=feats.to(dtype).float())
+        pr, p32 = p_ref, p_32
+        n_forced, n_compared = 0, 0
+
+        def oracle_step(orc, j, pkv_, hip_dec, hip_tl):
+            """One oracle step; a keep / evict pair inside the boundary band (fixtures.boundary_band) that fell the other way is repeated with the
+            HIP path's decision forced, so the caches stay in the same state and the comparison goes on."""
+            l_, p_ = orc.forward(forced[j][:, None], past_key_values=pkv_)
+            tl_ = orc.records["text_logit"][0, 0]
+            if bool(orc.records["text_decision"][0, 0]) != hip_dec:
+                assert fx.decision_may_differ(tl_, orc.dtype, hip_tl, dtype), f"step {j}: eviction decision differs away from the boundary (oracle {tl_.tolist()}, hip {hip_tl.tolist()})"
+                orc.force_text_decision = torch.tensor([[int(hip_dec)]])
+                l_, p_ = orc.forward(forced[j][:, None], past_key_values=pkv_)
+                orc.force_text_decision = None
+                return l_, p_, 1
+            return l_, p_, 0
+
         for j in range(steps):
             out = model(forced[j][:, None].cuda(), past_key_values=pkv)
             pkv = out.past_key_values
-            l_ref, pr = o.forward(forced[j][:, None], past_key_values=pr)
+            hip_dec = bool(model.debug_records["text_decision"][0])
+            hip_tl = model.debug_records["text_logit"].float().cpu()[0]
+            l_ref, pr, f1 = oracle_step(o, j, pr, hip_dec, hip_tl)
+            n_forced += f1
             if dtype == torch.float32:
                 assert float((out.logits.cpu() - l_ref).abs().max()) < 1e-3, f"step {j}"
             else:
-                l_32, p32 = o32.forward(forced[j][:, None], past_key_values=p32)
+                l_32, p32, f2 = oracle_step(o32, j, p32, hip_dec, hip_tl)
+                n_forced += f2
                 e_hip = float((out.logits.cpu() - l_32).abs().max())
                 e_ref = float((l_ref - l_32).abs().max())
                 assert e_hip <= 2.0 * e_ref + 2 * ULP[dtype] * float(l_32.abs().max()), (j, e_hip, e_ref)
-            gap = (o.records["text_logit"][0, 0, 0] - o.records["text_logit"][0, 0, 1]).abs()
-            if dtype == torch.float32 or float(gap) > 0.5:
-                assert bool(model.debug_records["text_decision"][0]) == bool(o.records["text_decision"][0, 0])
-            else:  # keep the two caches in the same state when the 16-bit decision sits on the boundary
-                break
+            n_compared += 1
+        assert n_compared == steps, "every decode step is compared"
+        assert n_forced <= 2 * fx.MAX_FORCED_DECISIONS, f"{n_forced} decisions had to be forced over {steps} steps: more than a boundary effect"
+        assert int(pr[1][-1][0]) == int(pkv[1][-1][0]), "KV length of the evicting layers after the compared steps"
 
 
 def test_keep_rate_one_equals_dense_path():
@@ -443,8 +468,11 @@ def test_checkpoint_roundtrip_through_load_pretrained_model(tmp_path):
     clip = fx.build_clip(cfg, seed=1)
     model = _build(cfg, sd, clip, torch.float16)
     save_pretrained(model, str(tmp_path))
-    tok, m2, proc, ctx = load_pretrained_model(str(tmp_path), None, "dynamic-llava-tiny")  # fp16 default like BLD:62
-    assert m2.dtype == torch.float16 and ctx == 2048
+    with pytest.raises(Exception):  # no tokenizer files in the directory: an error, as in the reference (BLD:45-49) -- not a silent None
+        load_pretrained_model(str(tmp_path), None, "dynamic-llava-tiny")
+    with pytest.warns(RuntimeWarning, match="no tokenizer"):
+        tok, m2, proc, ctx = load_pretrained_model(str(tmp_path), None, "dynamic-llava-tiny", require_tokenizer=False)  # fp16 default like BLD:62
+    assert tok is None and m2.dtype == torch.float16 and ctx == 2048
     ids = fx.make_prompt(cfg, 5, 7)[None].cuda()
     images = fx.make_images(cfg, 1).half().cuda()
     a = model.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
@@ -454,6 +482,49 @@ def test_checkpoint_roundtrip_through_load_pretrained_model(tmp_path):
         load_pretrained_model(str(tmp_path), None, "x", load_4bit=True)
     with pytest.raises(NotImplementedError):
         load_pretrained_model(str(tmp_path), "base", "x")
+
+
+def test_vision_tower_hub_id_resolves_from_the_local_hf_cache(tmp_path):
+    """BLD:237-242 / clip_encoder.py:22-38 load `config.mm_vision_tower` BY NAME; released checkpoints name a hub id ("openai/clip-vit-large-patch14-336").
+    No network here: the id must resolve from the local Hugging Face cache, and a missing entry must say so instead of pretending the id is a path."""
+    import json
+    import os
+    import shutil
+
+    from dynamic_llava_amd.builder import load_pretrained_model, save_pretrained
+
+    cfg = fx.tiny_config()
+    sd = fx.make_state_dict(cfg, seed=SD_SEED, predictor_gain=50.0)
+    clip = fx.build_clip(cfg, seed=1)
+    model = _build(cfg, sd, clip, torch.float16)
+    ckpt, cache = tmp_path / "ckpt", tmp_path / "hf_cache"
+    save_pretrained(model, str(ckpt))
+    # the checkpoint names a hub id and carries NO tower tensors (like a released LLaVA checkpoint)
+    from safetensors.torch import load_file, save_file
+
+    tensors = {k: v for k, v in load_file(str(ckpt / "model.safetensors")).items() if "vision_tower" not in k}
+    save_file(tensors, str(ckpt / "model.safetensors"))
+    cj = json.load(open(ckpt / "config.json"))
+    cj["mm_vision_tower"] = "openai/clip-tiny-for-tests"
+    json.dump(cj, open(ckpt / "config.json", "w"))
+    with pytest.raises(FileNotFoundError, match="local Hugging Face cache"):
+        load_pretrained_model(str(ckpt), None, "x", require_tokenizer=False, cache_dir=str(cache))
+    # put the tower into the cache the way the hub client lays it out: models--org--name/{refs/main, snapshots/<rev>/...}
+    from transformers import CLIPImageProcessor
+
+    rev = "0" * 40
+    snap = cache / "models--openai--clip-tiny-for-tests" / "snapshots" / rev
+    clip.save_pretrained(str(snap))
+    CLIPImageProcessor(size={"shortest_edge": cfg.clip["image_size"]}, crop_size={"height": cfg.clip["image_size"], "width": cfg.clip["image_size"]}).save_pretrained(str(snap))
+    os.makedirs(cache / "models--openai--clip-tiny-for-tests" / "refs", exist_ok=True)
+    (cache / "models--openai--clip-tiny-for-tests" / "refs" / "main").write_text(rev)
+    with pytest.warns(RuntimeWarning):
+        tok, m2, proc, ctx = load_pretrained_model(str(ckpt), None, "x", require_tokenizer=False, cache_dir=str(cache))
+    assert proc is not None, "the image processor comes from the tower's entry, as in clip_encoder.py:33-35"
+    ids = fx.make_prompt(cfg, 5, 7)[None].cuda()
+    images = fx.make_images(cfg, 1).half().cuda()
+    assert torch.equal(model.generate(ids, images=images, max_new_tokens=6, eos_token_id=None), m2.generate(ids, images=images, max_new_tokens=6, eos_token_id=None))
+    shutil.rmtree(cache)
 
 
 def test_text_only_and_edge_prompts_vs_oracle():
@@ -773,6 +844,49 @@ def test_harness_long_text_kv_length_curve_matches_reference_golden(golden_dir):
     # total_token_length follows the script's own accounting (images.shape[-2] * images.shape[-1] // 14 // 14 patches + text)
     assert rec["total_token_length"][0] == n_prompt and rec["total_token_length"][-1] == n_prompt + n - 1
     assert len(rec["max_memory"]) == n and all(m > 0 for m in rec["max_memory"])
+
+
+def test_harness_multi_round_ppl_drives_the_reference_loop(golden_dir):
+    """SURVEY 8f row N2 / model_lvis_multi_round_for_ppl.py:108-220: tools/harness_multi_round_ppl.py runs the reference's multi-round perplexity loop
+    (prefill, label tokens teacher-forced, every later round a multi-token chunk on the returned cache, a round's last label never fed) -- on the golden
+    multi-round case its sequence of model calls IS the golden's: every call's last-token logits within 1e-3 of the REFERENCE's, the last layer's KV
+    length after every call equal, and the per-round perplexities equal to the ones computed from the reference's logits."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("harness_mrp", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "harness_multi_round_ppl.py"))
+    h = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(h)
+    name = "tiny_fp32_multiround"
+    c, dtype, cfg, sd, clip = _golden_setup(name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = _build(cfg, sd, clip, dtype)
+    images = fx.make_images(cfg, 1, seed=0).to(dtype).cuda()
+    # the golden's call list, cut into rounds: a multi-token call opens a round, the single-token calls after it are that round's fed labels; the round's
+    # final label (a target only) is drawn here
+    calls = [torch.from_numpy(g[f"call_ids_{j}"]) for j in range(int(g["n_calls"]))]
+    gl = torch.Generator().manual_seed(77)
+    rounds, call_round = [], []
+    for j, ids in enumerate(calls):
+        if ids.shape[1] > 1:
+            rounds.append([ids, []])
+        else:
+            rounds[-1][1].append(int(ids[0, 0]))
+        call_round.append(len(rounds) - 1)
+    for r in rounds:
+        r[1].append(int(torch.randint(3, cfg.vocab_size, (1,), generator=gl)))
+    seen = []
+    rec = h.run(model, [(p_.cuda(), torch.tensor(l_).cuda()) for p_, l_ in rounds], images, patch=cfg.clip["patch_size"], on_call=lambda j, out: seen.append(out.logits[:, -1].float().cpu().numpy()))
+    assert rec["calls"] == len(calls) == len(seen)
+    for j in range(len(calls)):
+        assert np.abs(seen[j] - g["step_logits"][j]).max() < 1e-3, f"call {j}"
+    assert rec["kv_len_last_layer"] == [int(x) for x in g["kv_len_last"]]
+    for r, (p_, l_) in enumerate(rounds):
+        lg = torch.from_numpy(np.concatenate([g["step_logits"][j] for j in range(len(calls)) if call_round[j] == r]))
+        ppl_ref = float(torch.exp(F.cross_entropy(lg, torch.tensor(l_))))
+        assert abs(rec["round_ppl"][r] - ppl_ref) <= 2e-3 * ppl_ref, (r, rec["round_ppl"][r], ppl_ref)
+    assert rec["instruct_token_length"] == sum(p_.shape[1] for p_, _ in rounds) and rec["output_token_length"] == sum(len(l_) - 1 for _, l_ in rounds)
+    assert rec["prefill_cache_length"] == int(g["kv_len_last"][0]) + sum(p_.shape[1] for p_, _ in rounds[1:])
+    assert rec["output_cache_length"] == int(g["kv_len_last"][-1]) - rec["prefill_cache_length"]
 
 
 def test_harness_long_text_time_no_cache_drives_the_reference_loop(golden_dir):
