@@ -23,6 +23,7 @@ __device__ __forceinline__ void dma_piece_nt(const GLOBAL void* s_base, uint32_t
 }
 
 // mode 3
+template <int UNR>
 __global__ __launch_bounds__(1024) void mixed(const uint32_t* __restrict__ buf, uint32_t bytes, const char* __restrict__ big, int iters, int hbm_iters, uint32_t* out, long long* t_hit) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x >> 6) - 2;
@@ -42,16 +43,16 @@ __global__ __launch_bounds__(1024) void mixed(const uint32_t* __restrict__ buf, 
   u32x4_ acc = {0, 0, 0, 0};
   uint32_t pc = ((w - 2) + blockIdx.x * 7) % pieces;
   const long long t0 = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < iters; ++it) {
-    u32x4_ v[8];
+  for (int it = 0; it < iters * 8 / UNR; ++it) {
+    u32x4_ v[UNR];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       v[u] = *reinterpret_cast<const u32x4_*>(reinterpret_cast<const char*>(buf) + (size_t)pc * 1024 + lane * 16);
       pc += nw;
       pc = pc >= pieces ? pc - pieces : pc;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc ^= v[u];
+    for (int u = 0; u < UNR; ++u) acc ^= v[u];
   }
   if (lane == 0 && w == 2) t_hit[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
   if (acc.x == 0x12345678u) out[threadIdx.x] = acc.y ^ acc.z ^ acc.w;
@@ -122,13 +123,17 @@ int main() {
   char* big; hipMalloc(&big, (size_t)1 << 30);
   hipMemset(big, 1, (size_t)1 << 30);
   long long* t_hit; hipMalloc(&t_hit, 256 * 8);
-  hipFuncSetAttribute((const void*)mixed, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  for (int hit_waves : {4, 8}) {
-    for (int hbm_iters : {0, 100, 200}) {  // 2 waves x hbm_iters x 8 KiB per CU: 0 / 1.6 / 3.2 MiB per CU
+  hipFuncSetAttribute((const void*)mixed<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)mixed<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int cfg_ = 0; cfg_ < 4; ++cfg_) {
+    const int hit_waves = cfg_ == 0 ? 4 : cfg_ == 1 ? 8 : cfg_ == 2 ? 4 : 12, unr = cfg_ == 2 ? 16 : 8;
+    auto mk = unr == 16 ? mixed<16> : mixed<8>;
+    for (int hbm_iters : {0, 200}) {  // 2 waves x hbm_iters x 8 KiB per CU: 0 / 3.2 MiB per CU
       const int it_hit = 300;
-      for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(mixed, dim3(256), dim3((hit_waves + 2) * 64), 65536, 0, buf, bytes, big, it_hit, hbm_iters, out, t_hit);
+      printf("[%d loads in flight per hit wave] ", unr);
+      for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(mk, dim3(256), dim3((hit_waves + 2) * 64), 65536, 0, buf, bytes, big, it_hit, hbm_iters, out, t_hit);
       hipEventRecord(a);
-      hipLaunchKernelGGL(mixed, dim3(256), dim3((hit_waves + 2) * 64), 65536, 0, buf, bytes, big, it_hit, hbm_iters, out, t_hit);
+      hipLaunchKernelGGL(mk, dim3(256), dim3((hit_waves + 2) * 64), 65536, 0, buf, bytes, big, it_hit, hbm_iters, out, t_hit);
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
       std::vector<long long> th(256); hipMemcpy(th.data(), t_hit, 256 * 8, hipMemcpyDeviceToHost);

@@ -25,22 +25,30 @@ xin, mk = (x, None) if a.rowx else (xpk, (a.m, K))
 for wp in wps: ops.linear_packed(xin, wp, N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
 torch.cuda.synchronize()
 lib.dl_linear_packed_set_stamps(ctypes.c_void_p(st.data_ptr()))
-ops.linear_packed(xin, wps[0], N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+ops.linear_packed(xin, wps[1], N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
+e1.record()
 torch.cuda.synchronize()
 lib.dl_linear_packed_set_stamps(None)
+launch_us = e0.elapsed_time(e1) * 1e3
 s = st.view(n_wg, 6, 8).cpu().double()
-t0 = s[:, :, 0].min()
+# s_memtime counters of different XCDs are not synchronised: every wave is reported RELATIVE TO ITS OWN ENTRY stamp; ticks are converted with the
+# launch's event time over the longest entry -> end span (the shader clock under this load)
+span = (s[:, 2:, 4] - s[:, 2:, 0])
+us_per_tick = launch_us / float(span.max())
 n_sets = n_wg // a.ks
-us = lambda c: c / 100.0  # s_memtime ticks at 100 MHz (constant clock)
-print(f"{a.shape} M={a.m} nu={a.nu} ks={a.ks} workgroups={n_wg}; s_memtime ticks -> us assuming 100 MHz")
+print(f"{a.shape} M={a.m} nu={a.nu} ks={a.ks} workgroups={n_wg}: launch {launch_us:.1f} us between events (includes ~5 us of launch overhead); 1 tick = {us_per_tick * 1e3:.3f} ns ({1e-3 / us_per_tick:.2f} GHz)")
 for role, sel in (("partner", torch.arange(n_wg) < n_sets * (a.ks - 1)), ("reducer/last", torch.arange(n_wg) >= n_sets * (a.ks - 1))):
     if sel.sum() == 0: continue
     r = s[sel]
     for wname, wsel in (("loader", slice(0, 2)), ("consumer", slice(2, 6))):
         rr = r[:, wsel, :]
-        line = f"  {role:13s} {wname:8s}:"
-        for k, lab in enumerate(("entry", "first step", "loop done", "handover", "end")):
-            v = rr[:, :, k] - t0
-            v = v[rr[:, :, k] > 0]
-            if v.numel(): line += f" {lab} med {us(v.median()):6.2f} max {us(v.max()):6.2f} |"
+        line = f"  {role:13s} {wname:8s} (us after the wave's own entry):"
+        for k, lab in enumerate(("entry", "first step landed", "k loop done", "hand-over done", "stores done")):
+            if k == 0: continue
+            ok = rr[:, :, k] > 0
+            if not ok.any(): continue
+            v = ((rr[:, :, k] - rr[:, :, 0]) * us_per_tick)[ok]
+            line += f" {lab} med {float(v.median()):6.2f} max {float(v.max()):6.2f} |"
         print(line)

@@ -91,6 +91,22 @@ assert int(err.item()) == 0
 tp_bytes = sum(p_.numel() * 2 for p_ in tp.parameters())
 plan.append({"tag": "gemv_gu_tp", "kernel": "gemv_gu_tp_kernel", "N": N, "K": K, "algorithmic_bytes": N * K * 2 + tp_bytes + K * 2})
 
+# round 5: dl_linear_packed on the two prefill shapes the product runs on it (M = 170 packed rows; activations in fragment order): algorithmic bytes =
+# the weights once + X once + Y once (what a perfect kernel moves through HBM; X is read by every workgroup, but out of L2 after its first touch)
+for tag, N, K, epi, nu, ks in [("linear_packed qkv M=170", 12288, 4096, ops.LP_STORE, 6, 2), ("linear_packed gate_up+silu M=170", 22016, 4096, ops.LP_SILU_PAIR, 6, 1)]:
+    M = 170
+    x = torch.randn(M, K, device=dev, dtype=dt)
+    xp = ops.pack_x_tiles(x)
+    wsb = ops.linear_packed_workspace(M, N, K, dev, epi, nu, ks)
+    n_out = N // 2 if epi == ops.LP_SILU_PAIR else N
+    out = torch.empty(M, n_out, device=dev, dtype=dt)
+    for rep in range(3):
+        wp = ops.pack_weight_tiles(torch.randn(N, K, device=dev, dtype=dt) * 0.02, gate_up_pairs=(epi == ops.LP_SILU_PAIR))
+        torch.cuda.synchronize()
+        ops.linear_packed(xp, wp, N, out=out, epilogue=epi, units_per_workgroup=nu, k_split=ks, workspace=wsb, x_packed_mk=(M, K))
+        torch.cuda.synchronize()
+    plan.append({"tag": tag, "kernel": "linear_packed_kernel", "N": N, "K": K, "algorithmic_bytes": N * K * 2 + M * K * 2 + M * n_out * 2})
+
 for rows in (631, 170):
     x = torch.randn(rows, H, device=dev, dtype=dt)
     w = torch.ones(H, device=dev, dtype=dt)

@@ -23,7 +23,7 @@ def main():
     write = per_dispatch(sys.argv[2], "WRITE_SIZE")
     plan = json.loads(next(l for l in open(sys.argv[3]) if l.startswith("PLAN "))[5:])
     # the probe launches every case exactly 3x, in plan order: chunk the main-kernel dispatches by 3
-    main = lambda rows: [r for r in rows if any(k in r[0] for k in ("attn_decode_split_kernel", "gemv_kernel", "gemv_b1_plain_kernel", "gemv_b1_plain_halves_kernel", "gemv_qkv_attn_kernel", "gemv_gu_tp_kernel", "rmsnorm_kernel"))]
+    main = lambda rows: [r for r in rows if any(k in r[0] for k in ("attn_decode_split_kernel", "gemv_kernel", "gemv_b1_plain_kernel", "gemv_b1_plain_halves_kernel", "gemv_qkv_attn_kernel", "gemv_gu_tp_kernel", "linear_packed_kernel", "rmsnorm_kernel"))]
     chunk = lambda rows: [rows[i : i + 3] for i in range(0, len(rows), 3)]
     gf, gw = chunk(main(fetch)), chunk(main(write))
     assert len(gf) == len(plan) == len(gw), (len(gf), len(gw), len(plan))

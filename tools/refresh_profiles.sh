@@ -23,10 +23,19 @@ python tools/bench_configs.py c2 c4 2>/dev/null | tail -1 > gpurun_out/bench_con
 python tools/bench_configs.py c4cal 2>/dev/null | tail -1 > gpurun_out/bench_configs_4_calibrated.json
 DL_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_dp2_one_gpu.json 2> gpurun_out/bench_dp2_one_gpu.err
 python bench.py --steps 10 --warmup 3 --new-tokens 128 --no-cpu-baseline --no-ref-gpu > gpurun_out/bench_b1_128tokens.json 2>/dev/null
+# round 5: dl_linear_packed -- microbench table, per-wave timelines, request-counter passes per variant (library / splitk / packed variants), L2-hit ceilings
+python tools/bench_linear_packed.py --m 170,117 --sweep > gpurun_out/linear_packed_bench.txt 2>/dev/null
+for a in "qkv --nu 3 --ks 1" "qkv --nu 6 --ks 2" "gate|up --nu 6 --ks 1" "o --nu 2 --ks 2" "down --nu 4 --ks 4"; do python tools/lp_timeline.py --shape $a; done > gpurun_out/linear_packed_timelines.txt 2>/dev/null
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS -d $RAW/lp_sq -o s -- python tools/pmc_linear_packed_probe.py > gpurun_out/lp_probe.log 2>/dev/null
+rocprofv3 --kernel-trace --pmc TA_ADDR_STALLED_BY_TC_CYCLES TCC_BUSY TCC_EA0_RDREQ TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_EA0_RDREQ_LEVEL TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY -d $RAW/lp_tc -o s -- python tools/pmc_linear_packed_probe.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $RAW/lp_l2 -o s -- python tools/pmc_linear_packed_probe.py > /dev/null 2>&1
+python tools/pmc_linear_packed_report.py gpurun_out/lp_probe.log $(find $RAW/lp_sq $RAW/lp_tc $RAW/lp_l2 -name '*.db') > gpurun_out/linear_packed_counters.txt 2>&1
+(hipcc --offload-arch=gfx950 -O3 tools/l2_read_bw.hip -o /tmp/l2bw 2>/dev/null && /tmp/l2bw > gpurun_out/l2_read_ceilings.txt 2>&1) || true
 # then, back in the development container (gpurun merges gpurun_out/):
 #   cp gpurun_out/bench_default.json profiles/${R}_bench_b1.json; cp gpurun_out/kernel_stats.txt profiles/${R}_bench_kernel_stats.txt
 #   grep -v '^JSON' gpurun_out/pmc_report.txt > profiles/${R}_pmc_traffic.txt; grep '^JSON' gpurun_out/pmc_report.txt | sed 's/^JSON //' > profiles/${R}_pmc_traffic.json
 #   grep -v '^JSON' gpurun_out/mfma_report.txt > profiles/${R}_prefill_mfma_util.txt
 #   cp gpurun_out/stream_var.json profiles/${R}_varlen_stream.json; cp gpurun_out/stream_fixed.json profiles/${R}_varlen_stream_fixed_width.json
+#   cp gpurun_out/linear_packed_{bench,timelines,counters}.txt gpurun_out/l2_read_ceilings.txt -> profiles/${R}_*
 #   cp gpurun_out/bench_configs_2_4.json profiles/${R}_bench_configs_2_4.json; cp gpurun_out/bench_dp2_one_gpu.json profiles/${R}_bench_dp2_one_gpu.json
 echo "done: gpurun_out/{bench_default.json,kernel_stats.txt,pmc_report.txt,mfma_report.txt}"
