@@ -75,7 +75,7 @@ __device__ __forceinline__ void lp_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-enum { LP_EPI_STORE = 0, LP_EPI_SILU_PAIR = 1, LP_EPI_RESID = 2 };
+enum { LP_EPI_STORE = 0, LP_EPI_SILU_PAIR = 1, LP_EPI_RESID = 2, LP_EPI_PARTS = 3 };
 constexpr int kLpLoaders = 2, kLpConsumers = 4, kLpThreads = 64 * (kLpLoaders + kLpConsumers);
 
 struct LpParams {
@@ -87,6 +87,7 @@ struct LpParams {
   const void* R;   // LP_EPI_RESID: residual rows [M, n_out], may alias Y
   int64_t ldr;
   int M, n_units, S;  // S = K / 32 slabs
+  int y_packed;       // Y is written in the same fragment order (the next dl_linear_packed's x_packed input): LP_EPI_STORE / LP_EPI_SILU_PAIR
   int x_packed;       // X is Xp[step][tile][k half][lane][8] (dl_pack_x_tiles / a producer's packed output): every fragment one contiguous KiB
   int n_sets, k_split;  // workgroup b: unit set b % n_sets (NU units), k range b / n_sets of k_split
   int* flags;           // [n_sets][k_split - 1][4 consumers]: 1 once that wave's partial tiles are in `parts`; zero before and after every launch
@@ -258,6 +259,23 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
   // 39 -> 25).  The tiles travel as 8-byte agent-scope stores (global_store_dwordx2 ... sc1: written through, past the non-coherent L2s),
   // the wave waits for their acknowledgements, then publishes its flag the same way; the reducer polls the flag and reads the tiles with agent-scope
   // loads (sc1: never a stale line of its own L2, which still holds the previous launch's tiles at these addresses).
+  if constexpr (EPI == LP_EPI_PARTS) {
+    // fp32 partial sums of this workgroup's k range, [k range][M][N], for a consumer that adds the ranges in order (dl_add_rmsnorm_parts: o_proj /
+    // down_proj -> residual add + RMSNorm): no hand-over, no flags, plain 16-byte stores
+    float* P = reinterpret_cast<float*>(p.Y) + (int64_t)ks * p.M * p.ldy;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int row = (c * TPW + j) * 16 + lr;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (u0 + i >= p.n_units) continue;
+        *reinterpret_cast<float4*>(P + (int64_t)row * p.ldy + (u0 + i) * 16 + lg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    LP_STAMP(4);
+    return;
+  }
   if (p.k_split > 1) {
     constexpr int kTiles = NU * TPW;
     typedef unsigned long long u64;
@@ -327,7 +345,9 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
         }
         const uint32_t lo = (uint32_t)Elem<T>::from_f(o[0]) | ((uint32_t)Elem<T>::from_f(o[1]) << 16);
         const uint32_t hi = (uint32_t)Elem<T>::from_f(o[2]) | ((uint32_t)Elem<T>::from_f(o[3]) << 16);
-        *reinterpret_cast<uint2*>(Y + (int64_t)row * p.ldy + ((u0 + i) >> 1) * 16 + lg * 4) = make_uint2(lo, hi);
+        const int col = ((u0 + i) >> 1) * 16 + lg * 4;
+        S_* dst = p.y_packed ? Y + lp_x_chunk_offset(row, col >> 3, kLpConsumers * TPW) + (col & 7) : Y + (int64_t)row * p.ldy + col;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
       }
     } else {
 #pragma unroll
@@ -345,7 +365,8 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
         }
         const uint32_t lo = (uint32_t)Elem<T>::from_f(o[0]) | ((uint32_t)Elem<T>::from_f(o[1]) << 16);
         const uint32_t hi = (uint32_t)Elem<T>::from_f(o[2]) | ((uint32_t)Elem<T>::from_f(o[3]) << 16);
-        *reinterpret_cast<uint2*>(Y + (int64_t)row * p.ldy + col) = make_uint2(lo, hi);
+        S_* dst = (EPI == LP_EPI_STORE && p.y_packed) ? Y + lp_x_chunk_offset(row, col >> 3, kLpConsumers * TPW) + (col & 7) : Y + (int64_t)row * p.ldy + col;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
       }
     }
   }
@@ -401,6 +422,7 @@ static int lp_epi(const LpParams& p, int epilogue, hipStream_t st) {
   }
   if constexpr (ABL == 0) {
     if (epilogue == LP_EPI_RESID) return lp_launch<T, NU, TPW, LP_EPI_RESID, 0>(p, 0, st);
+    if (epilogue == LP_EPI_PARTS) return lp_launch<T, NU, TPW, LP_EPI_PARTS, 0>(p, 0, st);
   }
   set_error("dl_linear_packed: epilogue %d is not built for %d units per workgroup", epilogue, NU);
   return DL_ERR_ARG;
@@ -546,18 +568,23 @@ extern "C" int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const 
   DL_REQUIRE(M >= 0 && N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "dl_linear_packed: M=%d, N=%d (multiple of 16), K=%d (multiple of 64)", M, N, K);
   if (M == 0) return DL_OK;
   const int abl = (epilogue >> 8) & 0xff;  // measurement builds only (tools/bench_linear_packed.py)
-  epilogue &= 0xff;
-  DL_REQUIRE(epilogue >= 0 && epilogue <= LP_EPI_RESID, "dl_linear_packed: epilogue %d", epilogue);
+  const int y_packed = (epilogue >> 4) & 1;  // DL_LP_Y_PACKED
+  epilogue &= 0xf;
+  DL_REQUIRE(epilogue >= 0 && epilogue <= LP_EPI_PARTS, "dl_linear_packed: epilogue %d", epilogue);
+  DL_REQUIRE(!y_packed || epilogue == LP_EPI_STORE || epilogue == LP_EPI_SILU_PAIR, "dl_linear_packed: a fragment-order output goes with epilogue 0 or 1");
   DL_REQUIRE(X && Wp && Y && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Wp & 15) == 0 && ((uintptr_t)Y & 7) == 0 && ldy % 4 == 0,
              "dl_linear_packed: NULL / unaligned pointers or strides (ldy=%lld)", (long long)ldy);
   DL_REQUIRE(x_packed || (ldx % 8 == 0 && ldx >= K), "dl_linear_packed: ldx=%lld (multiple of 8, >= K)", (long long)ldx);
   const int n_out = epilogue == LP_EPI_SILU_PAIR ? N / 2 : N;
-  DL_REQUIRE(ldy >= n_out, "dl_linear_packed: ldy=%lld < %d output columns", (long long)ldy, n_out);
+  DL_REQUIRE(y_packed || ldy >= n_out, "dl_linear_packed: ldy=%lld < %d output columns", (long long)ldy, n_out);
+  DL_REQUIRE(!y_packed || (n_out % 64 == 0 && ((uintptr_t)Y & 15) == 0), "dl_linear_packed: a fragment-order output needs %d output columns to be a multiple of 64", n_out);
+  DL_REQUIRE(epilogue != LP_EPI_PARTS || (((uintptr_t)Y & 15) == 0 && ldy % 4 == 0), "dl_linear_packed: partial sums need a 16-byte aligned fp32 buffer");
   DL_REQUIRE(epilogue != LP_EPI_SILU_PAIR || N % 32 == 0, "dl_linear_packed: gate|up pairs need N=%d to be a multiple of 32", N);
   DL_REQUIRE(epilogue != LP_EPI_RESID || (resid && ((uintptr_t)resid & 7) == 0 && ldr % 4 == 0 && ldr >= N), "dl_linear_packed: residual pointer / stride");
   if (k_split <= 0) k_split = 1;
   DL_REQUIRE(k_split <= 8 && K / 64 >= k_split, "dl_linear_packed: k_split=%d (1..8, <= K / 64)", k_split);
-  DL_REQUIRE(k_split == 1 || (workspace && ((uintptr_t)workspace & 255) == 0), "dl_linear_packed: k_split > 1 needs a 256-byte aligned workspace (dl_linear_packed_workspace_bytes, zeroed once)");
+  DL_REQUIRE(k_split == 1 || epilogue == LP_EPI_PARTS || (workspace && ((uintptr_t)workspace & 255) == 0),
+             "dl_linear_packed: k_split > 1 needs a 256-byte aligned workspace (dl_linear_packed_workspace_bytes, zeroed once)");
   LpParams p;
   p.X = X;
   p.ldx = ldx;
@@ -570,6 +597,7 @@ extern "C" int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const 
   p.n_units = N / 16;
   p.S = K / 32;
   p.x_packed = x_packed;
+  p.y_packed = y_packed;
   const int nu = units_per_workgroup > 0 ? units_per_workgroup : lp_pick_units(p.n_units, epilogue, k_split);
   p.n_sets = (p.n_units + nu - 1) / nu;
   p.k_split = k_split;

@@ -609,7 +609,8 @@ def linear_splitk(a, w, parts, n_slices):
     return parts[: n_slices * M * N].view(n_slices, M, N)
 
 
-LP_STORE, LP_SILU_PAIR, LP_RESID = 0, 1, 2
+LP_STORE, LP_SILU_PAIR, LP_RESID, LP_PARTS = 0, 1, 2, 3
+LP_Y_PACKED = 16
 LP_MAX_ROWS = 256
 
 
@@ -658,10 +659,12 @@ def linear_packed_workspace(M, N, K, device, epilogue=LP_STORE, units_per_workgr
     return torch.zeros(max(need, 256), dtype=torch.uint8, device=device) if need else None
 
 
-def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_workgroup=0, k_split=1, workspace=None, err=None, x_packed_mk=None, _ablate=0):
+def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_workgroup=0, k_split=1, workspace=None, err=None, x_packed_mk=None, y_packed=False, _ablate=0):
     """out = x [M,K] @ W^T on the packed copy wp of W [N,K] (pack_weight_tiles).  epilogue LP_SILU_PAIR: out [M, N/2] = silu(gate) * up
     (wp packed with gate_up_pairs); LP_RESID: out = resid + x W^T (resid may be out).  x_packed_mk=(M, K): x is pack_x_tiles' output.
-    k_split > 1: that many workgroups share each unit set's k range (linear_packed_workspace)."""
+    k_split > 1: that many workgroups share each unit set's k range (linear_packed_workspace).
+    epilogue LP_PARTS: out is an fp32 tensor [k_split, M, N] of partial sums (no workspace).  y_packed (LP_STORE / LP_SILU_PAIR): out is a flat tensor in
+    fragment order, the x_packed_mk input of the next linear_packed."""
     _dev(x, wp, out, resid, workspace, err)
     if x_packed_mk is None:
         assert x.dim() == 2 and x.stride(1) == 1
@@ -673,20 +676,30 @@ def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_w
         assert x.is_contiguous() and x.numel() * x.element_size() >= int(lib().dl_packed_x_bytes(M, K))
     assert wp.numel() == N * K and wp.dtype == x.dtype
     n_out = N // 2 if epilogue == LP_SILU_PAIR else N
-    if out is None:
-        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
-    assert out.dim() == 2 and out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == x.dtype
+    if epilogue == LP_PARTS:
+        if out is None:
+            out = torch.empty((k_split, M, N), dtype=torch.float32, device=x.device)
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= k_split * M * N
+        ldy = N
+    elif y_packed:
+        out = _packed_out(M, n_out, x, out)
+        ldy = n_out
+    else:
+        if out is None:
+            out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+        assert out.dim() == 2 and out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == x.dtype
+        ldy = out.stride(0)
     if epilogue == LP_RESID:
         assert resid is not None and resid.shape == (M, N) and resid.stride(1) == 1 and resid.dtype == x.dtype
-    if k_split > 1:
+    if k_split > 1 and epilogue != LP_PARTS:
         need = int(lib().dl_linear_packed_workspace_bytes(M, N, K, int(epilogue), int(units_per_workgroup), int(k_split)))
         assert workspace is not None and workspace.numel() * workspace.element_size() >= need, "linear_packed: workspace missing / too small"
     _check(
-        lib().dl_linear_packed(_p(x), ldx, int(x_packed_mk is not None), _p(wp), _p(out), out.stride(0), _p(resid), 0 if resid is None else resid.stride(0), M, N, K,
-                               int(epilogue) | (int(_ablate) << 8), int(units_per_workgroup), int(k_split), _p(workspace), _p(err), dtype_code(x.dtype), _stream()),
+        lib().dl_linear_packed(_p(x), ldx, int(x_packed_mk is not None), _p(wp), _p(out), ldy, _p(resid), 0 if resid is None else resid.stride(0), M, N, K,
+                               int(epilogue) | (LP_Y_PACKED if y_packed else 0) | (int(_ablate) << 8), int(units_per_workgroup), int(k_split), _p(workspace), _p(err), dtype_code(x.dtype), _stream()),
         "dl_linear_packed",
     )
-    return out
+    return out[: k_split * M * N].view(k_split, M, N) if epilogue == LP_PARTS else out
 
 
 def gemm_smallm_ok(M, N, K, dtype):

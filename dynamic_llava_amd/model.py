@@ -88,6 +88,7 @@ class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-123
         # rows); gate|up with gate / up tiles interleaved for the SiLU * up epilogue.  +281 MB per 7B layer of 288 GB; the state dict is untouched.
         self.wp_qkv = None
         self.wp_gu = None
+        self.wp_down = None
 
     def pack(self, operand_copies: bool = False):
         a, m = self.self_attn, self.mlp
@@ -100,10 +101,12 @@ class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-123
         I = m.gate_proj.weight.shape[0]
         m.gate_proj.weight.data = self.w_gu[:I]
         m.up_proj.weight.data = self.w_gu[I:]
-        self.wp_qkv = self.wp_gu = None
+        self.wp_qkv = self.wp_gu = self.wp_down = None
         if operand_copies and self.w_qkv.dtype in (torch.bfloat16, torch.float16) and self.w_qkv.shape[1] % 64 == 0 and self.w_qkv.shape[0] % 16 == 0 and I % 16 == 0:
             self.wp_qkv = ops.pack_weight_tiles(self.w_qkv)
             self.wp_gu = ops.pack_weight_tiles(self.w_gu, gate_up_pairs=True)
+            if I % 64 == 0:  # down_proj reads the SiLU * up epilogue's fragment-order output and leaves fp32 partial sums for the residual-add / RMSNorm launch
+                self.wp_down = ops.pack_weight_tiles(m.down_proj.weight.data.contiguous())
 
 
 class _TransformerBlock(nn.Module):  # custom_transformer_layer.py:276-318 (parameters only)
@@ -468,6 +471,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # finalize(), activations handed over in fragment order by the norm launch that produces them).  tools/bench_linear_packed.py, M = 170:
         # q|k|v 36.2 us (two k ranges per unit set) vs the library's 41.4, gate|up + SiLU * up 57.2 vs 64.1.  DL_PACKED_GEMM=0: library GEMMs.
         self.packed_prefill_gemm = os.environ.get("DL_PACKED_GEMM", "1") == "1"
+        self.packed_down_proj = os.environ.get("DL_PACKED_DOWN", "1") == "1"  # down_proj too (partial sums for dl_add_rmsnorm_parts): A/B knob
         self._lp_ws = None   # hand-over workspace of the k-split launches (zeroed once; the kernel leaves its flag words zero)
         self._lp_err = None  # bit 3: a reducing wave of dl_linear_packed gave up waiting
         # split-K slices of the two WIDE projections (q|k|v, gate|up: 768 / 1376 sixteen-neuron wave tiles without any split) on dl_gemm_smallm; 0 = the
@@ -908,14 +912,22 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             else:
                 o = F.linear(attn, layer.self_attn.o_proj.weight)
                 x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps, packed=use_lp)
+            lp_down = use_lp and layer.wp_down is not None and self.packed_down_proj
             if use_lp:  # gate|up with silu(gate) * up in the epilogue: one launch, no [rows, 2 I] round trip
-                act = self._lp_linear(x, total, layer.wp_gu, layer.w_gu.shape[0], h.shape[1], ops.LP_SILU_PAIR)
+                act = self._lp_linear(x, total, layer.wp_gu, layer.w_gu.shape[0], h.shape[1], ops.LP_SILU_PAIR, y_packed=lp_down)
             else:
                 act = ops.silu_mul(F.linear(x, layer.w_gu))
             nw_next = self.model.norm.weight if i + 1 == L else (None if i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"])  # residual add only: layer SL's norm runs after compaction
                                                                else self.model.layers[i + 1].input_layernorm.weight)
             pk_next = nw_next is not None and i + 1 < L and lp_ok(total, self.model.layers[i + 1])  # the next layer's q|k|v reads this norm's output
-            if dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024 and act.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
+            if lp_down:
+                # down_proj on the operand-order copy: 4 k ranges per unit set, fp32 partial sums added in range order by the residual-add / RMSNorm launch
+                I_ = layer.w_gu.shape[0] // 2
+                nu_, ks_ = self._lp_config_parts(h.shape[1] // 16)
+                parts_ = ops.linear_packed(act, layer.wp_down, h.shape[1], out=self._splitk_ws(h.shape[1])[: ks_ * total * h.shape[1]], epilogue=ops.LP_PARTS, units_per_workgroup=nu_,
+                                           k_split=ks_, x_packed_mk=(total, I_))
+                x_new = ops.add_rmsnorm_parts(h, parts_, nw_next, eps, packed=pk_next)
+            elif dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024 and act.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
                 # down_proj at <= 192 packed rows (the compacted layers at B=1): the library streams [H, I] at 1.8 TB/s there; dl_linear_splitk
                 # cuts K into 8 slices and the residual-add / RMSNorm launch adds them in order (tools/bench_linear_splitk.py: 44 vs 54 us)
                 x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(h.shape[1]), 8), nw_next, eps, packed=pk_next)
@@ -948,11 +960,21 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     return nu, ks
         return 8, 1
 
-    def _lp_linear(self, x_pk, rows, wp, N, K, epilogue=ops.LP_STORE):
+    @staticmethod
+    def _lp_config_parts(n_units: int):
+        """(units per workgroup, k ranges) of a partial-sum launch (narrow N: o_proj / down_proj): as many k ranges as keep one workgroup per CU with at
+        most 4 units each -- every CU then pulls 1 / k_split of X through its L1 (256 units at 7B: 4 units x 4 ranges)."""
+        for ks in (8, 4, 2, 1):
+            for nu in (1, 2, 3, 4):
+                if -(-n_units // nu) * ks <= 256 and ks <= 4:
+                    return nu, ks
+        return 4, 1
+
+    def _lp_linear(self, x_pk, rows, wp, N, K, epilogue=ops.LP_STORE, y_packed=False):
         """x [rows, K] in fragment order @ W^T on the operand-order copy wp."""
         nu, ks = self._lp_config(N // 16, epilogue == ops.LP_SILU_PAIR)
         return ops.linear_packed(x_pk, wp, N, epilogue=epilogue, units_per_workgroup=nu, k_split=ks, workspace=self._lp_ws if ks > 1 else None, err=self._lp_err,
-                                 x_packed_mk=(rows, K))
+                                 x_packed_mk=(rows, K), y_packed=y_packed)
 
     def _splitk_ws(self, H):
         """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
@@ -1008,7 +1030,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             "use_hip_graph": self.use_hip_graph, "attn_inkernel_combine": self.attn_inkernel_combine, "device_prompt_layout": self.device_prompt_layout,
             "tp_side_stream": self.tp_side_stream, "gemv_max_decode_batch": self.gemv_max_decode_batch, "smallm_max_decode_batch": self.smallm_max_decode_batch,
             "fuse_qkv_attn": self.fuse_qkv_attn, "fuse_gu_tp": self.fuse_gu_tp, "fused_attn_max_splits": self.fused_attn_max_splits, "gu_grid_cap": self.gu_grid_cap,
-            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm,
+            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,

@@ -369,7 +369,16 @@ int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void* h_out, co
  *   output.  err_flag (may be NULL): bit 3 is set if a reducing wave gave up waiting (never on a healthy launch).
  *   epilogue 0: Y[m][n] = cast(acc); 1 (gate_up_pairs packing): Y[m][i] = cast(cast(silu(cast(gate_i))) * cast(up_i)), Y: [M, N / 2] (DML:328, the
  *   roundings of F.linear followed by dl_silu_mul); 2: Y[m][n] = cast(resid[m][n] + cast(acc)) (DML:1289 / 1295; resid may alias Y).
+ *   3 (DL_LP_PARTS): Y is an fp32 buffer [k_split][M][ldy]: range r of k_split writes its partial sums to slice r (no hand-over, no workspace) for a
+ *   consumer that adds the slices in order (dl_add_rmsnorm_parts; dl_linear_splitk's contract).
+ *   epilogue | DL_LP_Y_PACKED (epilogues 0 and 1): Y is written in dl_pack_x_tiles order (dl_packed_x_bytes(M, n_out) bytes, n_out % 64 == 0) -- the
+ *   x_packed input of the next dl_linear_packed (gate|up + SiLU * up feeding down_proj).
  *   units_per_workgroup: 0 = chosen here (one workgroup per CU), else 1, 2, 3, 4, 6, 8. */
+#define DL_LP_STORE 0
+#define DL_LP_SILU_PAIR 1
+#define DL_LP_RESID 2
+#define DL_LP_PARTS 3
+#define DL_LP_Y_PACKED 16
 /* dl_rmsnorm / dl_add_rmsnorm / dl_add_rmsnorm_parts with `out` written in dl_pack_x_tiles order (dl_packed_x_bytes(rows, H) bytes): the producer of a
  * dl_linear_packed(x_packed = 1) call writes its rows where the consumer's fragments expect them -- no separate packing launch.  rows <= 256,
  * H % 64 == 0, bf16 / f16; w and out are required (the residual-only form has no output to pack); same arithmetic, same roundings. */

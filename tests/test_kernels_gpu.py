@@ -943,6 +943,38 @@ def test_packed_norm_outputs_are_the_row_major_ones_in_fragment_order(ops, dtype
     assert torch.equal(unpack(ops.add_rmsnorm_parts(h1, parts, w, 1e-5, packed=True)), ops.add_rmsnorm_parts(h2, parts, w, 1e-5)) and torch.equal(h1, h2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,H,I,ks,nu", [(170, 4096, 11008, 4, 4), (117, 1024, 2816, 2, 0), (32, 512, 1536, 1, 0), (192, 5120, 13824, 4, 4)])
+def test_linear_packed_fragment_order_output_feeds_the_next_call_and_partial_sums(ops, dtype, M, H, I, ks, nu):
+    """The MLP chain of a prefill layer on dl_linear_packed: gate|up + SiLU * up written in FRAGMENT order (DL_LP_Y_PACKED) is exactly what
+    dl_pack_x_tiles makes of the row-major result, and down_proj with DL_LP_PARTS on that input gives fp32 partial sums [k ranges, M, H] whose sum is
+    the plain call's fp32 accumulation; fed to dl_add_rmsnorm_parts they reproduce library GEMM + dl_add_rmsnorm up to the rounding of the sum."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, H, generator=g).to(dtype).cuda()
+    w_gu = (torch.randn(2 * I, H, generator=g) / math.sqrt(H)).to(dtype).cuda()
+    w_dn = (torch.randn(H, I, generator=g) / math.sqrt(I)).to(dtype).cuda()
+    wp_gu, wp_dn = ops.pack_weight_tiles(w_gu, gate_up_pairs=True), ops.pack_weight_tiles(w_dn)
+    act_row = ops.linear_packed(x, wp_gu, 2 * I, epilogue=ops.LP_SILU_PAIR)
+    act_pk = ops.linear_packed(x, wp_gu, 2 * I, epilogue=ops.LP_SILU_PAIR, y_packed=True)
+    rows_pk = torch.equal(act_pk[: ops.pack_x_tiles(act_row).numel()], ops.pack_x_tiles(act_row))
+    if not rows_pk:  # rows past M are not written by the epilogue (dl_pack_x_tiles repeats row M - 1 there): compare the rows that exist
+        tiles = 4 * -(-(-(-M // 16)) // 4)
+        un = lambda p_: p_[: tiles * 16 * I].view(I // 64, tiles, 2, 4, 16, 8).permute(1, 4, 0, 2, 3, 5).reshape(tiles * 16, I)[:M]
+        assert torch.equal(un(act_pk), act_row)
+    parts = ops.linear_packed(act_pk, wp_dn, H, epilogue=ops.LP_PARTS, units_per_workgroup=nu, k_split=ks, x_packed_mk=(M, I))
+    assert parts.shape == (ks, M, H) and parts.dtype == torch.float32
+    ref = F.linear(act_row.float(), w_dn.float())
+    assert float((parts.sum(0) - ref).abs().max()) <= 3e-5 * math.sqrt(I / 1024 + 1) * max(1.0, float(ref.abs().max()))
+    assert torch.equal(parts, ops.linear_packed(act_pk, wp_dn, H, epilogue=ops.LP_PARTS, units_per_workgroup=nu, k_split=ks, x_packed_mk=(M, I)))
+    h0 = torch.randn(M, H, generator=g).to(dtype).cuda()
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype).cuda()
+    h1, h2 = h0.clone(), h0.clone()
+    x1 = ops.add_rmsnorm_parts(h1, parts.contiguous(), nw, 1e-5)
+    x2 = ops.add_rmsnorm(h2, ref.to(dtype), nw, 1e-5)
+    assert float((h1.float() - h2.float()).abs().max()) <= 2 * ULP[dtype] * float(h2.float().abs().max())
+    _close_ulp(x1, x2, dtype, 2.0, atol=2e-2)
+
+
 def test_linear_packed_rejects_bad_arguments(ops):
     x = torch.zeros(8, 128, dtype=torch.bfloat16, device="cuda")
     w = torch.zeros(64, 128, dtype=torch.bfloat16, device="cuda")

@@ -20,8 +20,8 @@ NB = 6
 H, I = (4096, 11008) if args.model == "7b" else (5120, 13824)
 SHAPES = [("qkv", 3 * H, H, ops.LP_STORE), ("o", H, H, ops.LP_STORE), ("gate|up", 2 * I, H, ops.LP_STORE), ("gate|up+silu", 2 * I, H, ops.LP_SILU_PAIR), ("down", H, I, ops.LP_STORE)]
 # (units per workgroup, k_split) candidates per shape
-CAND = {"qkv": [(3, 1), (6, 2), (3, 2), (6, 4), (4, 2)], "o": [(1, 1), (2, 2), (4, 4), (2, 4), (8, 8), (4, 8)], "gate|up": [(6, 1), (6, 2), (8, 2), (8, 1)], "gate|up+silu": [(6, 1), (6, 2), (8, 2)],
-        "down": [(1, 1), (2, 2), (4, 4), (2, 4), (8, 8), (4, 8)]}
+CAND = {"qkv": [(3, 1), (6, 2), (4, 2)], "o": [(1, 1), (2, 2), (4, 4), (2, 4)], "gate|up": [(6, 1), (4, 1)], "gate|up+silu": [(6, 1), (4, 1)],
+        "down": [(1, 1), (2, 2), (4, 4), (2, 4)]}
 
 
 def timed(fns, reps=2):
@@ -65,7 +65,7 @@ for M in [int(v) for v in args.m.split(",")]:
         line = f"M={M:3d} {name:13s} [{N},{K}] {mb:6.1f} MB: library {t_lib:6.2f}us ({mb / t_lib:4.2f} TB/s)"
         cands = CAND[name] if args.sweep else CAND[name][:2]
         for nu, ksp in cands:
-            for xp in ((1, 0) if args.sweep else (1,)):
+            for xp, xbc in (((1, 0), (0, 0)) if args.sweep else ((1, 0),)):
                 wsb = ops.linear_packed_workspace(M, N, K, dev, epi, nu, ksp)
                 kw = dict(epilogue=epi, units_per_workgroup=nu, k_split=ksp, workspace=wsb, err=err_flag)
                 xin, mk = (xpk, (M, K)) if xp else (x, None)
@@ -78,8 +78,8 @@ for M in [int(v) for v in args.m.split(",")]:
                 err = float((got - ref).abs().max() / ref.abs().max())
                 same = bool(torch.equal(got, got2))
                 t = timed([lambda wp=wp: ops.linear_packed(xin, wp, N, out=out, x_packed_mk=mk, **kw) for wp in wps])
-                rec[f"nu{nu}_ks{ksp}_xp{xp}_us"] = t
-                line += f" | nu={nu} ks={ksp}{'' if xp else ' rowX'}: {t:6.2f}us ({mb / t:4.2f} TB/s, err {err:.1e}{'' if same else ' NONDET'})"
+                rec[f"nu{nu}_ks{ksp}_xp{xp}_xbc{xbc}_us"] = t
+                line += f" | nu={nu} ks={ksp}{'' if xp else ' rowX'}{' v1' if xbc else ''}: {t:6.2f}us ({mb / t:4.2f} TB/s, err {err:.1e}{'' if same else ' NONDET'})"
         if args.ablate and not pair and 128 < M <= 192:
             for ab, lab in ((1, "noMFMA"), (2, "noX"), (7, "loader-only")):
                 for nu, ksp in [c for c in CAND[name] if c[0] in (3, 6)][:2]:

@@ -58,6 +58,37 @@ __global__ __launch_bounds__(1024) void mixed(const uint32_t* __restrict__ buf, 
   if (acc.x == 0x12345678u) out[threadIdx.x] = acc.y ^ acc.z ^ acc.w;
 }
 
+// mode 4: like mode 3, but the L2-hit side is LDS-DMA too (waves 2 .. 2 + n_hit): what dl_linear_packed would get if X went through the loaders
+__global__ __launch_bounds__(1024) void mixed_dma(const uint32_t* __restrict__ buf, uint32_t bytes, const char* __restrict__ big, int iters, int hbm_iters, long long* t_hit) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x >> 6) - 2;
+  const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (uint32_t)w * 16384u;
+  if (w < 2) {
+    const GLOBAL char* base = (const GLOBAL char*)big + ((size_t)blockIdx.x * 2 + w) * (size_t)hbm_iters * 8192;
+    for (int it = 0; it < hbm_iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dma_piece_nt(base, (uint32_t)it * 8192u + u * 1024u + lane * 16u, ring + (uint32_t)__builtin_amdgcn_readfirstlane(((it & 1) * 8 + u)) * 1024u);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  const uint32_t pieces = bytes / 1024;
+  uint32_t pc = ((w - 2) + blockIdx.x * 7) % pieces;
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      dma_piece((const GLOBAL void*)buf, pc * 1024u + lane * 16u, ring + (uint32_t)__builtin_amdgcn_readfirstlane(((it & 1) * 8 + u)) * 1024u);
+      pc += nw;
+      pc = pc >= pieces ? pc - pieces : pc;
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && w == 2) t_hit[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void l2bw(const uint32_t* __restrict__ buf, uint32_t bytes, int iters, uint32_t* out) {
   extern __shared__ unsigned char smem[];
@@ -140,6 +171,22 @@ int main() {
       double avg = 0; for (auto v : th) avg += (double)v; avg /= 256;
       const double hit_bytes = (double)hit_waves * it_hit * 8 * 1024, hbm_bytes = 2.0 * hbm_iters * 8192;
       printf("mode 3 hit waves %d, HBM %.1f MiB/CU: launch %.1f us; hit side: %.0f memtime ticks per CU for %.0f KiB -> %.2f B/tick/CU; HBM side %.2f TB/s over the launch\n", hit_waves, hbm_bytes / 1048576.0, ms * 1e3, avg, hit_bytes / 1024, hit_bytes / avg, 256 * hbm_bytes / ms / 1e9);
+    }
+  }
+  hipFuncSetAttribute((const void*)mixed_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int hit_waves : {1, 2, 4}) {
+    for (int hbm_iters : {0, 200}) {
+      const int it_hit = 600;
+      for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(mixed_dma, dim3(256), dim3((hit_waves + 2) * 64), (hit_waves + 2) * 16384, 0, buf, bytes, big, it_hit, hbm_iters, t_hit);
+      hipEventRecord(a);
+      hipLaunchKernelGGL(mixed_dma, dim3(256), dim3((hit_waves + 2) * 64), (hit_waves + 2) * 16384, 0, buf, bytes, big, it_hit, hbm_iters, t_hit);
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b);
+      std::vector<long long> th(256); hipMemcpy(th.data(), t_hit, 256 * 8, hipMemcpyDeviceToHost);
+      double avg = 0; for (auto v : th) avg += (double)v; avg /= 256;
+      const double hit_bytes = (double)hit_waves * it_hit * 8 * 1024, hbm_bytes = 2.0 * hbm_iters * 8192;
+      printf("mode 4 (DMA hit side) hit waves %d, HBM %.1f MiB/CU: launch %.1f us; hit side: %.0f ticks per CU for %.0f KiB -> %.2f B/tick/CU; HBM side %.2f TB/s over the launch; total %.1f GB/s per CU\n", hit_waves,
+             hbm_bytes / 1048576.0, ms * 1e3, avg, hit_bytes / 1024, hit_bytes / avg, 256 * hbm_bytes / ms / 1e9, (hit_bytes + hbm_bytes) / ms / 1e6);
     }
   }
   return 0;
