@@ -417,6 +417,17 @@ class _DecodeState:
             ops.gemm_smallm_ok(B, n, k, dtype) for n, k in (((nH + 2 * nKV) * d, H), (H, nH * d), (2 * I, H), (H, I), (V, H))
         )
         self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
+        # round 5: decode batches past dl_gemm_smallm's range (25..32 rows: configs[2] / [3]) run their MLP on dl_linear_packed -- gate|up with the SiLU * up
+        # epilogue writing `act` in fragment order, down_proj leaving 4 k ranges of fp32 partial sums for the residual-add / RMSNorm launch
+        # (tools/bench_linear_packed.py, M = 32: 38.4 vs 44.8 us and 25.5 vs 31.7 us against the library); q|k|v and o_proj stay on the library (a tie / slower)
+        l0 = model.model.layers[0]
+        self.use_lp_mlp = (not self.use_gemv and not self.use_smallm and B <= 32 and model.packed_decode_mlp and getattr(l0, "wp_gu", None) is not None
+                           and getattr(l0, "wp_down", None) is not None)
+        if self.use_lp_mlp:
+            n_el = lambda cols: int(ops.lib().dl_packed_x_bytes(B, cols)) // 2
+            self.x_pk = torch.empty(n_el(H), dtype=dtype, device=device)
+            self.act_pk = torch.empty(n_el(I), dtype=dtype, device=device)
+            self.lp_parts = torch.empty(4 * B * H, dtype=torch.float32, device=device)
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
         # dl_gemv_gu_tp's granules (batch 1; the predictor's stage 1 stages the row in LDS: H <= 5120)
         tpm = getattr(model.model, "output_text_score_predictor", None)
@@ -472,6 +483,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # q|k|v 36.2 us (two k ranges per unit set) vs the library's 41.4, gate|up + SiLU * up 57.2 vs 64.1.  DL_PACKED_GEMM=0: library GEMMs.
         self.packed_prefill_gemm = os.environ.get("DL_PACKED_GEMM", "1") == "1"
         self.packed_down_proj = os.environ.get("DL_PACKED_DOWN", "1") == "1"  # down_proj too (partial sums for dl_add_rmsnorm_parts): A/B knob
+        self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 25..32: gate|up + SiLU * up and down_proj on dl_linear_packed
         self._lp_ws = None   # hand-over workspace of the k-split launches (zeroed once; the kernel leaves its flag words zero)
         self._lp_err = None  # bit 3: a reducing wave of dl_linear_packed gave up waiting
         # split-K slices of the two WIDE projections (q|k|v, gate|up: 768 / 1376 sixteen-neuron wave tiles without any split) on dl_gemm_smallm; 0 = the
@@ -1030,7 +1042,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             "use_hip_graph": self.use_hip_graph, "attn_inkernel_combine": self.attn_inkernel_combine, "device_prompt_layout": self.device_prompt_layout,
             "tp_side_stream": self.tp_side_stream, "gemv_max_decode_batch": self.gemv_max_decode_batch, "smallm_max_decode_batch": self.smallm_max_decode_batch,
             "fuse_qkv_attn": self.fuse_qkv_attn, "fuse_gu_tp": self.fuse_gu_tp, "fused_attn_max_splits": self.fused_attn_max_splits, "gu_grid_cap": self.gu_grid_cap,
-            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj,
+            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_decode_mlp": self.packed_decode_mlp,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,
@@ -1157,6 +1169,16 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws, n_slices=self.smallm_wide_slices)
                 ops.silu_mul_parts(parts, st.act)
                 parts, _ = ops.gemm_smallm_parts(st.act, layer.mlp.down_proj.weight, ws)
+                ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)
+            elif st.use_lp_mlp:
+                H_, I2 = st.h.shape[1], layer.w_gu.shape[0]
+                o = F.linear(st.attn, layer.self_attn.o_proj.weight)
+                ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x_pk, packed=True)
+                nu_g, ks_g = self._lp_config(I2 // 16, True)
+                ops.linear_packed(st.x_pk, layer.wp_gu, I2, out=st.act_pk, epilogue=ops.LP_SILU_PAIR, units_per_workgroup=nu_g, k_split=ks_g, workspace=self._lp_ws if ks_g > 1 else None,
+                                  err=self._lp_err, x_packed_mk=(st.B, H_), y_packed=True)
+                nu_d, ks_d = self._lp_config_parts(H_ // 16)
+                parts = ops.linear_packed(st.act_pk, layer.wp_down, H_, out=st.lp_parts, epilogue=ops.LP_PARTS, units_per_workgroup=nu_d, k_split=ks_d, x_packed_mk=(st.B, I2 // 2))
                 ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)
             else:
                 o = F.linear(st.attn, layer.self_attn.o_proj.weight)
