@@ -508,13 +508,28 @@ def measured_ceilings(device):
     src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
     dst = torch.empty_like(src)
     ms_copy = min(event_time_ms(lambda: dst.copy_(src), 10, 3) for _ in range(2))
+    # a READ-ONLY stream beside it (what a weight-streaming kernel does): this package's own dl_gemv over a [2^17, 4096] bf16 matrix (1 GiB), and a library
+    # reduction over the same bytes -- the copy's read + write mix is not the ceiling of a pure read stream
+    read = {}
+    try:
+        from dynamic_llava_amd import hip_ops as ops
+
+        wbig = src.view(torch.bfloat16).view(-1, 4096)
+        xv = torch.randn(1, 4096, device=device, dtype=torch.bfloat16)
+        yv = torch.empty(1, wbig.shape[0], device=device, dtype=torch.bfloat16)
+        ms_gemv = min(event_time_ms(lambda: ops.gemv(wbig, yv, x=xv), 10, 3) for _ in range(2))
+        ms_sum = min(event_time_ms(lambda: src.view(torch.int32).sum(), 10, 3) for _ in range(2))
+        read = {"hbm_read_dl_gemv_GBps": round(n / ms_gemv / 1e6, 1), "hbm_read_torch_sum_GBps": round(n / ms_sum / 1e6, 1),
+                "hbm_read": "1 GiB read once: dl_gemv [262144, 4096] bf16 at batch 1 / torch.sum over the same bytes as int32"}
+    except Exception as e:  # noqa: BLE001
+        read = {"hbm_read_error": repr(e)}
     N = 8192
     a = torch.randn(N, N, device=device, dtype=torch.bfloat16)
     b = torch.randn(N, N, device=device, dtype=torch.bfloat16)
     c = torch.empty(N, N, device=device, dtype=torch.bfloat16)
     ms_gemm = min(event_time_ms(lambda: torch.mm(a, b, out=c), 10, 3) for _ in range(2))
     return {"hbm_copy_GBps": round(2 * n / ms_copy / 1e6, 1), "hbm_copy": "torch copy_ of 1 GiB (uint8, 16-byte accesses): (read + written bytes) / time",
-            "hbm_spec_GBps": HBM_PEAK_GBS, "hbm_copy_frac_of_spec": round(2 * n / ms_copy / 1e6 / HBM_PEAK_GBS, 3),
+            "hbm_spec_GBps": HBM_PEAK_GBS, "hbm_copy_frac_of_spec": round(2 * n / ms_copy / 1e6 / HBM_PEAK_GBS, 3), **read,
             "bf16_gemm_TFLOPs": round(2 * N**3 / ms_gemm / 1e9, 1), "bf16_gemm": f"torch.mm {N}x{N}x{N} bf16 (hipBLASLt)", "bf16_dense_spec_TFLOPs": 2500.0,
             "bf16_gemm_frac_of_spec": round(2 * N**3 / ms_gemm / 1e9 / 2500.0, 3)}
 

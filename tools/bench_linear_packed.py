@@ -80,6 +80,23 @@ for M in [int(v) for v in args.m.split(",")]:
                 t = timed([lambda wp=wp: ops.linear_packed(xin, wp, N, out=out, x_packed_mk=mk, **kw) for wp in wps])
                 rec[f"nu{nu}_ks{ksp}_xp{xp}_xbc{xbc}_us"] = t
                 line += f" | nu={nu} ks={ksp}{'' if xp else ' rowX'}{' v1' if xbc else ''}: {t:6.2f}us ({mb / t:4.2f} TB/s, err {err:.1e}{'' if same else ' NONDET'})"
+        if name in ("o", "down"):  # the product's form for the narrow projections: fp32 partial sums per k range, consumed by dl_add_rmsnorm_parts
+            h0 = torch.randn(M, N, device=dev, dtype=dt)
+            nw = torch.ones(N, device=dev, dtype=dt)
+            parts8 = torch.empty(8 * M * N, device=dev, dtype=torch.float32)
+            t_sk = timed([lambda w=w: ops.linear_splitk(x, w, parts8, 8) for w in ws])
+            t_skc = timed([lambda w=w: ops.add_rmsnorm_parts(h0, ops.linear_splitk(x, w, parts8, 8), nw, 1e-5) for w in ws])
+            line += f" | splitk s=8: {t_sk:6.2f}us (+ add_rmsnorm_parts {t_skc:6.2f})"
+            rec["splitk8_us"], rec["splitk8_with_consumer_us"] = t_sk, t_skc
+            for nu, ksp in ((4, 4), (2, 4), (4, 2), (2, 8) if K // 64 >= 8 else (4, 4)):
+                pbuf = torch.empty(ksp * M * N, device=dev, dtype=torch.float32)
+                f = lambda wp: ops.linear_packed(xpk, wp, N, out=pbuf, epilogue=ops.LP_PARTS, units_per_workgroup=nu, k_split=ksp, x_packed_mk=(M, K))
+                got = f(wps[0]).sum(0)
+                err = float((got - ref).abs().max() / ref.abs().max())
+                t = timed([lambda wp=wp: f(wp) for wp in wps])
+                tc = timed([lambda wp=wp: ops.add_rmsnorm_parts(h0, f(wp), nw, 1e-5) for wp in wps])
+                rec[f"parts_nu{nu}_ks{ksp}_us"], rec[f"parts_nu{nu}_ks{ksp}_with_consumer_us"] = t, tc
+                line += f" | PARTS nu={nu} ks={ksp}: {t:6.2f}us (+ consumer {tc:6.2f}, err {err:.1e})"
         if args.ablate and not pair and 128 < M <= 192:
             for ab, lab in ((1, "noMFMA"), (2, "noX"), (7, "loader-only")):
                 for nu, ksp in [c for c in CAND[name] if c[0] in (3, 6)][:2]:

@@ -10,7 +10,8 @@ for db in sys.argv[2:]:
     cur, seen_warm = None, 0
     per_dispatch = collections.OrderedDict()
     for did, name, gx, wx, cname, val, dur, start in rows:
-        per_dispatch.setdefault(did, dict(name=name, grid=gx // max(wx, 1), dur=dur, c={}))["c"][cname] = per_dispatch[did]["c"].get(cname, 0.0) + val
+        d_ = per_dispatch.setdefault(did, dict(name=name, grid=gx // max(wx, 1), dur=dur, c={}))
+        d_["c"][cname] = d_["c"].get(cname, 0.0) + val
     for d in per_dispatch.values():
         if "pack_x_tiles_kernel" in d["name"] and d["grid"] <= 4:  # a marker (the probe's own X packing has a larger grid)
             seen_warm += 1

@@ -8,7 +8,7 @@ R=${1:-r01}
 RAW=/tmp/dl_prof_raw   # raw rocprofv3 databases stay off gpurun_out/ (64 MiB merge limit): only the summaries go there
 rm -rf "$RAW"; mkdir -p gpurun_out "$RAW"
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-rocprofv3 --kernel-trace --stats -d $RAW/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ref-gpu > gpurun_out/bench_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $RAW/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ref-gpu --no-extra-legs > gpurun_out/bench_prof.json 2>/dev/null
 python tools/prof_summary.py "$(find $RAW/prof_bench -name '*.db' | head -1)" 45 > gpurun_out/kernel_stats.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $RAW/pmc_fetch -o p -- python tools/pmc_probe.py > gpurun_out/pmc_fetch.log 2>/dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $RAW/pmc_write -o p -- python tools/pmc_probe.py > gpurun_out/pmc_write.log 2>/dev/null
