@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
   constexpr int kStepBytes = NU * 2048;
 #define LP_STAMP(k_)                                                                                               \
   do {                                                                                                             \
-    if (p.stamps && lane == 0) p.stamps[((int64_t)blockIdx.x * 6 + w) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); \
+    if (p.stamps && lane == 0) p.stamps[((int64_t)blockIdx.x * 10 + w) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
   LP_STAMP(0);
 
@@ -548,9 +548,6 @@ static int lp_pick_units(int n_units, int epilogue, int k_split) {
   return nu;
 }
 
-static long long* g_lp_stamps = nullptr;
-extern "C" void dl_linear_packed_set_stamps(void* buf) { g_lp_stamps = reinterpret_cast<long long*>(buf); }  // measurement hook (tools/lp_timeline.py)
-
 extern "C" int64_t dl_linear_packed_workspace_bytes(int M, int N, int K, int epilogue, int units_per_workgroup, int k_split) {
   if (M <= 0 || M > 256 || N <= 0 || N % 16 || K <= 0 || K % 64 || k_split < 1 || k_split > 8) return -1;
   if (k_split == 1) return 0;
@@ -561,8 +558,8 @@ extern "C" int64_t dl_linear_packed_workspace_bytes(int M, int N, int K, int epi
   return flag_bytes + n_slots * nu * dl::lp_tiles_per_wave(M) * 1024;
 }
 
-extern "C" int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N,
-                                int K, int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int dtype, void* stream) {
+static int lp_entry(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N, int K, int epilogue,
+                    int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, long long* stamps, int dtype, void* stream) {
   using namespace dl;
   DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, "dl_linear_packed: bf16 / fp16 only (dtype %d)", dtype);
   DL_REQUIRE(M >= 0 && N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "dl_linear_packed: M=%d, N=%d (multiple of 16), K=%d (multiple of 64)", M, N, K);
@@ -605,7 +602,7 @@ extern "C" int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const 
   p.flags = reinterpret_cast<int*>(workspace);
   p.parts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (n_slots * 4 + 255) / 256 * 256);
   p.err = err_flag;
-  p.stamps = g_lp_stamps;
+  p.stamps = stamps;
   int rc = DL_ERR_ARG;
   if (dtype == DL_BF16) {
     switch (abl) {
@@ -625,4 +622,17 @@ extern "C" int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const 
   if (rc != DL_OK) return rc;
   DL_CHECK_LAUNCH("dl_linear_packed");
   return DL_OK;
+}
+
+extern "C" int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N,
+                                int K, int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int dtype, void* stream) {
+  return lp_entry(X, ldx, x_packed, Wp, Y, ldy, resid, ldr, M, N, K, epilogue, units_per_workgroup, k_split, workspace, err_flag, nullptr, dtype, stream);
+}
+
+extern "C" int dl_linear_packed_stamped(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M,
+                                        int N, int K, int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int64_t* stamps,
+                                        int dtype, void* stream) {
+  DL_REQUIRE(stamps, "dl_linear_packed_stamped: NULL stamp buffer");
+  return lp_entry(X, ldx, x_packed, Wp, Y, ldy, resid, ldr, M, N, K, epilogue, units_per_workgroup, k_split, workspace, err_flag, reinterpret_cast<long long*>(stamps),
+                  dtype, stream);
 }

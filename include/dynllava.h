@@ -393,6 +393,11 @@ int dl_pack_x_tiles(const void* X, int64_t ldx, void* Xp, int M, int K, int dtyp
 int64_t dl_linear_packed_workspace_bytes(int M, int N, int K, int epilogue, int units_per_workgroup, int k_split);
 int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N, int K,
                      int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int dtype, void* stream);
+/* The same launch with a per-wave timeline (tools/lp_timeline.py): every wave writes s_memtime stamps -- entry, first ring step landed, k loop done, hand-over done,
+ * stores done -- to stamps[(workgroup * 10 + wave) * 8 + k]; stamps: 80 int64 per workgroup, zeroed by the caller.  Results are unchanged. */
+int dl_linear_packed_stamped(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N,
+                             int K, int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int64_t* stamps, int dtype,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,31 +8,28 @@ import torch
 from dynamic_llava_amd import hip_ops as ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="qkv"); ap.add_argument("--nu", type=int, default=3); ap.add_argument("--ks", type=int, default=1); ap.add_argument("--m", type=int, default=170)
-ap.add_argument("--rowx", action="store_true")
+ap.add_argument("--rowx", action="store_true"); ap.add_argument("--silu", action="store_true")
 a = ap.parse_args()
 H, I = 4096, 11008
 N, K = {"qkv": (3 * H, H), "o": (H, H), "gate|up": (2 * I, H), "down": (H, I)}[a.shape]
 dev, dt = "cuda", torch.bfloat16
-lib = ops.lib()
-lib.dl_linear_packed_set_stamps.argtypes = [ctypes.c_void_p]; lib.dl_linear_packed_set_stamps.restype = None
 ws = [torch.randn(N, K, device=dev, dtype=dt) / K**0.5 for _ in range(4)]
-wps = [ops.pack_weight_tiles(w) for w in ws]
+wps = [ops.pack_weight_tiles(w, gate_up_pairs=a.silu) for w in ws]
+EPI = ops.LP_SILU_PAIR if a.silu else ops.LP_STORE
 x = torch.randn(a.m, K, device=dev, dtype=dt); xpk = ops.pack_x_tiles(x)
 wsb = ops.linear_packed_workspace(a.m, N, K, dev, 0, a.nu, a.ks)
 n_wg = -(-(N // 16) // a.nu) * a.ks
-st = torch.zeros(n_wg * 6 * 8, dtype=torch.int64, device=dev)
+st = torch.zeros(n_wg * 10 * 8, dtype=torch.int64, device=dev)
 xin, mk = (x, None) if a.rowx else (xpk, (a.m, K))
-for wp in wps: ops.linear_packed(xin, wp, N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
+for wp in wps: ops.linear_packed(xin, wp, N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb, epilogue=EPI)
 torch.cuda.synchronize()
-lib.dl_linear_packed_set_stamps(ctypes.c_void_p(st.data_ptr()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-ops.linear_packed(xin, wps[1], N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb)
+ops.linear_packed(xin, wps[1], N, x_packed_mk=mk, units_per_workgroup=a.nu, k_split=a.ks, workspace=wsb, epilogue=EPI, stamps=st)
 e1.record()
 torch.cuda.synchronize()
-lib.dl_linear_packed_set_stamps(None)
 launch_us = e0.elapsed_time(e1) * 1e3
-s = st.view(n_wg, 6, 8).cpu().double()
+s = st.view(n_wg, 10, 8).cpu().double()[:, :6]
 # s_memtime counters of different XCDs are not synchronised: every wave is reported RELATIVE TO ITS OWN ENTRY stamp; ticks are converted with the
 # launch's event time over the longest entry -> end span (the shader clock under this load)
 span = (s[:, 2:, 4] - s[:, 2:, 0])
