@@ -20,9 +20,13 @@
 //               back so every 128-byte line is used whole -- through a register ring DX steps deep; nothing of X passes through LDS, and its
 //               vmcnt counts X loads only.  Weight fragments are read from the ring (ds_read_b128, lane-linear: conflict-free), each feeding TPW MFMAs.
 //   one s_barrier per step: "step t has landed" (the loaders waited for it) and "step t - 1 is consumed" (its ring slot is re-filled next).
-// Every weight byte is read from HBM exactly once, no split-K (one fp32 accumulation per output in k order -> deterministic, one rounding), no
-// partials.  Epilogues: plain store, SiLU(gate) * up on a gate / up INTERLEAVED packing (unit 2 j = gate tile j, unit 2 j + 1 = up tile j:
-// both values of a neuron sit in the same lane), residual add.
+// Every weight byte is read from HBM exactly once.  What bounds the launch is not that stream (the loaders alone run at 5.0-5.4 TB/s) but the bytes every CU pulls
+// through its L1: its own weights AND all of X for its k range, ~30 B/clk per CU beside an HBM stream.  Hence k ranges: k_split workgroups
+// share a unit set, each a contiguous range of steps -- X per CU shrinks by k_split, the weights do not grow.  The ranges' fp32 tiles meet either inside the launch
+// (wave c of a partner -> wave c of the last range, fence-free sc1 stores / loads and a flag; the reducer adds in range order: deterministic, one rounding per
+// output) or in the consumer kernel (LP_EPI_PARTS: [k range][M][N] fp32 for dl_add_rmsnorm_parts).
+// Epilogues: plain store, SiLU(gate) * up on a gate / up INTERLEAVED packing (unit 2 j = gate tile j, unit 2 j + 1 = up tile j: both values of a neuron sit in
+// the same lane), residual add, partial sums; the first two can write Y in the fragment order the next call's X wants.
 #include <mutex>
 #include <type_traits>
 
