@@ -94,6 +94,7 @@ struct LpParams {
   int y_packed;       // Y is written in the same fragment order (the next dl_linear_packed's x_packed input): LP_EPI_STORE / LP_EPI_SILU_PAIR
   int x_packed;       // X is Xp[step][tile][k half][lane][8] (dl_pack_x_tiles / a producer's packed output): every fragment one contiguous KiB
   int n_sets, k_split;  // workgroup b: unit set b % n_sets (NU units), k range b / n_sets of k_split
+  int trim256;          // see the k-range bounds in the kernel (0 for LP_EPI_PARTS / one range)
   int* flags;           // [n_sets][k_split - 1][4 consumers]: 1 once that wave's partial tiles are in `parts`; zero before and after every launch
   float* parts;         // [n_sets][k_split - 1][4 consumers][NU x TPW tiles][64 lanes x 4]
   int32_t* err;         // may be NULL: bit 3 is set if a reducing wave gave up waiting for a partner
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
   // dispatched after the partners it waits for, whatever the grid size) adds the partners' fp32 tiles to its own, in range order, and runs the epilogue
   const int set = blockIdx.x % p.n_sets, ks = blockIdx.x / p.n_sets;
   const int all_steps = p.S >> 1;  // 64 k per step
-  const int t_begin = (int)((int64_t)all_steps * ks / p.k_split), t_end = (int)((int64_t)all_steps * (ks + 1) / p.k_split);
+  // In-kernel hand-over: the partners' ranges are `trim256` / 256 shorter than an even share and the reducer's range longer, so that a partner's
+  // tiles are written through and acknowledged (5-6 us) while the reducer still multiplies -- the reducer then pays only for reading them.
+  auto bound = [&](int r) { return r >= p.k_split ? all_steps : (int)((int64_t)all_steps * r * (256 - p.trim256) / (256 * p.k_split)); };
+  const int t_begin = bound(ks), t_end = bound(ks + 1);
   const int steps = t_end - t_begin;
   const int u0 = set * NU;
   DL_LDS unsigned char* ring = (DL_LDS unsigned char*)lp_smem;
@@ -570,6 +574,7 @@ static int lp_entry(const void* X, int64_t ldx, int x_packed, const void* Wp, vo
   if (M == 0) return DL_OK;
   const int abl = (epilogue >> 8) & 0xff;  // measurement builds only (tools/bench_linear_packed.py)
   const int y_packed = (epilogue >> 4) & 1;  // DL_LP_Y_PACKED
+  const int trim_arg = (epilogue >> 16) & 0xff;  // measurement: trim256 + 1 (0 = the default below)
   epilogue &= 0xf;
   DL_REQUIRE(epilogue >= 0 && epilogue <= LP_EPI_PARTS, "dl_linear_packed: epilogue %d", epilogue);
   DL_REQUIRE(!y_packed || epilogue == LP_EPI_STORE || epilogue == LP_EPI_SILU_PAIR, "dl_linear_packed: a fragment-order output goes with epilogue 0 or 1");
@@ -602,6 +607,7 @@ static int lp_entry(const void* X, int64_t ldx, int x_packed, const void* Wp, vo
   const int nu = units_per_workgroup > 0 ? units_per_workgroup : lp_pick_units(p.n_units, epilogue, k_split);
   p.n_sets = (p.n_units + nu - 1) / nu;
   p.k_split = k_split;
+  p.trim256 = (k_split > 1 && epilogue != LP_EPI_PARTS) ? (trim_arg ? trim_arg - 1 : 24) : 0;  // default: partners 9 % short of an even share (tools/bench_lp_trim.py)
   const int64_t n_slots = (int64_t)p.n_sets * (k_split - 1) * kLpConsumers;
   p.flags = reinterpret_cast<int*>(workspace);
   p.parts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (n_slots * 4 + 255) / 256 * 256);

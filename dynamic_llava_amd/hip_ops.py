@@ -660,7 +660,7 @@ def linear_packed_workspace(M, N, K, device, epilogue=LP_STORE, units_per_workgr
     return torch.zeros(max(need, 256), dtype=torch.uint8, device=device) if need else None
 
 
-def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_workgroup=0, k_split=1, workspace=None, err=None, x_packed_mk=None, y_packed=False, _ablate=0, stamps=None):
+def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_workgroup=0, k_split=1, workspace=None, err=None, x_packed_mk=None, y_packed=False, _ablate=0, stamps=None, _trim256=None):
     """out = x [M,K] @ W^T on the packed copy wp of W [N,K] (pack_weight_tiles).  epilogue LP_SILU_PAIR: out [M, N/2] = silu(gate) * up
     (wp packed with gate_up_pairs); LP_RESID: out = resid + x W^T (resid may be out).  x_packed_mk=(M, K): x is pack_x_tiles' output.
     k_split > 1: that many workgroups share each unit set's k range (linear_packed_workspace).
@@ -696,7 +696,7 @@ def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_w
         need = int(lib().dl_linear_packed_workspace_bytes(M, N, K, int(epilogue), int(units_per_workgroup), int(k_split)))
         assert workspace is not None and workspace.numel() * workspace.element_size() >= need, "linear_packed: workspace missing / too small"
     args_ = (_p(x), ldx, int(x_packed_mk is not None), _p(wp), _p(out), ldy, _p(resid), 0 if resid is None else resid.stride(0), M, N, K,
-             int(epilogue) | (LP_Y_PACKED if y_packed else 0) | (int(_ablate) << 8), int(units_per_workgroup), int(k_split), _p(workspace), _p(err))
+             int(epilogue) | (LP_Y_PACKED if y_packed else 0) | (int(_ablate) << 8) | (0 if _trim256 is None else (int(_trim256) + 1) << 16), int(units_per_workgroup), int(k_split), _p(workspace), _p(err))
     if stamps is not None:  # measurement: per-wave timeline (tools/lp_timeline.py)
         assert stamps.dtype == torch.int64 and stamps.is_cuda and stamps.is_contiguous()
         _check(lib().dl_linear_packed_stamped(*args_, _p(stamps), dtype_code(x.dtype), _stream()), "dl_linear_packed_stamped")

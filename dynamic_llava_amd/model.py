@@ -976,9 +976,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     def _lp_config_parts(n_units: int):
         """(units per workgroup, k ranges) of a partial-sum launch (narrow N: o_proj / down_proj): as many k ranges as keep one workgroup per CU with at
         most 4 units each -- every CU then pulls 1 / k_split of X through its L1 (256 units at 7B: 4 units x 4 ranges)."""
-        for ks in (8, 4, 2, 1):
+        for ks in (4, 2, 1):
             for nu in (1, 2, 3, 4):
-                if -(-n_units // nu) * ks <= 256 and ks <= 4:
+                if -(-n_units // nu) * ks <= 256:
                     return nu, ks
         return 4, 1
 
