@@ -182,7 +182,12 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
   const bool x_packed = p.x_packed != 0;
   if (x_packed) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) xp[j] = X + ((int64_t)(c * TPW + j) * 2) * 512 + lane * 8;
+    for (int j = 0; j < TPW; ++j) {
+      // a tile wholly past row M (M = 170: the twelfth) re-reads the last real tile instead of its own padding: the same lines the wave asked for a
+      // moment ago, so nothing more leaves L2 for rows nobody stores
+      const int n_real = (p.M + 15) >> 4, tile = c * TPW + j;
+      xp[j] = X + ((int64_t)(tile < n_real ? tile : n_real - 1) * 2) * 512 + lane * 8;
+    }
   }
   const int64_t x_step = x_packed ? (int64_t)kLpConsumers * TPW * 1024 : 64;
   const int x_half = x_packed ? 512 : 32;

@@ -247,3 +247,29 @@ def test_profile_tools_name_kernels_the_library_really_contains():
     probe = open(os.path.join(root, "tools", "pmc_probe.py")).read()
     for n in set(re.findall(r'"kernel": "([a-z0-9_]+)"', probe)):
         assert n.encode() in blob, f"tools/pmc_probe.py plans a case on `{n}`, which is not a kernel of the built library"
+
+
+def test_linear_packed_launch_shapes_cover_the_chip_once():
+    """Host-side choice of (units per workgroup, k ranges) for dl_linear_packed: at most one workgroup per CU (256), gate|up in gate / up PAIRS, two k ranges
+    for q|k|v where 8 units per workgroup suffice, four for the narrow projections' partial sums (7B and 13B shapes)."""
+    from dynamic_llava_amd.model import DynamicLlavaLlamaForCausalLM as M
+
+    for n_units, pairs, want in ((768, False, (6, 2)), (1376, True, (6, 1)), (960, False, (8, 2)), (1728, True, (8, 1))):
+        nu, ks = M._lp_config(n_units, pairs)
+        assert (nu, ks) == want and -(-n_units // nu) * ks <= 256 and (not pairs or nu % 2 == 0)
+    for n_units, want in ((256, (4, 4)), (320, (3, 2))):
+        nu, ks = M._lp_config_parts(n_units)
+        assert (nu, ks) == want and -(-n_units // nu) * ks <= 256
+
+
+def test_boundary_band_scales_with_the_logit_magnitude():
+    """tests' keep / evict decision band (oracle/fixtures.py): a few ulps of the larger logit, never an absolute number."""
+    import torch
+
+    from oracle import fixtures as fx
+
+    assert fx.boundary_band([0.3, -0.2], torch.bfloat16) == 8 * 2.0**-7  # magnitudes below 1 are held to 1
+    assert fx.boundary_band([16.0, 15.0], torch.bfloat16) == 8 * 2.0**-7 * 16
+    assert fx.boundary_band([16.0, 15.0], torch.float32) < 1e-2
+    assert fx.decision_may_differ([4.0, 3.99], torch.bfloat16, [4.0, 1.0], torch.bfloat16)  # the first pair's gap (0.01) is inside its band (0.25)
+    assert not fx.decision_may_differ([4.0, 3.0], torch.bfloat16, [4.0, 1.0], torch.bfloat16)
