@@ -30,7 +30,7 @@
 #include <mutex>
 #include <type_traits>
 
-#define DL_LP_ABLATIONS 1  // measurement phase
+#define DL_LP_ABLATIONS 1  // also builds the ablated variants tools/bench_linear_packed.py --ablate times (no MFMA / no X loads / loaders alone)
 
 #include "dl_common.h"
 
