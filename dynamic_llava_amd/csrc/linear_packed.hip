@@ -208,7 +208,9 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
 #pragma unroll
       for (int j = 0; j < TPW; ++j) xr[d][j][0] = xr[d][j][1] = lp_u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   }
-  lp_static_for<0, DX - 1>([&](auto d) { load_x(d, d < steps ? (int)d : steps - 1); });  // always DX - 1 steps in flight: the waits count loads
+  // always DX - 1 steps in flight: the waits count loads.  (A trimmed partner range of a very short K can be EMPTY -- K = 128 in two ranges: 0 + 2 steps --
+  // and must not ask for step -1: it re-loads step t_begin, which exists because the last range never is empty, and hands over zeros.)
+  lp_static_for<0, DX - 1>([&](auto d) { load_x(d, d < steps ? (int)d : (steps > 0 ? steps - 1 : 0)); });
 
   lp_f32x4 acc[NU][TPW];
 #pragma unroll

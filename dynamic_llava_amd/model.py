@@ -417,11 +417,11 @@ class _DecodeState:
             ops.gemm_smallm_ok(B, n, k, dtype) for n, k in (((nH + 2 * nKV) * d, H), (H, nH * d), (2 * I, H), (H, I), (V, H))
         )
         self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
-        # round 5: decode batches past dl_gemm_smallm's range (25..32 rows: configs[2] / [3]) run their MLP on dl_linear_packed -- gate|up with the SiLU * up
+        # round 5: decode batches of packed_decode_mlp_min_batch..32 rows (configs[2] / [3]: 32) run their MLP on dl_linear_packed -- gate|up with the SiLU * up
         # epilogue writing `act` in fragment order, down_proj leaving 4 k ranges of fp32 partial sums for the residual-add / RMSNorm launch
-        # (tools/bench_linear_packed.py, M = 32: 38.4 vs 44.8 us and 25.5 vs 31.7 us against the library); q|k|v and o_proj stay on the library (a tie / slower)
+        # (tools/bench_linear_packed.py, M = 32: 38.4 vs 44.8 us and 25.5 vs 31.7 us against the library) -- whatever q|k|v and o_proj run on
         l0 = model.model.layers[0]
-        self.use_lp_mlp = (not self.use_gemv and not self.use_smallm and B <= 32 and model.packed_decode_mlp and getattr(l0, "wp_gu", None) is not None
+        self.use_lp_mlp = (not self.use_gemv and model.packed_decode_mlp_min_batch <= B <= 32 and model.packed_decode_mlp and getattr(l0, "wp_gu", None) is not None
                            and getattr(l0, "wp_down", None) is not None)
         if self.use_lp_mlp:
             n_el = lambda cols: int(ops.lib().dl_packed_x_bytes(B, cols)) // 2
@@ -468,7 +468,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # B <= this (and past the GEMV range): dl_gemm_smallm; larger batches use the library GEMM.  tools/bench_decode_batch.py: 3.87 / 3.95 /
         # 4.24 ms per step at B = 4 / 8 / 16 against 5.1-5.3 on the library; a wash at 20-24 (4.64 / 4.80 vs 4.66 / 4.75) where the hand-written
         # path is kept for being deterministic and batch-invariant; 4 % behind at 32 (5.09 vs 4.89)
-        self.smallm_max_decode_batch = 24
+        self.smallm_max_decode_batch = 32
         self.fuse_qkv_attn = os.environ.get("DL_FUSE_QKV_ATTN", "1") == "1"
         self.fuse_gu_tp = os.environ.get("DL_FUSE_GU_TP", "1") == "1"
         # attention workgroups per head inside the fused launch: up to this many, one per 128 keys of the scheduled bound (DL_QA_SPLITS=1: always one)
@@ -483,6 +483,10 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # q|k|v 36.2 us (two k ranges per unit set) vs the library's 41.4, gate|up + SiLU * up 57.2 vs 64.1.  DL_PACKED_GEMM=0: library GEMMs.
         self.packed_prefill_gemm = os.environ.get("DL_PACKED_GEMM", "1") == "1"
         self.packed_down_proj = os.environ.get("DL_PACKED_DOWN", "1") == "1"  # down_proj too (partial sums for dl_add_rmsnorm_parts): A/B knob
+        # batched decode (4..32 rows), tools/bench_decode_batch.py: the MLP on dl_linear_packed from 4 rows on (B = 16: 4.05 -> 3.79 ms per step, 24: 4.63 -> 4.03), q|k|v too from 16 rows
+        # on (24: 4.05 -> 3.97, 32: 4.21 -> 4.11); o_proj stays on dl_gemm_smallm's partial sums up to 32 rows (against the library GEMM + add: 32 rows 4.20 -> 4.11)
+        self.packed_decode_qkv_min_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_MIN_B", "16"))
+        self.packed_decode_mlp_min_batch = int(os.environ.get("DL_PACKED_DECODE_MLP_MIN_B", "4"))
         self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 25..32: gate|up + SiLU * up and down_proj on dl_linear_packed
         self._lp_ws = None   # hand-over workspace of the k-split launches (zeroed once; the kernel leaves its flag words zero)
         self._lp_err = None  # bit 3: a reducing wave of dl_linear_packed gave up waiting
@@ -1042,7 +1046,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             "use_hip_graph": self.use_hip_graph, "attn_inkernel_combine": self.attn_inkernel_combine, "device_prompt_layout": self.device_prompt_layout,
             "tp_side_stream": self.tp_side_stream, "gemv_max_decode_batch": self.gemv_max_decode_batch, "smallm_max_decode_batch": self.smallm_max_decode_batch,
             "fuse_qkv_attn": self.fuse_qkv_attn, "fuse_gu_tp": self.fuse_gu_tp, "fused_attn_max_splits": self.fused_attn_max_splits, "gu_grid_cap": self.gu_grid_cap,
-            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_decode_mlp": self.packed_decode_mlp,
+            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,
@@ -1153,36 +1157,46 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
         sm, ws = st.use_smallm, st.lin_ws
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
-        ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x)
+        lp_qkv = st.use_lp_mlp and st.B >= self.packed_decode_qkv_min_batch and getattr(self.model.layers[0], "wp_qkv", None) is not None
+        if lp_qkv:
+            nu_q, ks_q = self._lp_config(st.qkv.shape[1] // 16, False)
+        ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x_pk if lp_qkv else st.x, packed=lp_qkv)
         for i, layer in enumerate(self.model.layers):
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
-            qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws, n_slices=self.smallm_wide_slices) if sm else F.linear(st.x, layer.w_qkv)
+            if lp_qkv:
+                qkv = ops.linear_packed(st.x_pk, layer.wp_qkv, st.qkv.shape[1], out=st.qkv, units_per_workgroup=nu_q, k_split=ks_q, workspace=self._lp_ws if ks_q > 1 else None, err=self._lp_err,
+                                        x_packed_mk=(st.B, st.h.shape[1]))
+            else:
+                qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws, n_slices=self.smallm_wide_slices) if sm else F.linear(st.x, layer.w_qkv)
             ns = cache.n_splits(i, st.B * nH)
             ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
                                  call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
+            lp = st.use_lp_mlp
+            x_mlp = st.x_pk if lp else st.x  # the packed MLP reads its input in fragment order: the norm launch writes it that way
             if sm:
                 parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)
-                ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=st.x)
-                parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws, n_slices=self.smallm_wide_slices)
-                ops.silu_mul_parts(parts, st.act)
-                parts, _ = ops.gemm_smallm_parts(st.act, layer.mlp.down_proj.weight, ws)
-                ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)
-            elif st.use_lp_mlp:
-                H_, I2 = st.h.shape[1], layer.w_gu.shape[0]
+                ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
+            else:
                 o = F.linear(st.attn, layer.self_attn.o_proj.weight)
-                ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x_pk, packed=True)
+                ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
+            if lp:
+                H_, I2 = st.h.shape[1], layer.w_gu.shape[0]
                 nu_g, ks_g = self._lp_config(I2 // 16, True)
                 ops.linear_packed(st.x_pk, layer.wp_gu, I2, out=st.act_pk, epilogue=ops.LP_SILU_PAIR, units_per_workgroup=nu_g, k_split=ks_g, workspace=self._lp_ws if ks_g > 1 else None,
                                   err=self._lp_err, x_packed_mk=(st.B, H_), y_packed=True)
                 nu_d, ks_d = self._lp_config_parts(H_ // 16)
                 parts = ops.linear_packed(st.act_pk, layer.wp_down, H_, out=st.lp_parts, epilogue=ops.LP_PARTS, units_per_workgroup=nu_d, k_split=ks_d, x_packed_mk=(st.B, I2 // 2))
+                nxt_pk = lp_qkv and i + 1 < L  # the final norm feeds lm_head: row-major
+                ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x_pk if nxt_pk else st.x, packed=nxt_pk)
+            elif sm:
+                parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws, n_slices=self.smallm_wide_slices)
+                ops.silu_mul_parts(parts, st.act)
+                parts, _ = ops.gemm_smallm_parts(st.act, layer.mlp.down_proj.weight, ws)
                 ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)
             else:
-                o = F.linear(st.attn, layer.self_attn.o_proj.weight)
-                ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=st.x)
                 ops.silu_mul(F.linear(st.x, layer.w_gu), out=st.act)
                 dn = F.linear(st.act, layer.mlp.down_proj.weight)
                 ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
@@ -1284,7 +1298,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         fused_ns = (cache.fused_attn_splits(0, self.fused_attn_max_splits), cache.fused_attn_splits(cfg.num_hidden_layers - 1, self.fused_attn_max_splits)) if (st.B == 1 and st.qa_gran is not None) else (1, 1)
         key = (cache.slab.data_ptr(), cache.t_cap, splits, fused_ns, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
                repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split,
-               self.fused_attn_max_splits, self.qkv_attn_grid_cap, self.gu_grid_cap)
+               self.fused_attn_max_splits, self.qkv_attn_grid_cap, self.gu_grid_cap, self.packed_decode_qkv_min_batch)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)

@@ -199,9 +199,10 @@ def test_c5_13b_width_long_decode_with_eviction():
         assert n_forced <= 2 * fx.MAX_FORCED_DECISIONS, f"{n_forced} decisions of {n_oracle} steps x 2 oracles had to be forced: more than a boundary effect"
 
 
-@pytest.mark.parametrize("B", [4, 7, 16, 20, 24])
+@pytest.mark.parametrize("B", [4, 7, 16, 20, 24, 28, 32])
 def test_mid_batch_decode_smallm_rows_equal_b1(B):
-    """Decode batches 4..24 run on dl_gemm_smallm (+ partial-sum consumers).  Every row of a ragged batch must match its own B=1 run
+    """Decode batches 4..32 run q|k|v (up to 15 rows) and o_proj on dl_gemm_smallm (+ partial-sum consumers), the MLP -- and q|k|v from 16 rows on -- on
+    dl_linear_packed.  Every row of a ragged batch must match its own B=1 run
     (dl_gemv path): greedy tokens and per-step eviction decisions away from decision boundaries, logits in the same noise class."""
     dtype = torch.bfloat16
     cfg = fx.llava7b_config(num_hidden_layers=3)

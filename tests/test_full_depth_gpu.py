@@ -194,7 +194,8 @@ def test_configs2_batch32_ragged_32_layers_two_rows_vs_oracle(model7b):
     feats = model.encode_images(images.cuda())
     forced = fx.make_forced_tokens(cfg, 4, B, seed=6)
     s = _compare_rows_vs_oracle(model, cfg, prompts, feats, [0, 17], forced, "configs[2] 7B x 32 layers, B=32 ragged")
-    assert model._dstate.B == B and not model._dstate.use_gemv and not model._dstate.use_smallm, "B=32 decodes on the library-GEMM + ragged-attention path"
+    st = model._dstate
+    assert st.B == B and not st.use_gemv and st.use_smallm and st.use_lp_mlp, "B=32 decodes on dl_linear_packed (q|k|v, MLP) + dl_gemm_smallm (o_proj) + ragged attention"
     assert sorted(s) == [0, 17] and all(v["steps_compared"] == 5 for v in s.values())
 
 

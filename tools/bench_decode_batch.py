@@ -24,14 +24,18 @@ def run(B, n_new):
 
 batches = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 8, 16, 20, 24, 32]
 for B in batches:
-    for maxb, wide in ((0, 0), (32, 0), (32, 2), (32, 3)):  # 0: dl_gemm_smallm off (library GEMM past the dl_gemv range); wide: split-K slices of q|k|v and gate|up
-        if B <= 3 and (maxb == 0 or wide):
+    # maxb 0: dl_gemm_smallm off (library GEMM past the dl_gemv range); lp_min: from which batch the MLP runs on dl_linear_packed (99: never)
+    for maxb, lp_min, lpq in ((0, 4, 0), (0, 4, 1), (32, 4, 0), (32, 4, 1)):
+        if B <= 3 and (maxb == 0 or lp_min != 99):
             continue
         model.smallm_max_decode_batch = maxb
-        model.smallm_wide_slices = wide
+        model.packed_decode_mlp_min_batch = lp_min
+        model.packed_decode_qkv_min_batch = 4 if lpq else 99
+        wide = 0
         model._dstate = None
         for _ in range(2):
             run(B, 33); run(B, 1)
         t = min(run(B, 65) for _ in range(3)) - min(run(B, 1) for _ in range(3))
         path = "dl_gemv" if B <= model.gemv_max_decode_batch else ("dl_gemm_smallm" if B <= maxb else "library GEMM")
-        print(f"B={B} ({path:12s}{', q|k|v and gate|up in ' + str(wide) + ' slices' if wide and path == 'dl_gemm_smallm' else ''}): {t / 64 * 1e3:6.3f} ms/step  {B * 64 / t:8.1f} tok/s", flush=True)
+        mlp = "MLP on dl_linear_packed" if (B > model.gemv_max_decode_batch and lp_min <= B <= 32) else "MLP on the same"
+        print(f"B={B} (q|k|v, o: {path:14s} {mlp:24s}{', q|k|v too' if lpq else ''}): {t / 64 * 1e3:6.3f} ms/step  {B * 64 / t:8.1f} tok/s", flush=True)
