@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <vector>
 #include <cmath>
+#include <cstring>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define GI32 __attribute__((address_space(1))) int
@@ -24,8 +25,8 @@ __device__ __forceinline__ float bf(uint32_t w, int hi) { return __uint_as_float
 
 // y[n] = sum_k W[n][k] x[k] (bf16 weights, fp32 x and y), one row per wave per pass, K <= 11008
 template <int OVERLAP, int DYN>
-__global__ __launch_bounds__(256) void stream_gemv(const uint16_t* __restrict__ W, const float* x, float* y, int N, int K, const int* wait_flag, int* counter, int* done_flag, int epoch,
-                                                   int* err, unsigned long long* stamps) {
+__global__ __launch_bounds__(256, 4) void stream_gemv(const uint16_t* __restrict__ W, const float* x, float* y, int N, int K, const int* wait_flag, int* counter, int* done_flag, int epoch,
+                                                   int* err, unsigned long long* stamps, int done_tag) {
   __shared__ float xs_raw[10240];  // 40 KiB: four workgroups fill a CU's LDS; x kept as bf16 pairs in the first 22 KB
   uint16_t* xs = reinterpret_cast<uint16_t*>(xs_raw);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void stream_gemv(const uint16_t* __restrict__ 
   // DYN: rows past the first come from a ticket counter, one ticket requested a whole row ahead of its use
   int raw = 0;
   if (DYN && lane == 0) raw = __hip_atomic_fetch_add((GI32*)counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (OVERLAP && wait_flag) {
+  if (OVERLAP == 1 && wait_flag) {
     if (threadIdx.x == 0) {
       int spins = 0;
       while (__hip_atomic_load((const GI32*)wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void stream_gemv(const uint16_t* __restrict__ 
   }
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 1] = wall_clock64();
   // x: past the caches (the previous launch may still be running on other CUs)
-  {
+  if constexpr (OVERLAP != 2) {
     typedef __attribute__((address_space(1))) uint64_t GU64;
     uint64_t t[22];  // K / 2 / 256 <= 21.5: every request in flight before the first use
 #pragma unroll
@@ -70,6 +71,39 @@ __global__ __launch_bounds__(256) void stream_gemv(const uint16_t* __restrict__ 
     for (int i = 0; i < 22; ++i) {
       const int idx = threadIdx.x + i * 256;
       if (idx * 2 < K) reinterpret_cast<uint32_t*>(xs)[idx] = (uint32_t)((t[i] >> 16) & 0xffffu) | (uint32_t)((t[i] >> 32) & 0xffff0000u);
+    }
+  }
+  if constexpr (OVERLAP == 2) {
+    // granules: x[k] = {fp32 bits, tag of the launch that wrote it}; poll until every granule of this thread carries the producer's tag (wait_flag != NULL),
+    // all requests in flight together, bounded
+    typedef __attribute__((address_space(1))) uint64_t GU64;
+    const uint64_t* xg = reinterpret_cast<const uint64_t*>(x);
+    const uint32_t want = (uint32_t)epoch;
+    int spins = 0;
+    for (int c0 = 0; c0 < 44; c0 += 11) {  // 11 granules per thread and pass (registers), each pass polled until its granules carry the tag
+      uint64_t t[11];
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+          const int idx = threadIdx.x + (c0 + i) * 256;
+          t[i] = (uint64_t)want << 32;
+          if (idx < K) t[i] = __hip_atomic_load((const GU64*)(xg + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 11; ++i) ok = ok && (!wait_flag || (uint32_t)(t[i] >> 32) == want);
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 18)) {
+          atomicOr(err, 2);
+          break;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 11; ++i) {
+        const int idx = threadIdx.x + (c0 + i) * 256;
+        if (idx < K) xs[idx] = (uint16_t)((uint32_t)t[i] >> 16);
+      }
     }
   }
   __syncthreads();
@@ -105,7 +139,10 @@ __global__ __launch_bounds__(256) void stream_gemv(const uint16_t* __restrict__ 
     for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) {
       const float r = acc * 0.02f;  // keep the chain's magnitude bounded
-      if (OVERLAP)
+      if (OVERLAP == 2) {
+        typedef __attribute__((address_space(1))) uint64_t GU64;
+        __hip_atomic_store((GU64*)(reinterpret_cast<uint64_t*>(y) + n), ((uint64_t)(uint32_t)done_tag << 32) | __float_as_uint(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (OVERLAP)
         __hip_atomic_store((GU32*)(y + n), __float_as_uint(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else
         y[n] = r;
@@ -114,7 +151,7 @@ __global__ __launch_bounds__(256) void stream_gemv(const uint16_t* __restrict__ 
     first = false;
   }
   if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + 3] = wall_clock64();
-  if (OVERLAP) {
+  if (OVERLAP == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's outputs are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -145,9 +182,9 @@ int main() {
       total += n * 2;
     }
   const int n_k = L * 4;
-  float* buf[3][5];
-  for (int m = 0; m < 3; ++m)
-    for (int i = 0; i < 5; ++i) { CK(hipMalloc(&buf[m][i], 22016 * 4)); CK(hipMemset(buf[m][i], 0, 22016 * 4)); }
+  float* buf[4][5];
+  for (int m = 0; m < 4; ++m)
+    for (int i = 0; i < 5; ++i) { CK(hipMalloc(&buf[m][i], 22016 * 8)); CK(hipMemset(buf[m][i], 0, 22016 * 8)); }
   std::vector<float> x0(22016);
   for (int i = 0; i < 22016; ++i) x0[i] = std::sin(0.37f * i);
   int *flags, *counters, *err;
@@ -168,33 +205,41 @@ int main() {
       const Shape sh = shp[j & 3];
       float* in = buf[mode][j % 5];
       float* out = buf[mode][(j + 1) % 5];
-      hipStream_t st = (mode == 1 && (j & 1)) ? s1 : s0;
+      hipStream_t st = ((mode == 1 || mode == 3) && (j & 1)) ? s1 : s0;
       const int* wf = (mode == 1 && j > 0) ? flags + (j - 1) * 16 : nullptr;
-      if (mode == 1)
-        hipLaunchKernelGGL((stream_gemv<1, 0>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, wf, counters + j * 16, flags + j * 16, epoch, err, st_ptr);
+      if (mode == 3)  // granules: wanted tag = the producer's (launch j - 1 of this chain), own tag on the outputs
+        hipLaunchKernelGGL((stream_gemv<2, 0>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, j > 0 ? flags : (const int*)nullptr, (int*)nullptr, (int*)nullptr, epoch * 64 + j - 1, err,
+                           st_ptr, epoch * 64 + j);
+      else if (mode == 1)
+        hipLaunchKernelGGL((stream_gemv<1, 0>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, wf, counters + j * 16, flags + j * 16, epoch, err, st_ptr, 0);
       else if (mode == 2)
-        hipLaunchKernelGGL((stream_gemv<0, 1>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, (const int*)nullptr, counters + j * 16, (int*)nullptr, epoch, err, st_ptr);
+        hipLaunchKernelGGL((stream_gemv<0, 1>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, (const int*)nullptr, counters + j * 16, (int*)nullptr, epoch, err, st_ptr, 0);
       else
-        hipLaunchKernelGGL((stream_gemv<0, 0>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, (const int*)nullptr, (int*)nullptr, (int*)nullptr, epoch, err, st_ptr);
+        hipLaunchKernelGGL((stream_gemv<0, 0>), dim3(1024), dim3(256), 0, st, W[j], in, out, sh.N, sh.K, (const int*)nullptr, (int*)nullptr, (int*)nullptr, epoch, err, st_ptr, 0);
     }
   };
   int epoch = 0;
-  for (int mode = 0; mode < 3; ++mode) {
-    CK(hipMemcpy(buf[mode][0], x0.data(), 22016 * 4, hipMemcpyHostToDevice));
+  for (int mode = 0; mode < 4; ++mode) {
+    if (mode == 3) {
+      std::vector<uint64_t> g0(22016);
+      for (int i = 0; i < 22016; ++i) { uint32_t b; memcpy(&b, &x0[i], 4); g0[i] = b; }
+      CK(hipMemcpy(buf[3][0], g0.data(), 22016 * 8, hipMemcpyHostToDevice));
+    } else
+      CK(hipMemcpy(buf[mode][0], x0.data(), 22016 * 4, hipMemcpyHostToDevice));
     for (int rep = 0; rep < 3; ++rep) {  // warm
       ++epoch;
-      if (mode == 1) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
+      if (mode == 1 || mode == 3) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
       chain(mode, epoch);
-      if (mode == 1) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
+      if (mode == 1 || mode == 3) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
     }
     CK(hipDeviceSynchronize());
     const int reps = 10;
     CK(hipEventRecord(ea, s0));
     for (int rep = 0; rep < reps; ++rep) {
       ++epoch;
-      if (mode == 1) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
+      if (mode == 1 || mode == 3) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
       chain(mode, epoch);
-      if (mode == 1) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
+      if (mode == 1 || mode == 3) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
     }
     CK(hipEventRecord(eb, s0));
     CK(hipDeviceSynchronize());
@@ -203,9 +248,9 @@ int main() {
     {
       std::vector<unsigned long long> h((size_t)n_k * 4096);
       stamp_now = true; ++epoch;
-      if (mode == 1) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
+      if (mode == 1 || mode == 3) { CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0)); }
       chain(mode, epoch);
-      if (mode == 1) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
+      if (mode == 1 || mode == 3) { CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0)); }
       CK(hipDeviceSynchronize());
       stamp_now = false;
       CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
@@ -234,7 +279,7 @@ int main() {
         }
       }
     }
-    printf("mode %d (%s): %.1f us per chain of %d launches, %.2f us per launch, %.2f TB/s over %.2f GB\n", mode, mode == 1 ? "two streams + device-side flags" : mode == 2 ? "one stream, rows from a ticket counter" : "one stream", ms * 1e3 / reps,
+    printf("mode %d (%s): %.1f us per chain of %d launches, %.2f us per launch, %.2f TB/s over %.2f GB\n", mode, mode == 3 ? "two streams + tagged 8-byte granules" : mode == 1 ? "two streams + device-side flags" : mode == 2 ? "one stream, rows from a ticket counter" : "one stream", ms * 1e3 / reps,
            n_k, us_per_launch, total * reps / (ms * 1e-3) / 1e12, total / 1e9);
   }
   int herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
@@ -248,6 +293,13 @@ int main() {
   for (int i = 0; i < 5; ++i) {
     CK(hipMemcpy(a.data(), buf[0][i], 22016 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), buf[2][i], 22016 * 4, hipMemcpyDeviceToHost));
     for (int k = 0; k < 22016; ++k) maxd = std::fmax(maxd, std::fabs((double)a[k] - b[k]));
+  }
+  {
+    std::vector<uint64_t> gb(22016);
+    for (int i = 0; i < 5; ++i) {
+      CK(hipMemcpy(a.data(), buf[0][i], 22016 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gb.data(), buf[3][i], 22016 * 8, hipMemcpyDeviceToHost));
+      for (int k = 0; k < 22016; ++k) { float v; uint32_t bits = (uint32_t)gb[k]; memcpy(&v, &bits, 4); maxd = std::fmax(maxd, std::fabs((double)a[k] - v)); }
+    }
   }
   printf("error flag %d; max |serial - overlapped| over the chain's buffers %.3g (max |value| %.3g)\n", herr, maxd, maxa);
   return 0;
