@@ -1176,7 +1176,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             lp = st.use_lp_mlp
             x_mlp = st.x_pk if lp else st.x  # the packed MLP reads its input in fragment order: the norm launch writes it that way
-            if sm:
+            if sm:  # (o_proj on dl_linear_packed's partial sums instead: a tie at 8..32 rows, measured and dropped)
                 parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)
                 ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
             else:
