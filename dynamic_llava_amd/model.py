@@ -460,7 +460,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # pixels) and the graph object
         self.max_prefill_graphs = 64
         self.prefill_width_bucket = int(os.environ.get("DL_WIDTH_BUCKET", "16"))  # see _width_bucket
-        self.use_hip_graph = True
+        self.use_hip_graph = os.environ.get("DL_USE_HIP_GRAPH", "1") == "1"  # 0: every launch eager (debugging: e.g. under PYTORCH_NO_CUDA_MEMORY_CACHING=1 to expose out-of-bounds reads)
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
@@ -487,7 +487,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # on (24: 4.05 -> 3.97, 32: 4.21 -> 4.11); o_proj stays on dl_gemm_smallm's partial sums up to 32 rows (against the library GEMM + add: 32 rows 4.20 -> 4.11)
         self.packed_decode_qkv_min_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_MIN_B", "16"))
         self.packed_decode_mlp_min_batch = int(os.environ.get("DL_PACKED_DECODE_MLP_MIN_B", "4"))
-        self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 25..32: gate|up + SiLU * up and down_proj on dl_linear_packed
+        self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 4..32: gate|up + SiLU * up and down_proj on dl_linear_packed
         self._lp_ws = None   # hand-over workspace of the k-split launches (zeroed once; the kernel leaves its flag words zero)
         self._lp_err = None  # bit 3: a reducing wave of dl_linear_packed gave up waiting
         # split-K slices of the two WIDE projections (q|k|v, gate|up: 768 / 1376 sixteen-neuron wave tiles without any split) on dl_gemm_smallm; 0 = the
@@ -1147,9 +1147,11 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             torch.cuda.current_stream().wait_stream(st.tp_stream)  # join before anything reads st.decision
 
     def _decode_step_gemm(self, st: _DecodeState, cache: KVSlabCache):
-        """Decode step for batches past the GEMV range.  B <= smallm_max_decode_batch: dl_gemm_smallm (weights streamed into the
-        matrix cores); its split-K partials are added by the consumer kernels (residual add + RMSNorm, SiLU*up) -- 9 launches per
-        layer.  Larger batches: library GEMMs."""
+        """Decode step for batches past the GEMV range (round 5, `profiles/r05_decode_batch_paths.txt`).  Up to smallm_max_decode_batch (32) rows:
+        o_proj -- and q|k|v below packed_decode_qkv_min_batch (16) rows -- on dl_gemm_smallm (row-major weights streamed into the matrix cores, fp32
+        split-K partials added by the residual-add / RMSNorm launch); from packed_decode_mlp_min_batch (4) rows the MLP, from 16 rows q|k|v too, on
+        dl_linear_packed (operand-order weight copies; SiLU * up in the epilogue, down_proj as 4 k ranges of partial sums; the norm launches write the
+        GEMMs' input in fragment order): 7 launches per layer.  Larger batches, or a model without operand copies: library GEMMs."""
         cfg, sc = self.config, self.config.sparse_config
         nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]

@@ -354,7 +354,7 @@ int dl_gemv_gu_tp(const void* W, int N, int K, const void* h_in, void* h_out, co
                   void* granules, int call_tag, int32_t* err_flag, int dtype, int grid_cap, void* stream);
 
 /* ---- weight-streaming projection on a PRE-PACKED weight copy (round 5): the decoder's nn.Linear calls at a few hundred rows or fewer -- DML:1011-1013
- * (q|k|v), DML:1127 (o_proj), DML:328 (gate / up / down) in the post-compaction prefill layers (M = N' = 117..192) and decode steps of 25..32 rows.
+ * (q|k|v), DML:1127 (o_proj), DML:328 (gate / up / down) in the post-compaction prefill layers (M = N' = 117..192) and decode steps of 4..32 rows.
  * dl_pack_weight_tiles writes W [N,K] (nn.Linear layout, contiguous) once in matrix-core operand order: 16-neuron x 32-k fragments of one contiguous
  * KiB each, Wp[((u S + s) 64 + lane) 8 + j] = W[16 u + lane % 16][32 s + 8 (lane / 16) + j], S = K / 32 (u: unit, s: slab); with gate_up_pairs != 0,
  * W = [gate; up] ([2 I, K]) and unit 2 j holds gate neurons [16 j, 16 j + 16), unit 2 j + 1 the matching up neurons.  N % 16 == 0, K % 64 == 0; bf16 / f16;
