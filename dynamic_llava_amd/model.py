@@ -460,7 +460,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # pixels) and the graph object
         self.max_prefill_graphs = 64
         self.prefill_width_bucket = int(os.environ.get("DL_WIDTH_BUCKET", "16"))  # see _width_bucket
-        self.use_hip_graph = os.environ.get("DL_USE_HIP_GRAPH", "1") == "1"  # 0: every launch eager (debugging: e.g. under PYTORCH_NO_CUDA_MEMORY_CACHING=1 to expose out-of-bounds reads)
+        self.use_hip_graph = True  # (DL_USE_HIP_GRAPH=0 in the environment forces every launch eager, whatever is assigned here: see the property)
         self.attn_inkernel_combine = True  # decode attention: split 0's workgroup merges the split-KV partials inside the launch (no combine launch)
         self.device_prompt_layout = True  # generate(): un-padded one-image-per-row prompts are laid out by a device kernel (no device->host copy)
         self.tp_side_stream = False  # run the text predictor as a parallel graph branch (measured slower: see DESIGN.md)
@@ -962,6 +962,18 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if last_only:
             x = x.index_select(0, p["last_rows"] - p["instruct_drop"])
         return x
+
+    # DL_USE_HIP_GRAPH=0: debugging switch that wins over any assignment -- e.g. the GPU tests under PYTORCH_NO_CUDA_MEMORY_CACHING=1 (every tensor its own
+    # allocation, so that an out-of-bounds read faults instead of landing in a neighbour; stream capture is impossible without the caching allocator)
+    _force_eager = os.environ.get("DL_USE_HIP_GRAPH", "1") == "0"
+
+    @property
+    def use_hip_graph(self):
+        return self._use_hip_graph and not self._force_eager
+
+    @use_hip_graph.setter
+    def use_hip_graph(self, v):
+        self._use_hip_graph = bool(v)
 
     @staticmethod
     def _lp_config(n_units: int, pairs: bool):
