@@ -156,6 +156,62 @@ def decode_attn_roofline(model, label, B, T_list, n_heads, head_dim):
     return {"kernel": name, "shape": label, "n_splits": n_splits, "bytes": nbytes, "us": round(ms * 1e3, 3), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
 
+def linear_packed_roofline(model):
+    """dl_linear_packed (round 5) on the post-compaction prefill shapes (M = 170) and the 32-row decode step's MLP, walking the 30 layers' operand-order weight
+    copies in one hipGraph (cold weights), between events on the launch stream.  Algorithmic bytes: the weights + X + Y."""
+    from dynamic_llava_amd import hip_ops as ops
+
+    layers = [l for l in model.model.layers[2:] if getattr(l, "wp_qkv", None) is not None and getattr(l, "wp_down", None) is not None]
+    if not layers:
+        return []
+    dev, dt = model.device, model.dtype
+    H, I = model.config.hidden_size, model.config.intermediate_size
+    Nq = layers[0].w_qkv.shape[0]
+    out = []
+    for M in (170, 32):
+        x = torch.randn((M, H), device=dev, dtype=dt)
+        xi = torch.randn((M, I), device=dev, dtype=dt) * 0.1
+        xp, xip = ops.pack_x_tiles(x), ops.pack_x_tiles(xi)
+        nu_q, ks_q = model._lp_config(Nq // 16, False)
+        nu_g, ks_g = model._lp_config(2 * I // 16, True)
+        nu_d, ks_d = model._lp_config_parts(H // 16)
+        y_q = torch.empty((M, Nq), device=dev, dtype=dt)
+        act = torch.empty(int(ops.lib().dl_packed_x_bytes(M, I)) // 2, device=dev, dtype=dt)
+        parts = torch.empty(ks_d * M * H, device=dev, dtype=torch.float32)
+        cases = [
+            (f"q|k|v ({nu_q} units x {ks_q} k ranges handed over in the launch)", [Nq, H], Nq * H * 2 + M * H * 2 + M * Nq * 2,
+             lambda l: ops.linear_packed(xp, l.wp_qkv, Nq, out=y_q, units_per_workgroup=nu_q, k_split=ks_q, workspace=model._lp_ws if ks_q > 1 else None, err=model._lp_err, x_packed_mk=(M, H))),
+            (f"gate|up + SiLU*up epilogue, act in fragment order ({nu_g} units)", [2 * I, H], 2 * I * H * 2 + M * H * 2 + M * I * 2,
+             lambda l: ops.linear_packed(xp, l.wp_gu, 2 * I, out=act, epilogue=ops.LP_SILU_PAIR, units_per_workgroup=nu_g, k_split=ks_g, workspace=model._lp_ws if ks_g > 1 else None, err=model._lp_err,
+                                         x_packed_mk=(M, H), y_packed=True)),
+            (f"down_proj, fp32 partial sums ({nu_d} units x {ks_d} k ranges)", [H, I], H * I * 2 + M * I * 2 + ks_d * M * H * 4,
+             lambda l: ops.linear_packed(xip, l.wp_down, H, out=parts, epilogue=ops.LP_PARTS, units_per_workgroup=nu_d, k_split=ks_d, x_packed_mk=(M, I))),
+        ]
+        for name, shape, nbytes, fn in cases:
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                fn(layers[0])
+            torch.cuda.current_stream().wait_stream(s_)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for l in layers:
+                    fn(l)
+            g.replay()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(5):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) / (5 * len(layers)) * 1e3
+            out.append({"kernel": "dl_linear_packed " + name, "shape": f"M={M} x {shape} bf16, {len(layers)} layers' weight copies in one graph", "bytes": nbytes, "us": round(us, 3),
+                        "achieved": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)})
+    model.check_device_errors()
+    return out
+
+
 def gemv_roofline(model):
     """dl_gemv on the decode step's four weight shapes, walking all 32 layers' weights (13 GB >> 256 MB Infinity Cache)."""
     from dynamic_llava_amd import hip_ops as ops
@@ -713,7 +769,7 @@ def _main(args, partial):
         decode_attn_roofline(model, "configs[2]-like: B=32 ragged T~U[200,900]", 32, [200 + (i * 701) % 700 for i in range(32)], nH, d),
         decode_attn_roofline(model, "configs[4]-like: 13B heads (40x128), B=1, T=2048", 1, [2048], 40, d),
         decode_attn_roofline(model, "B=32, T=2048", 32, [2048] * 32, nH, d),
-    ] + gemv_shapes + other_kernel_rooflines(model, n_prompt)
+    ] + gemv_shapes + linear_packed_roofline(model) + other_kernel_rooflines(model, n_prompt)
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_probe.py under rocprofv3 --pmc, see profiles/)
         import glob
