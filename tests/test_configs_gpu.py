@@ -199,13 +199,13 @@ def test_c5_13b_width_long_decode_with_eviction():
         assert n_forced <= 2 * fx.MAX_FORCED_DECISIONS, f"{n_forced} decisions of {n_oracle} steps x 2 oracles had to be forced: more than a boundary effect"
 
 
-@pytest.mark.parametrize("B", [4, 7, 16, 20, 24, 28, 32])
-def test_mid_batch_decode_smallm_rows_equal_b1(B):
+@pytest.mark.parametrize("B,width", [(4, "7b"), (7, "7b"), (16, "7b"), (20, "7b"), (24, "7b"), (28, "7b"), (32, "7b"), (12, "13b"), (32, "13b")])
+def test_mid_batch_decode_smallm_rows_equal_b1(B, width):
     """Decode batches 4..32 run q|k|v (up to 15 rows) and o_proj on dl_gemm_smallm (+ partial-sum consumers), the MLP -- and q|k|v from 16 rows on -- on
     dl_linear_packed.  Every row of a ragged batch must match its own B=1 run
     (dl_gemv path): greedy tokens and per-step eviction decisions away from decision boundaries, logits in the same noise class."""
     dtype = torch.bfloat16
-    cfg = fx.llava7b_config(num_hidden_layers=3)
+    cfg = fx.llava7b_config(num_hidden_layers=3) if width == "7b" else fx.llava13b_config(num_hidden_layers=3)  # 13B: 8 units per workgroup, down_proj in 3 units x 2 k ranges
     cfg.vocab_size = 4096
     sd = fx.make_state_dict(cfg, seed=11, predictor_gain=50.0)
     model = _build(cfg, sd, dtype)
@@ -213,7 +213,7 @@ def test_mid_batch_decode_smallm_rows_equal_b1(B):
     g = torch.Generator().manual_seed(5)
     n_q = torch.randint(8, 40, (B,), generator=g).tolist()
     prompts = [fx.make_prompt(cfg, 35, n_q[b], seed=20 + b) for b in range(B)]
-    feats = torch.randn(B, 576, 4096, generator=g).to(dtype)
+    feats = torch.randn(B, 576, cfg.hidden_size, generator=g).to(dtype)
     W = max(p.shape[0] for p in prompts)
     ids = torch.zeros(B, W, dtype=torch.long)
     am = torch.zeros(B, W, dtype=torch.long)
@@ -233,7 +233,7 @@ def test_mid_batch_decode_smallm_rows_equal_b1(B):
         dec_b.append(model.debug_records["text_decision"].cpu().clone())
         tl = model.debug_records["text_logit"].cpu()
         gap_b.append((tl[:, 0] - tl[:, 1]).abs())
-    assert model._dstate.use_smallm and not model._dstate.use_gemv, "this batch size must run on dl_gemm_smallm"
+    assert model._dstate.use_smallm and model._dstate.use_lp_mlp and not model._dstate.use_gemv, "this batch size must run on dl_gemm_smallm (o_proj) + dl_linear_packed (MLP)"
     lens_b = [t.clone() for t in pkv[1]]
     for b in sorted({0, B // 2, B - 1}):
         o1 = model(prompts[b][None].cuda(), image_features=feats[b : b + 1].cuda())

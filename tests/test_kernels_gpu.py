@@ -616,7 +616,7 @@ def test_attn_prefill_cached_chunk_on_slab(ops, dtype, nH, nKV, d, Lq):
     "M,N,K,n_slices,wg_waves",
     [(32, 4096, 4096, 0, 0), (16, 12288, 4096, 1, 4), (5, 22016, 4096, 0, 8), (8, 4096, 11008, 0, 0), (32, 4096, 11008, 0, 4), (17, 200, 512, 2, 0),
      (1, 64, 256, 0, 0), (9, 132, 768, 3, 8), (32, 32000, 4096, 0, 0), (24, 1000, 1280, 1, 0),
-     (8, 15360, 5120, 0, 0), (16, 27648, 5120, 0, 0), (6, 5120, 13824, 0, 0)],  # last three: LLaVA-1.5-13B projections
+     (8, 15360, 5120, 0, 0), (16, 27648, 5120, 0, 0), (6, 5120, 13824, 0, 0), (32, 5120, 5120, 0, 0), (32, 32000, 5120, 0, 0)],  # last five: LLaVA-1.5-13B projections (32 rows: o_proj, lm_head)
 )
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_gemm_smallm(ops, dtype, M, N, K, n_slices, wg_waves, variant):
