@@ -178,9 +178,12 @@ def linear_packed_roofline(model):
         y_q = torch.empty((M, Nq), device=dev, dtype=dt)
         act = torch.empty(int(ops.lib().dl_packed_x_bytes(M, I)) // 2, device=dev, dtype=dt)
         parts = torch.empty(ks_d * M * H, device=dev, dtype=torch.float32)
+        parts_q = torch.empty(ks_q * M * Nq, device=dev, dtype=torch.float32)
         cases = [
-            (f"q|k|v ({nu_q} units x {ks_q} k ranges handed over in the launch)", [Nq, H], Nq * H * 2 + M * H * 2 + M * Nq * 2,
+            (f"q|k|v ({nu_q} units x {ks_q} k ranges handed over in the launch: decode batches of 16..32 rows)", [Nq, H], Nq * H * 2 + M * H * 2 + M * Nq * 2,
              lambda l: ops.linear_packed(xp, l.wp_qkv, Nq, out=y_q, units_per_workgroup=nu_q, k_split=ks_q, workspace=model._lp_ws if ks_q > 1 else None, err=model._lp_err, x_packed_mk=(M, H))),
+            (f"q|k|v, fp32 partial sums for the RoPE / KV-append launch ({nu_q} units x {ks_q} k ranges: the prefill's path)", [Nq, H], Nq * H * 2 + M * H * 2 + ks_q * M * Nq * 4,
+             lambda l: ops.linear_packed(xp, l.wp_qkv, Nq, out=parts_q, epilogue=ops.LP_PARTS, units_per_workgroup=nu_q, k_split=ks_q, x_packed_mk=(M, H))),
             (f"gate|up + SiLU*up epilogue, act in fragment order ({nu_g} units)", [2 * I, H], 2 * I * H * 2 + M * H * 2 + M * I * 2,
              lambda l: ops.linear_packed(xp, l.wp_gu, 2 * I, out=act, epilogue=ops.LP_SILU_PAIR, units_per_workgroup=nu_g, k_split=ks_g, workspace=model._lp_ws if ks_g > 1 else None, err=model._lp_err,
                                          x_packed_mk=(M, H), y_packed=True)),

@@ -7,12 +7,14 @@ namespace dl {
 
 constexpr int kRopeThreads = 256;
 
-template <typename T>
+// PARTS: the projection arrives as `n_parts` fp32 partial sums [part][total][row_w] (dl_linear_packed's k ranges, DL_LP_PARTS): a chunk is their sum in
+// part order, rounded once to the model dtype -- exactly what the GEMM would have stored -- and q / k (rotated) and v are WRITTEN to qkv instead of updated.
+template <typename T, bool PARTS>
 __global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
     void* __restrict__ qkv_, const void* __restrict__ cos_, const void* __restrict__ sin_, int n_pos,
     const int32_t* __restrict__ cu, const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_base,
     const int32_t* __restrict__ kv_base, void* __restrict__ k_slab_, void* __restrict__ v_slab_, int64_t stride_b,
-    int64_t stride_h, int T_cap, int B, int nH, int nKV, int d) {
+    int64_t stride_h, int T_cap, int B, int nH, int nKV, int d, const float* __restrict__ parts = nullptr, int n_parts = 0, int64_t part_stride = 0) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
   __shared__ int sh[4];
@@ -47,13 +49,31 @@ __global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
   const int cpv = d / V;
   const int n_cpy = nKV * cpv;
   const int items = n_rot + n_cpy;
+  const float* prow = PARTS ? parts + (int64_t)t * row_w : nullptr;
+  auto load_sum = [&](int col, float (&o)[V]) {  // V model-dtype values at column `col` of this row: sum of the partial sums, part 0 first, rounded once
+    static_assert(V % 4 == 0, "16-byte chunks of a 2-byte type");
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      float4 a = *reinterpret_cast<const float4*>(prow + col + q * 4);
+      for (int s_ = 1; s_ < n_parts; ++s_) {
+        const float4 b_ = *reinterpret_cast<const float4*>(prow + (int64_t)s_ * part_stride + col + q * 4);
+        a.x += b_.x; a.y += b_.y; a.z += b_.z; a.w += b_.w;
+      }
+      o[q * 4] = Elem<T>::round(a.x); o[q * 4 + 1] = Elem<T>::round(a.y); o[q * 4 + 2] = Elem<T>::round(a.z); o[q * 4 + 3] = Elem<T>::round(a.w);
+    }
+  };
   for (int it = blockIdx.y * kRopeThreads + threadIdx.x; it < items; it += gridDim.y * kRopeThreads) {
     if (it < n_rot) {
       const int h = it / cph, c = (it - h * cph) * V;
       S* x = row + h * d;
       float x1[V], x2[V], cs[V], sn[V], o1[V], o2[V];
-      load16<T>(x + c, x1);
-      load16<T>(x + half + c, x2);
+      if constexpr (PARTS) {
+        load_sum(h * d + c, x1);
+        load_sum(h * d + half + c, x2);
+      } else {
+        load16<T>(x + c, x1);
+        load16<T>(x + half + c, x2);
+      }
       load16<T>(cosr + c, cs);  // table = cat(freqs, freqs): second half equals the first
       load16<T>(sinr + c, sn);
 #pragma unroll
@@ -70,12 +90,22 @@ __global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
         *reinterpret_cast<uint4*>(dst + c) = p1;
         *reinterpret_cast<uint4*>(dst + half + c) = p2;
       }
-    } else if (store_ok) {
+    } else if (PARTS || store_ok) {
       const int iv = it - n_rot;
       const int h = iv / cpv, c = (iv - h * cpv) * V;
-      const uint4 val = *reinterpret_cast<const uint4*>(row + (nH + nKV + h) * d + c);
-      S* dst = v_slab + (int64_t)b * stride_b + (int64_t)h * stride_h + (int64_t)slot * d;
-      *reinterpret_cast<uint4*>(dst + c) = val;
+      uint4 val;
+      if constexpr (PARTS) {
+        float vv[V];
+        load_sum((nH + nKV + h) * d + c, vv);
+        val = pack16<T>(vv);
+        *reinterpret_cast<uint4*>(row + (nH + nKV + h) * d + c) = val;  // the prefill attention reads v from the packed projection
+      } else {
+        val = *reinterpret_cast<const uint4*>(row + (nH + nKV + h) * d + c);
+      }
+      if (store_ok) {
+        S* dst = v_slab + (int64_t)b * stride_b + (int64_t)h * stride_h + (int64_t)slot * d;
+        *reinterpret_cast<uint4*>(dst + c) = val;
+      }
     }
   }
 }
@@ -84,28 +114,51 @@ __global__ __launch_bounds__(kRopeThreads) void rope_kv_write_kernel(
 
 using namespace dl;
 
-extern "C" int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* cu_seqlens,
-                                const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base, void* k_slab, void* v_slab,
-                                int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, int B, int total, int n_heads,
-                                int n_kv_heads, int head_dim, int dtype, void* stream) {
-  DL_REQUIRE(B > 0 && total >= 0 && n_heads > 0 && n_kv_heads > 0 && n_pos > 0, "dl_rope_kv_write: bad shape");
+static int rope_kv_write_impl(const char* who, void* qkv, const float* parts, int n_parts, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* cu_seqlens,
+                              const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base, void* k_slab, void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h,
+                              int T_cap, int B, int total, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(B > 0 && total >= 0 && n_heads > 0 && n_kv_heads > 0 && n_pos > 0, "%s: bad shape", who);
   if (total == 0) return DL_OK;  // an empty input is a no-op, whatever its (possibly NULL) pointers
-  DL_REQUIRE(qkv && cos_tab && sin_tab && cu_seqlens && kv_base && k_slab && v_slab, "dl_rope_kv_write: NULL pointer");
-  DL_REQUIRE(pos || pos_base, "dl_rope_kv_write: one of pos / pos_base is required");
+  DL_REQUIRE(qkv && cos_tab && sin_tab && cu_seqlens && kv_base && k_slab && v_slab, "%s: NULL pointer", who);
+  DL_REQUIRE(pos || pos_base, "%s: one of pos / pos_base is required", who);
+  DL_REQUIRE(!parts || (n_parts >= 1 && n_parts <= 8 && ((uintptr_t)parts & 15) == 0 && (dtype == DL_BF16 || dtype == DL_F16) && head_dim % 8 == 0),
+             "%s: 1..8 partial sums, 16-byte aligned, 2-byte model dtypes", who);
   DL_DISPATCH_DTYPE(dtype, T, {
-    DL_REQUIRE(head_dim > 0 && (head_dim / 2) % Elem<T>::kVec == 0, "dl_rope_kv_write: head_dim=%d unsupported", head_dim);
+    DL_REQUIRE(head_dim > 0 && (head_dim / 2) % Elem<T>::kVec == 0, "%s: head_dim=%d unsupported", who, head_dim);
     const int items = (n_heads + n_kv_heads) * (head_dim / 2 / Elem<T>::kVec) + n_kv_heads * (head_dim / Elem<T>::kVec);
     int gy = 1;
     if (total < 256) {  // decode: spread one token's heads over several workgroups
       gy = (items + kRopeThreads - 1) / kRopeThreads;
       if (gy > 8) gy = 8;
     }
-    hipLaunchKernelGGL((rope_kv_write_kernel<T>), dim3((unsigned)total, (unsigned)gy), dim3(kRopeThreads), 0, as_stream(stream), qkv,
+    const int64_t part_stride = (int64_t)total * (n_heads + 2 * n_kv_heads) * head_dim;
+    if (parts)
+      hipLaunchKernelGGL((rope_kv_write_kernel<T, true>), dim3((unsigned)total, (unsigned)gy), dim3(kRopeThreads), 0, as_stream(stream), qkv, cos_tab, sin_tab, n_pos, cu_seqlens, pos,
+                         pos_base, kv_base, k_slab, v_slab, slab_stride_b, slab_stride_h, T_cap, B, n_heads, n_kv_heads, head_dim, parts, n_parts, part_stride);
+    else
+      hipLaunchKernelGGL((rope_kv_write_kernel<T, false>), dim3((unsigned)total, (unsigned)gy), dim3(kRopeThreads), 0, as_stream(stream), qkv,
                        cos_tab, sin_tab, n_pos, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, slab_stride_b, slab_stride_h,
                        T_cap, B, n_heads, n_kv_heads, head_dim);
   });
-  DL_CHECK_LAUNCH("dl_rope_kv_write");
+  DL_CHECK_LAUNCH(who);
   return DL_OK;
+}
+
+extern "C" int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* cu_seqlens,
+                                const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base, void* k_slab, void* v_slab,
+                                int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, int B, int total, int n_heads,
+                                int n_kv_heads, int head_dim, int dtype, void* stream) {
+  return rope_kv_write_impl("dl_rope_kv_write", qkv, nullptr, 0, cos_tab, sin_tab, n_pos, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, slab_stride_b, slab_stride_h, T_cap, B, total,
+                            n_heads, n_kv_heads, head_dim, dtype, stream);
+}
+
+extern "C" int dl_rope_kv_write_parts(void* qkv_out, const float* parts, int n_parts, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* cu_seqlens,
+                                      const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base, void* k_slab, void* v_slab,
+                                      int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, int B, int total, int n_heads,
+                                      int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(parts || total == 0, "dl_rope_kv_write_parts: NULL partial sums");
+  return rope_kv_write_impl("dl_rope_kv_write_parts", qkv_out, parts, n_parts, cos_tab, sin_tab, n_pos, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, slab_stride_b, slab_stride_h, T_cap, B,
+                            total, n_heads, n_kv_heads, head_dim, dtype, stream);
 }
 
 // ---- in-place packing of the kept rows of a just-appended chunk (multi-round "new instruct" call: DML:2506-2521 decides per chunk

@@ -52,6 +52,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
+    "dl_rope_kv_write_parts": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_void_p],
+    ),
     "dl_attn_prefill": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -240,13 +245,25 @@ def silu_mul(gate_up, out=None):
     return out
 
 
-def rope_kv_write(qkv, cos, sin, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, n_heads, n_kv_heads, head_dim):
-    """qkv [total, (nH+2nKV)*d] rotated in place; k_slab/v_slab [B, nKV, T_cap, d]."""
+def rope_kv_write(qkv, cos, sin, cu_seqlens, pos, pos_base, kv_base, k_slab, v_slab, n_heads, n_kv_heads, head_dim, parts=None):
+    """qkv [total, (nH+2nKV)*d] rotated in place; k_slab/v_slab [B, nKV, T_cap, d].  parts (fp32 [n_parts, total, (nH+2nKV)*d], dl_linear_packed's
+    partial sums): qkv is written from their rounded sum instead (q, k rotated, v as is)."""
     _dev(qkv, cos, sin, cu_seqlens, k_slab, v_slab)
     assert qkv.is_contiguous() and cos.is_contiguous() and sin.is_contiguous()
     assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
     B = cu_seqlens.numel() - 1
     total = qkv.shape[0]
+    if parts is not None:
+        _dev(parts)
+        assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.dim() == 3 and tuple(parts.shape[1:]) == tuple(qkv.shape)
+        _check(
+            lib().dl_rope_kv_write_parts(
+                _p(qkv), _p(parts), parts.shape[0], _p(cos), _p(sin), cos.shape[0], _p(cu_seqlens), _p(pos), _p(pos_base), _p(kv_base), _p(k_slab), _p(v_slab),
+                k_slab.stride(0), k_slab.stride(1), k_slab.shape[2], B, total, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
+            ),
+            "dl_rope_kv_write_parts",
+        )
+        return
     _check(
         lib().dl_rope_kv_write(
             _p(qkv), _p(cos), _p(sin), cos.shape[0], _p(cu_seqlens), _p(pos), _p(pos_base), _p(kv_base), _p(k_slab), _p(v_slab),

@@ -487,6 +487,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         # on (24: 4.05 -> 3.97, 32: 4.21 -> 4.11); o_proj stays on dl_gemm_smallm's partial sums up to 32 rows (against the library GEMM + add: 32 rows 4.20 -> 4.11)
         self.packed_decode_qkv_min_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_MIN_B", "16"))
         self.packed_decode_mlp_min_batch = int(os.environ.get("DL_PACKED_DECODE_MLP_MIN_B", "4"))
+        self.packed_qkv_parts = os.environ.get("DL_PACKED_QKV_PARTS", "1") == "1"  # prefill q|k|v: partial sums added by the RoPE / KV-append launch instead of the in-launch hand-over
         self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 4..32: gate|up + SiLU * up and down_proj on dl_linear_packed
         self._lp_ws = None   # hand-over workspace of the k-split launches (zeroed once; the kernel leaves its flag words zero)
         self._lp_err = None  # bit 3: a reducing wave of dl_linear_packed gave up waiting
@@ -815,6 +816,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         x_pk = lp_ok(total, self.model.layers[0]) and not (SL == 0 and (vision_on or p["instruct_on"] or p["nocache"]))
         x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps, packed=x_pk)
         attn_buf = None
+        qkv_buf = None
         for i, layer in enumerate(self.model.layers):
             if i == SL and vision_on:
                 # ---- F1..F5: predictor -> top-k -> compaction (DML:1826-1994) on the un-normed residual stream ----
@@ -915,8 +917,20 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                 x_pk = use_lp
                 x = ops.rmsnorm(h, layer.input_layernorm.weight, eps, packed=x_pk)
             use_lp = use_lp and x_pk
-            qkv = self._lp_linear(x, total, layer.wp_qkv, layer.w_qkv.shape[0], h.shape[1]) if use_lp else F.linear(x, layer.w_qkv)
-            ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
+            Nq = layer.w_qkv.shape[0]
+            nu_q, ks_q = self._lp_config(Nq // 16, False)
+            if use_lp and self.packed_qkv_parts and ks_q > 1:
+                # the two k ranges of q|k|v leave fp32 partial sums instead of meeting inside the GEMM launch (its hand-over is 8-11 us of a 35 us launch); the
+                # RoPE / KV-append launch adds them -- the same sum, rounded once -- and writes q, k, v for the attention
+                if qkv_buf is None or qkv_buf.shape[0] != total or qkv_buf.shape[1] != Nq:
+                    qkv_buf = torch.zeros((total, Nq), dtype=dt, device=dev)  # (rows past the last sequence are never written, nor read)
+                parts_q = ops.linear_packed(x, layer.wp_qkv, Nq, out=self._qkv_parts_ws(ks_q * ops.LP_MAX_ROWS * Nq), epilogue=ops.LP_PARTS, units_per_workgroup=nu_q, k_split=ks_q,
+                                            x_packed_mk=(total, h.shape[1]))
+                qkv = qkv_buf
+                ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d, parts=parts_q)
+            else:
+                qkv = self._lp_linear(x, total, layer.wp_qkv, Nq, h.shape[1]) if use_lp else F.linear(x, layer.w_qkv)
+                ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
             if attn_buf is None or attn_buf.shape[0] != total:
                 # one zero-filled buffer per row count, shared by the layers (the attention launch writes the rows of real sequences only: padding rows
                 # of a width bucket stay zero instead of holding whatever the allocator handed out -- ADVICE r4)
@@ -1004,6 +1018,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return ops.linear_packed(x_pk, wp, N, epilogue=epilogue, units_per_workgroup=nu, k_split=ks, workspace=self._lp_ws if ks > 1 else None, err=self._lp_err,
                                  x_packed_mk=(rows, K), y_packed=y_packed)
 
+    def _qkv_parts_ws(self, n):
+        """fp32 partial sums of the q|k|v projection (k ranges x LP_MAX_ROWS x columns: one size per model, so that captured graphs keep a valid pointer)."""
+        ws = getattr(self, "_qkv_parts_buf", None)
+        if ws is None or ws.numel() < n:
+            ws = self._qkv_parts_buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        return ws
+
     def _splitk_ws(self, H):
         """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
         ws = getattr(self, "_splitk_buf", None)
@@ -1058,7 +1079,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             "use_hip_graph": self.use_hip_graph, "attn_inkernel_combine": self.attn_inkernel_combine, "device_prompt_layout": self.device_prompt_layout,
             "tp_side_stream": self.tp_side_stream, "gemv_max_decode_batch": self.gemv_max_decode_batch, "smallm_max_decode_batch": self.smallm_max_decode_batch,
             "fuse_qkv_attn": self.fuse_qkv_attn, "fuse_gu_tp": self.fuse_gu_tp, "fused_attn_max_splits": self.fused_attn_max_splits, "gu_grid_cap": self.gu_grid_cap,
-            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch,
+            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_qkv_parts": self.packed_qkv_parts, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,

@@ -74,6 +74,15 @@ int dl_rope_kv_write(void* qkv, const void* cos_tab, const void* sin_tab, int n_
                      void* k_slab, void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap,
                      int B, int total, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
 
+/* The same on a projection that arrives as fp32 PARTIAL SUMS (round 5: dl_linear_packed with DL_LP_PARTS on q|k|v, DML:1011-1013, k ranges not handed over inside
+ * the GEMM launch): parts [n_parts][total][(n_heads + 2 n_kv_heads) head_dim] fp32, 16-byte aligned, 1 <= n_parts <= 8; a value is the sum of its partial sums in
+ * part order rounded once to the model dtype -- what the GEMM would have stored.  qkv_out (same shape as dl_rope_kv_write's qkv, model dtype) is WRITTEN: rotated q
+ * and k, v as is (the prefill attention reads all three from it); slab writes as above.  bf16 / f16. */
+int dl_rope_kv_write_parts(void* qkv_out, const float* parts, int n_parts, const void* cos_tab, const void* sin_tab, int n_pos,
+                           const int32_t* cu_seqlens, const int32_t* pos, const int32_t* pos_base, const int32_t* kv_base,
+                           void* k_slab, void* v_slab, int64_t slab_stride_b, int64_t slab_stride_h, int T_cap,
+                           int B, int total, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream);
+
 /* ---- F9 (prefill): F.scaled_dot_product_attention as called at DML:1114-1122 with is_causal=True, and
  * CTL:164-169 (non-causal, inside VisionPredictor).  Packed varlen self-attention:
  * q/k/v element (token t, head h, dim e) at base[t*row_stride + h*head_dim + e] (k/v use kv head

@@ -995,3 +995,39 @@ def test_linear_packed_rejects_bad_arguments(ops):
     with pytest.raises(ops.HipOpsError):
         ops.linear_packed(big, wp, 64)  # more than one tile of rows
     assert ops.linear_packed(x[:0], wp, 64).shape == (0, 64)  # empty input: a no-op
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n_parts,total,nH,nKV,d", [(2, 170, 32, 32, 128), (4, 37, 8, 8, 64), (1, 5, 4, 2, 128)])
+def test_rope_kv_write_parts_equals_rope_on_the_rounded_sum(ops, dtype, n_parts, total, nH, nKV, d):
+    """dl_rope_kv_write_parts (q|k|v as dl_linear_packed's fp32 partial sums) == dl_rope_kv_write on the sum of the parts (part order) rounded once to the
+    model dtype: q / k rotated, v as is, slab rows -- bit for bit; rows past the last sequence untouched."""
+    g = torch.Generator().manual_seed(9)
+    W = (nH + 2 * nKV) * d
+    pad = 3  # a launch sized for a width bucket: rows past cu[B] are padding
+    parts = torch.randn(n_parts, total + pad, W, generator=g).cuda()
+    acc = parts[0].clone()
+    for s_ in range(1, n_parts):
+        acc += parts[s_]
+    qkv_ref = acc.to(dtype)
+    B = 2
+    cu = torch.tensor([0, total // 2, total], dtype=torch.int32, device="cuda")
+    T_cap = total + 8
+    cos = torch.randn(T_cap, d, generator=g).to(dtype).cuda()
+    sin = torch.randn(T_cap, d, generator=g).to(dtype).cuda()
+    pos = torch.randint(0, T_cap, (total + pad,), generator=g).to(torch.int32).cuda()
+    kvb = torch.tensor([3, 0], dtype=torch.int32, device="cuda")
+    outs = []
+    for use_parts in (False, True):
+        k_slab = torch.zeros(B, nKV, T_cap, d, dtype=dtype, device="cuda")
+        v_slab = torch.zeros_like(k_slab)
+        if use_parts:
+            qkv = torch.full((total + pad, W), 7.0, dtype=dtype, device="cuda")
+            ops.rope_kv_write(qkv, cos, sin, cu, pos, None, kvb, k_slab, v_slab, nH, nKV, d, parts=parts)
+            assert bool((qkv[total:] == 7.0).all()), "padding rows must stay untouched"
+        else:
+            qkv = qkv_ref.clone()
+            ops.rope_kv_write(qkv, cos, sin, cu, pos, None, kvb, k_slab, v_slab, nH, nKV, d)
+        outs.append((qkv[:total].clone(), k_slab, v_slab))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
