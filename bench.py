@@ -174,7 +174,7 @@ def linear_packed_roofline(model):
         xp, xip = ops.pack_x_tiles(x), ops.pack_x_tiles(xi)
         nu_q, ks_q = model._lp_config(Nq // 16, False)
         nu_g, ks_g = model._lp_config(2 * I // 16, True)
-        nu_d, ks_d = model._lp_config_parts(H // 16)
+        nu_d, ks_d = model._lp_config_parts(H // 16, M)
         y_q = torch.empty((M, Nq), device=dev, dtype=dt)
         act = torch.empty(int(ops.lib().dl_packed_x_bytes(M, I)) // 2, device=dev, dtype=dt)
         parts = torch.empty(ks_d * M * H, device=dev, dtype=torch.float32)

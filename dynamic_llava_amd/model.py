@@ -953,7 +953,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             if lp_down:
                 # down_proj on the operand-order copy: 4 k ranges per unit set, fp32 partial sums added in range order by the residual-add / RMSNorm launch
                 I_ = layer.w_gu.shape[0] // 2
-                nu_, ks_ = self._lp_config_parts(h.shape[1] // 16)
+                nu_, ks_ = self._lp_config_parts(h.shape[1] // 16, total)
                 parts_ = ops.linear_packed(act, layer.wp_down, h.shape[1], out=self._splitk_ws(h.shape[1])[: ks_ * total * h.shape[1]], epilogue=ops.LP_PARTS, units_per_workgroup=nu_,
                                            k_split=ks_, x_packed_mk=(total, I_))
                 x_new = ops.add_rmsnorm_parts(h, parts_, nw_next, eps, packed=pk_next)
@@ -1003,9 +1003,13 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return 8, 1
 
     @staticmethod
-    def _lp_config_parts(n_units: int):
+    def _lp_config_parts(n_units: int, rows: int = 0):
         """(units per workgroup, k ranges) of a partial-sum launch (narrow N: o_proj / down_proj): as many k ranges as keep one workgroup per CU with at
-        most 4 units each -- every CU then pulls 1 / k_split of X through its L1 (256 units at 7B: 4 units x 4 ranges)."""
+        most 4 units each -- every CU then pulls 1 / k_split of X through its L1 (256 units at 7B: 4 units x 4 ranges).  With more than 128 rows, where X is
+        what the launch waits for, 8 units x 8 ranges when that is exactly one workgroup per CU (7B down_proj at M = 170: 32.6 -> 28.5 us, with the consumer's
+        eight slices 39.5 -> 36.6; a tie at 117 rows, slower at 32)."""
+        if 128 < rows <= 192 and n_units % 8 == 0 and n_units // 8 * 8 == 256:
+            return 8, 8
         for ks in (4, 2, 1):
             for nu in (1, 2, 3, 4):
                 if -(-n_units // nu) * ks <= 256:

@@ -260,6 +260,8 @@ def test_linear_packed_launch_shapes_cover_the_chip_once():
     for n_units, want in ((256, (4, 4)), (320, (3, 2))):
         nu, ks = M._lp_config_parts(n_units)
         assert (nu, ks) == want and -(-n_units // nu) * ks <= 256
+    # more than 128 rows (X-bound): 8 units x 8 ranges where that is exactly one workgroup per CU, and only while the partial sums fit the 8 x 192-row workspace
+    assert M._lp_config_parts(256, 170) == (8, 8) and M._lp_config_parts(256, 117) == (4, 4) and M._lp_config_parts(256, 200) == (4, 4) and M._lp_config_parts(320, 170) == (3, 2)
 
 
 def test_boundary_band_scales_with_the_logit_magnitude():
