@@ -187,6 +187,124 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* x_, con
   }
 }
 
+// ---- LayerNorm, a WAVE per row (round 6: the CLIP tower's H = 1024 rows between dl_linear_tiles calls) ----
+// The block-per-row kernel above spends a 256-thread workgroup, two LDS reductions and two barriers on a 2 KB row (577 workgroups of half-idle
+// threads: 5.2 us per launch, twice per encoder layer).  Here a row lives in ONE wave (VPL 16-byte vectors per lane, lanes contiguous: 1 KiB per load
+// instruction), both reductions are DPP + readlane, four rows share a workgroup and nothing synchronises.
+// ADD = 1: x = cast(x + delta) first (16-bit delta rows).  ADD = 2: delta = cast(sum_s parts[s][row][:] + bias) -- the fp32 k-range partial sums of
+// dl_linear_tiles(DL_LT_PARTS), added in range order, then the Linear's bias, one rounding (what F.linear would have returned), then the residual add.
+// out_tiles > 0: the normalised row goes out in dl_linear_tiles' fragment order (its x_packed input).
+template <typename T, int ADD, int VPL>
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(void* x_, const void* __restrict__ delta_, int n_slices, int64_t slice_stride,
+                                                              const void* __restrict__ bias_, const void* __restrict__ w_, const void* __restrict__ b_,
+                                                              void* __restrict__ out_, int64_t rows, int H, float eps, int out_tiles) {
+  constexpr int V = Elem<T>::kVec;
+  using S = typename Elem<T>::storage;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  S* xr = reinterpret_cast<S*>(x_) + row * H;
+  const int nvec = H / V;
+  float x[VPL][V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      load16<T>(xr + v * V, x[i]);
+      if constexpr (ADD == 1) {
+        float d[V];
+        load16<T>(reinterpret_cast<const S*>(delta_) + row * H + v * V, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
+        store16<T>(xr + v * V, x[i]);
+      } else if constexpr (ADD == 2) {
+        float d[V];
+        const float* pp = reinterpret_cast<const float*>(delta_) + row * H + v * V;
+#pragma unroll
+        for (int j = 0; j < V; ++j) d[j] = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) {
+#pragma unroll
+          for (int q = 0; q < V / 4; ++q) {
+            const float4 pv = *reinterpret_cast<const float4*>(pp + sl * slice_stride + q * 4);
+            d[q * 4] += pv.x;
+            d[q * 4 + 1] += pv.y;
+            d[q * 4 + 2] += pv.z;
+            d[q * 4 + 3] += pv.w;
+          }
+        }
+        if (bias_) {
+          float bb[V];
+          load16<T>(reinterpret_cast<const S*>(bias_) + v * V, bb);
+#pragma unroll
+          for (int j = 0; j < V; ++j) d[j] += bb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + Elem<T>::round(d[j]));
+        store16<T>(xr + v * V, x[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) s += x[i][j];
+    }
+  }
+  if (w_ == nullptr) return;  // residual add only
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (lane + 64 * i < nvec) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float d = x[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  const S* w = reinterpret_cast<const S*>(w_);
+  const S* b = reinterpret_cast<const S*>(b_);
+  S* out = reinterpret_cast<S*>(out_);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      float wv[V], bv[V], o[V];
+      load16<T>(w + v * V, wv);
+      load16<T>(b + v * V, bv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = (x[i][j] - mean) * rstd * wv[j] + bv[j];
+      if (out_tiles > 0)
+        store16<T>(out + lp_x_chunk_offset(row, v, out_tiles), o);
+      else
+        store16<T>(out + row * H + v * V, o);
+    }
+  }
+}
+
+template <typename T, int ADD>
+static int ln_wave_launch(void* x, const void* delta, int n_slices, const void* bias, const void* w, const void* b, void* out, int64_t rows, int H, float eps,
+                          int out_packed, hipStream_t st) {
+  const int nvec = H / Elem<T>::kVec;
+  const int vpl = (nvec + 63) / 64;
+  const int out_tiles = out_packed ? (int)((rows + 15) / 16) : 0;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define LN_WAVE_CASE(v_)                                                                                                                                  \
+  case v_:                                                                                                                                                \
+    hipLaunchKernelGGL((layernorm_wave_kernel<T, ADD, v_>), grid, dim3(256), 0, st, x, delta, n_slices, (int64_t)rows * H, bias, w, b, out, rows, H, eps, \
+                       out_tiles);                                                                                                                        \
+    return DL_OK
+  switch (vpl) {
+    LN_WAVE_CASE(1);
+    LN_WAVE_CASE(2);
+    LN_WAVE_CASE(3);
+    LN_WAVE_CASE(4);
+    LN_WAVE_CASE(8);
+  }
+#undef LN_WAVE_CASE
+  set_error("layernorm (wave per row): H=%d is not built (H / 8 <= 256 or == 512 vectors of 16 bytes)", H);
+  return DL_ERR_ARG;
+}
+
 // ---- CLIP's QuickGELU (HF activations.QuickGELUActivation: `input * torch.sigmoid(1.702 * input)`), three roundings as in eager ----
 template <typename T>
 __global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const void* __restrict__ x_, void* __restrict__ out_, int64_t nvec) {
@@ -383,6 +501,55 @@ extern "C" int dl_add_layernorm(void* h, const void* delta, const void* w, const
                        out, H, eps);
   });
   DL_CHECK_LAUNCH("dl_add_layernorm");
+  return DL_OK;
+}
+
+#define DL_LN_ROWS_CHECKS(name)                                                                                                                     \
+  DL_REQUIRE(rows >= 0 && H > 0, name ": bad shape");                                                                                               \
+  if (rows == 0) return DL_OK;                                                                                                                      \
+  DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, name ": bf16 / fp16 only");                                                                       \
+  DL_REQUIRE(H % 8 == 0 && (!out_packed || H % 64 == 0), name ": H=%d must be a multiple of 8 (of 64 for a fragment-order output)", H);             \
+  DL_REQUIRE((w == nullptr) == (out == nullptr) && (w == nullptr) == (b == nullptr), name ": w, b and out must all be given or all be NULL");      \
+  DL_REQUIRE(!out || ((uintptr_t)out & 15) == 0, name ": unaligned output")
+
+extern "C" int dl_layernorm_rows(const void* x, const void* w, const void* b, void* out, int64_t rows, int H, float eps, int out_packed, int dtype, void* stream) {
+  DL_LN_ROWS_CHECKS("dl_layernorm_rows");
+  DL_REQUIRE(x && w && x != out, "dl_layernorm_rows: NULL pointer / out aliases x");
+  int rc;
+  if (dtype == DL_BF16)
+    rc = ln_wave_launch<bf16_t, 0>(const_cast<void*>(x), nullptr, 0, nullptr, w, b, out, rows, H, eps, out_packed, as_stream(stream));
+  else
+    rc = ln_wave_launch<f16_t, 0>(const_cast<void*>(x), nullptr, 0, nullptr, w, b, out, rows, H, eps, out_packed, as_stream(stream));
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_layernorm_rows");
+  return DL_OK;
+}
+
+extern "C" int dl_add_layernorm_rows(void* h, const void* delta, const void* w, const void* b, void* out, int64_t rows, int H, float eps, int out_packed, int dtype,
+                                     void* stream) {
+  DL_LN_ROWS_CHECKS("dl_add_layernorm_rows");
+  DL_REQUIRE(h && delta && h != out, "dl_add_layernorm_rows: NULL pointer / out aliases h");
+  int rc;
+  if (dtype == DL_BF16)
+    rc = ln_wave_launch<bf16_t, 1>(h, delta, 0, nullptr, w, b, out, rows, H, eps, out_packed, as_stream(stream));
+  else
+    rc = ln_wave_launch<f16_t, 1>(h, delta, 0, nullptr, w, b, out, rows, H, eps, out_packed, as_stream(stream));
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_add_layernorm_rows");
+  return DL_OK;
+}
+
+extern "C" int dl_add_layernorm_parts(void* h, const float* parts, int n_slices, const void* bias, const void* w, const void* b, void* out, int64_t rows, int H,
+                                      float eps, int out_packed, int dtype, void* stream) {
+  DL_LN_ROWS_CHECKS("dl_add_layernorm_parts");
+  DL_REQUIRE(h && parts && n_slices >= 1 && ((uintptr_t)parts & 15) == 0 && h != out, "dl_add_layernorm_parts: bad arguments");
+  int rc;
+  if (dtype == DL_BF16)
+    rc = ln_wave_launch<bf16_t, 2>(h, parts, n_slices, bias, w, b, out, rows, H, eps, out_packed, as_stream(stream));
+  else
+    rc = ln_wave_launch<f16_t, 2>(h, parts, n_slices, bias, w, b, out, rows, H, eps, out_packed, as_stream(stream));
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_add_layernorm_parts");
   return DL_OK;
 }
 

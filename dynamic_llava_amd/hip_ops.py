@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdynllava_hip.so")
 
 DL_F32, DL_F16, DL_BF16 = 0, 1, 2
-ABI_VERSION = 3  # include/dynllava.h DL_ABI_VERSION: a library built from another header is refused at load
+ABI_VERSION = 4  # include/dynllava.h DL_ABI_VERSION: a library built from another header is refused at load
 EPI_GELU, EPI_RESIDUAL = 1, 2
 _DTYPES = {torch.float32: DL_F32, torch.float16: DL_F16, torch.bfloat16: DL_BF16}
 
@@ -122,6 +122,13 @@ SIGNATURES = {
     "dl_linear_packed_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dl_linear_packed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dl_linear_packed_stamped": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dl_tiles_x_bytes": (c_int64, [c_int, c_int]),
+    "dl_layernorm_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
+    "dl_add_layernorm_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
+    "dl_add_layernorm_parts": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
+    "dl_pack_x_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dl_linear_tiles": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dl_linear_tiles_stamped": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "dl_decode_advance": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
@@ -415,6 +422,54 @@ def add_layernorm(h, delta, w=None, b=None, eps=1e-5, out=None):
     if w is not None and out is None:
         out = torch.empty_like(h)
     _check(lib().dl_add_layernorm(_p(h), _p(delta), _p(w), _p(b), _p(out) if w is not None else None, rows, H, eps, dtype_code(h.dtype), _stream()), "dl_add_layernorm")
+    return out if w is not None else None
+
+
+def _ln_rows_out(rows, H, like, out, packed):
+    if packed:
+        n = tiles_x_numel(rows, H)
+        if out is None:
+            out = torch.empty(n, dtype=like.dtype, device=like.device)
+        assert out.is_contiguous() and out.dtype == like.dtype and out.numel() >= n
+    elif out is None:
+        out = torch.empty((rows, H), dtype=like.dtype, device=like.device)
+    return out
+
+
+def layernorm_rows(x, w, b, eps=1e-5, out=None, packed=False):
+    """LN(x) * w + b, a wave per row (the CLIP tower's launches around linear_tiles); packed: fragment-order output for linear_tiles(x_packed_mk=...)."""
+    _dev(x, w, b, out)
+    assert x.is_contiguous()
+    H = x.shape[-1]
+    rows = x.numel() // H
+    out = _ln_rows_out(rows, H, x, out, packed)
+    _check(lib().dl_layernorm_rows(_p(x), _p(w), _p(b), _p(out), rows, H, eps, int(bool(packed)), dtype_code(x.dtype), _stream()), "dl_layernorm_rows")
+    return out
+
+
+def add_layernorm_rows(h, delta, w=None, b=None, eps=1e-5, out=None, packed=False):
+    """h += delta in place (rounded); returns LN(h) * w + b (None when w is None), a wave per row; packed: fragment-order output."""
+    _dev(h, delta, w, b, out)
+    assert h.is_contiguous() and delta.is_contiguous() and h.shape == delta.shape
+    H = h.shape[-1]
+    rows = h.numel() // H
+    if w is not None:
+        out = _ln_rows_out(rows, H, h, out, packed)
+    _check(lib().dl_add_layernorm_rows(_p(h), _p(delta), _p(w), _p(b), _p(out) if w is not None else None, rows, H, eps, int(bool(packed)), dtype_code(h.dtype), _stream()),
+           "dl_add_layernorm_rows")
+    return out if w is not None else None
+
+
+def add_layernorm_parts(h, parts, bias=None, w=None, b=None, eps=1e-5, out=None, packed=False):
+    """h += cast(sum of the fp32 k-range partial sums `parts` [n, rows, H] (linear_tiles LT_PARTS) + bias) in place; returns LN(h) * w + b (None when w is None)."""
+    _dev(h, parts, bias, w, b, out)
+    assert h.is_contiguous() and parts.is_contiguous() and parts.dtype == torch.float32 and parts.dim() == 3 and tuple(parts.shape[1:]) == tuple(h.shape)
+    H = h.shape[-1]
+    rows = h.numel() // H
+    if w is not None:
+        out = _ln_rows_out(rows, H, h, out, packed)
+    _check(lib().dl_add_layernorm_parts(_p(h), _p(parts), parts.shape[0], _p(bias), _p(w), _p(b), _p(out) if w is not None else None, rows, H, eps, int(bool(packed)),
+                                        dtype_code(h.dtype), _stream()), "dl_add_layernorm_parts")
     return out if w is not None else None
 
 
@@ -720,6 +775,77 @@ def linear_packed(x, wp, N, out=None, epilogue=LP_STORE, resid=None, units_per_w
     else:
         _check(lib().dl_linear_packed(*args_, dtype_code(x.dtype), _stream()), "dl_linear_packed")
     return out[: k_split * M * N].view(k_split, M, N) if epilogue == LP_PARTS else out
+
+
+LT_BIAS, LT_QGELU, LT_GELU, LT_PARTS = 0, 1, 2, 3
+
+
+def linear_tiles_ok(M, N, K, dtype):
+    """Shapes dl_linear_tiles takes (any row count: the grid grows with it)."""
+    return dtype in (torch.bfloat16, torch.float16) and M > 0 and N % 16 == 0 and K % 64 == 0
+
+
+def tiles_x_numel(M, K):
+    need = int(lib().dl_tiles_x_bytes(M, K))
+    if need < 0:
+        raise HipOpsError(f"dl_tiles_x_bytes: unsupported shape [{M},{K}]")
+    return need // 2
+
+
+def pack_x_rows(x, out=None):
+    """x [M,K] in dl_linear_tiles' fragment order (ceil(M / 16) tiles; include/dynllava.h); returns a flat tensor."""
+    _dev(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    n = tiles_x_numel(M, K)
+    if out is None:
+        out = torch.empty(n, dtype=x.dtype, device=x.device)
+    assert out.numel() >= n and out.is_contiguous() and out.dtype == x.dtype
+    _check(lib().dl_pack_x_rows(_p(x), x.stride(0), _p(out), M, K, dtype_code(x.dtype), _stream()), "dl_pack_x_rows")
+    return out
+
+
+def linear_tiles(x, wp, N, bias=None, out=None, epilogue=LT_BIAS, x_packed_mk=None, y_packed=False, tile_shape=0, k_split=1, stamps=None, _wrap=0):
+    """out = x [M,K] @ W^T (+ bias, activation) on the packed copy wp of W [N,K] (pack_weight_tiles): the tiled MFMA GEMM of the vision side
+    (CLIP tower, projector, vision predictor).  x_packed_mk=(M, K): x is in fragment order (pack_x_rows / layernorm(rows_packed=True) / a previous call's
+    y_packed output).  epilogue LT_QGELU / LT_GELU: activation on the rounded Linear output; LT_PARTS: out is fp32 [k_split, M, N] partial sums (no bias)."""
+    _dev(x, wp, out, bias)
+    if x_packed_mk is None:
+        assert x.dim() == 2 and x.stride(1) == 1
+        M, K = x.shape
+        ldx = x.stride(0)
+    else:
+        M, K = x_packed_mk
+        ldx = K
+        assert x.is_contiguous() and (_wrap or x.numel() >= tiles_x_numel(M, K))
+    assert (_wrap or wp.numel() == N * K) and wp.dtype == x.dtype
+    if epilogue == LT_PARTS:
+        assert bias is None and not y_packed
+        if out is None:
+            out = torch.empty((k_split, M, N), dtype=torch.float32, device=x.device)
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= k_split * M * N
+        ldy = N
+    elif y_packed:
+        n = tiles_x_numel(M, N)
+        if out is None:
+            out = torch.empty(n, dtype=x.dtype, device=x.device)
+        assert out.is_contiguous() and out.dtype == x.dtype and out.numel() >= n
+        ldy = N
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        assert out.dim() == 2 and out.shape == (M, N) and out.stride(1) == 1 and out.dtype == x.dtype
+        ldy = out.stride(0)
+    if bias is not None:
+        assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
+    args_ = (_p(x), ldx, int(x_packed_mk is not None), _p(wp), _p(bias), _p(out), ldy, int(bool(y_packed)), M, N, K, int(epilogue), int(tile_shape), int(k_split))
+    if stamps is not None:
+        assert stamps.dtype == torch.int64 and stamps.is_cuda and stamps.is_contiguous()
+        args_ = args_[:11] + (int(epilogue) | (int(_wrap) << 8),) + args_[12:]
+        _check(lib().dl_linear_tiles_stamped(*args_, _p(stamps), dtype_code(x.dtype), _stream()), "dl_linear_tiles_stamped")
+    else:
+        _check(lib().dl_linear_tiles(*args_, dtype_code(x.dtype), _stream()), "dl_linear_tiles")
+    return out[: k_split * M * N].view(k_split, M, N) if epilogue == LT_PARTS else out
 
 
 def gemm_smallm_ok(M, N, K, dtype):

@@ -232,6 +232,10 @@ class CLIPVisionTower(nn.Module):
         )
         self.vision_tower.requires_grad_(False)
         self.is_loaded = True
+        # round 6 knobs: the tower's projections on dl_linear_tiles (False: the library GEMMs), up to how many images per call, k ranges of out_proj / fc2
+        self.tiles_gemm = os.environ.get("DL_CLIP_TILES", "1") != "0"
+        self.tiles_max_batch = 4
+        self.tiles_ksplit_out, self.tiles_ksplit_fc2 = 2, 4
         self._patch_embed_as_gemm()
 
     def _patch_embed_as_gemm(self):
@@ -252,16 +256,33 @@ class CLIPVisionTower(nn.Module):
         conv.forward = types.MethodType(gemm_forward, conv)
 
     def pack(self):
-        """Fuse q|k|v of every encoder layer into one [3C, C] weight (+bias) for a single projection GEMM.  Call after the
-        weights are loaded / cast (finalize() does)."""
+        """Fuse q|k|v of every encoder layer into one [3C, C] weight (+bias) for a single projection GEMM, and (16-bit dtypes) keep the four projections of
+        every layer a second time in matrix-core operand order for dl_linear_tiles (+0.6 GB for ViT-L/14-336 in bf16; `tiles_bytes` says how much: the
+        harness counterparts report it).  Call after the weights are loaded / cast (finalize() does)."""
         vm = next(m for n, m in self.vision_tower.named_modules() if hasattr(m, "encoder") and hasattr(m, "embeddings"))
         self._vm = [vm]  # in a list: not a registered submodule (the parameter tree / state-dict keys stay HF's)
         self._qkv = []
+        self._tiles = []  # per layer: (wp_qkv, wp_out, wp_fc1, wp_fc2) or None
+        self.tiles_bytes = 0
         for l in vm.encoder.layers:
             a = l.self_attn
-            self._qkv.append((torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous(), torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()))
+            wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()
+            self._qkv.append((wq, torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()))
+            ws = (wq, a.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)
+            if self.tiles_gemm and wq.is_cuda and all(ops.linear_tiles_ok(1, w.shape[0], w.shape[1], w.dtype) for w in ws):
+                self._tiles.append(tuple(ops.pack_weight_tiles(w.detach().contiguous()) for w in ws))
+                self.tiles_bytes += sum(t.numel() * t.element_size() for t in self._tiles[-1])
+            else:
+                self._tiles.append(None)
+        self._tiles_src = [(w.data_ptr(), w._version) for l in vm.encoder.layers for w in (l.self_attn.q_proj.weight, l.self_attn.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)]
         self._cu = {}
         return self
+
+    def _tiles_fresh(self):
+        """The operand-order copies are detached: replacing / editing a weight after pack() must not leave the tiled path on the old values."""
+        vm = self._vm[0]
+        now = [(w.data_ptr(), w._version) for l in vm.encoder.layers for w in (l.self_attn.q_proj.weight, l.self_attn.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)]
+        return now == self._tiles_src
 
     def _n_layers_needed(self):
         """hidden_states[k] is the stream after k encoder layers; select_layer = -2 needs L-1 of the L layers (HF computes all L
@@ -299,6 +320,22 @@ class CLIPVisionTower(nn.Module):
         if not (h.dtype == torch.float32 or d in (32, 64, 128)):
             raise ops.HipOpsError(f"CLIP head_dim={d}: dl_attn_prefill tiles head dims 32 / 64 / 128 in 16-bit dtypes (no torch fallback exists)")
         layers = vm.encoder.layers[: self._n_layers_needed()]
+        if not self._tiles_fresh():
+            self.pack()
+        if len(layers) and all(self._tiles[i] is not None for i in range(len(layers))) and B <= self.tiles_max_batch:
+            self._encoder_tiles(h, layers, cu, B, T, C, nH, d, eps)
+        else:
+            self._encoder_library(h, layers, cu, B, T, C, nH, d, eps)
+        f = h.view(B, T, C)
+        if self.select_feature == "patch":
+            f = f[:, 1:]
+        elif self.select_feature != "cls_patch":
+            raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        return f.to(images.dtype) if images.is_floating_point() else f
+
+    def _encoder_library(self, h, layers, cu, B, T, C, nH, d, eps):
+        """Library GEMMs (bias fused) + this package's glue kernels: fp32 models, batches past `tiles_max_batch` images (the library's large-tile kernels
+        are MFMA-bound there), towers whose shapes dl_linear_tiles does not take."""
         xn = ops.layernorm(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if len(layers) else None
         for i, l in enumerate(layers):
             wq, bq = self._qkv[i]
@@ -314,12 +351,31 @@ class CLIPVisionTower(nn.Module):
                 xn = ops.add_layernorm(h, y, nl.layer_norm1.weight, nl.layer_norm1.bias, eps)
             else:
                 ops.add_layernorm(h, y)
-        f = h.view(B, T, C)
-        if self.select_feature == "patch":
-            f = f[:, 1:]
-        elif self.select_feature != "cls_patch":
-            raise ValueError(f"Unexpected select feature: {self.select_feature}")
-        return f.to(images.dtype) if images.is_floating_point() else f
+
+    def _encoder_tiles(self, h, layers, cu, B, T, C, nH, d, eps):
+        """Round 6: every projection on dl_linear_tiles (own MFMA GEMM on operand-order weight copies; 7 launches per layer).  Activations between the
+        launches travel in the GEMM's fragment order wherever a producer can write it: LN -> q|k|v, LN -> fc1, fc1 (+ QuickGELU in the epilogue) -> fc2;
+        out_proj and fc2 leave fp32 k-range partial sums that the residual-add / LayerNorm launch adds in order (with the Linear's bias, one rounding:
+        F.linear's value)."""
+        M = B * T
+        I = layers[0].mlp.fc1.weight.shape[0]
+        xn = ops.layernorm_rows(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps, packed=True)
+        attn = torch.empty((M, C), dtype=h.dtype, device=h.device)
+        qkv = torch.empty((M, 3 * C), dtype=h.dtype, device=h.device)
+        ks_o, ks_2 = max(1, min(self.tiles_ksplit_out, C // 64)), max(1, min(self.tiles_ksplit_fc2, I // 64))  # (tiny test towers: K = 64 is one step)
+        for i, l in enumerate(layers):
+            wp_qkv, wp_out, wp_fc1, wp_fc2 = self._tiles[i]
+            ops.linear_tiles(xn, wp_qkv, 3 * C, bias=self._qkv[i][1], out=qkv, x_packed_mk=(M, C))
+            ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
+            parts = ops.linear_tiles(attn, wp_out, C, epilogue=ops.LT_PARTS, k_split=ks_o)
+            xn = ops.add_layernorm_parts(h, parts, l.self_attn.out_proj.bias, l.layer_norm2.weight, l.layer_norm2.bias, eps, packed=True)
+            g = ops.linear_tiles(xn, wp_fc1, I, bias=l.mlp.fc1.bias, epilogue=ops.LT_QGELU, x_packed_mk=(M, C), y_packed=True)
+            parts = ops.linear_tiles(g, wp_fc2, C, epilogue=ops.LT_PARTS, k_split=ks_2, x_packed_mk=(M, I))
+            if i + 1 < len(layers):
+                nl = layers[i + 1]
+                xn = ops.add_layernorm_parts(h, parts, l.mlp.fc2.bias, nl.layer_norm1.weight, nl.layer_norm1.bias, eps, packed=True)
+            else:
+                ops.add_layernorm_parts(h, parts, l.mlp.fc2.bias)
 
     @torch.no_grad()
     def forward_eager(self, images):
@@ -524,7 +580,36 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
 
     def encode_images(self, images):  # dynamic_llava_arch.py:163-166
         f = self.get_vision_tower()(images)
-        return self.model.mm_projector(f.to(self.dtype))
+        return self._project(f.to(self.dtype))
+
+    def _pack_projector(self):
+        """Operand-order copies of the mlp2x_gelu projector's two weights for dl_linear_tiles (multimodal_projector/builder.py:172-179; +42 MB at 7B)."""
+        pj = self.model.mm_projector
+        self._proj_tiles = None
+        vt = self.get_vision_tower()
+        ws = (pj[0].weight, pj[2].weight)
+        if (vt is None or vt.tiles_gemm) and all(w.is_cuda and ops.linear_tiles_ok(1, w.shape[0], w.shape[1], w.dtype) for w in ws) and pj[0].weight.shape[0] % 64 == 0:
+            self._proj_tiles = tuple(ops.pack_weight_tiles(w.detach().contiguous()) for w in ws)
+        self._proj_src = [(w.data_ptr(), w._version) for w in ws]
+
+    def _project(self, f):
+        """mm_projector(f): Linear -> GELU -> Linear.  16-bit models, up to `tiles_max_batch` images: both Linears on dl_linear_tiles, the GELU in the first one's
+        epilogue, the intermediate in fragment order (2 launches instead of 3 library launches)."""
+        pj = self.model.mm_projector
+        vt = self.get_vision_tower()
+        if getattr(self, "_proj_src", None) != [(w.data_ptr(), w._version) for w in (pj[0].weight, pj[2].weight)]:
+            self._pack_projector()
+        B = f.shape[0] if f.dim() == 3 else 1
+        if self._proj_tiles is None or f.dtype != pj[0].weight.dtype or not f.is_cuda or B > (vt.tiles_max_batch if vt is not None else 4) or pj[0].bias is None or pj[2].bias is None:
+            return pj(f)
+        C = f.shape[-1]
+        x = f.reshape(-1, C)  # a view for one image (the CLS row is skipped by the offset), a copy for several
+        if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+            x = x.contiguous()
+        M, H1, H2 = x.shape[0], pj[0].weight.shape[0], pj[2].weight.shape[0]
+        g = ops.linear_tiles(x, self._proj_tiles[0], H1, bias=pj[0].bias, epilogue=ops.LT_GELU, y_packed=True)
+        y = ops.linear_tiles(g, self._proj_tiles[1], H2, bias=pj[2].bias, x_packed_mk=(M, H1))
+        return y.view(*f.shape[:-1], H2)
 
     def finalize(self):
         """Call once after weights are loaded / moved: fuses QKV and gate|up, builds the RoPE table."""
@@ -547,6 +632,7 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._lp_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         if self.get_vision_tower() is not None:
             self.get_vision_tower().pack()
+        self._pack_projector()
         self._packed = True
         self._build_rope(self.config.max_position_embeddings)
         self._dstate = None
@@ -1086,6 +1172,8 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_qkv_parts": self.packed_qkv_parts, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
+            "clip_tiles_gemm": getattr(self.get_vision_tower(), "tiles_gemm", None), "clip_tiles_max_batch": getattr(self.get_vision_tower(), "tiles_max_batch", None),
+            "clip_tiles_ksplit": [getattr(self.get_vision_tower(), "tiles_ksplit_out", None), getattr(self.get_vision_tower(), "tiles_ksplit_fc2", None)],
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,
             "test_hook_min_keys_per_split": getattr(self, "min_keys_per_split", None),
         }

@@ -37,7 +37,7 @@ extern "C" {
 #define DL_F16 1
 #define DL_BF16 2
 
-#define DL_ABI_VERSION 3
+#define DL_ABI_VERSION 4
 
 #define DL_OK 0
 #define DL_ERR_ARG (-1)     /* bad argument (NULL pointer, unsupported size / dtype) */
@@ -407,6 +407,48 @@ int dl_linear_packed(const void* X, int64_t ldx, int x_packed, const void* Wp, v
 int dl_linear_packed_stamped(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N,
                              int K, int epilogue, int units_per_workgroup, int k_split, void* workspace, int32_t* err_flag, int64_t* stamps, int dtype,
                              void* stream);
+
+/* ---- tiled MFMA GEMM for the vision side's nn.Linear calls at M = 577 B rows (round 6): the CLIP ViT-L/14-336 encoder layer's projections
+ * (llava/model/multimodal_encoder/clip_encoder.py:53-71 runs transformers' CLIPEncoderLayer: q|k|v, out_proj, fc1 + QuickGELU, fc2 -- a pinned
+ * dependency, not under /root/reference), the mlp2x_gelu projector (llava/model/multimodal_projector/builder.py:172-179) and the vision predictor's
+ * linears (DML:1348-1359, CTL:153-180).  Y[M,N] = X[M,K] W^T on dl_pack_weight_tiles' copy of W [N,K] (gate_up_pairs = 0), fp32 accumulation.
+ *   x_packed: 0 = X row-major (row stride ldx >= K elements, 16-byte aligned rows); 1 = fragment order Xp[step = k / 64][tile = row / 16 of ceil(M / 16)]
+ *   [k half][lane = 16 ((k % 32) / 8) + row % 16][8] (dl_pack_x_rows, dl_layernorm_rows / dl_add_layernorm_rows, or a previous call's y_packed output;
+ *   dl_tiles_x_bytes(M, K) bytes; rows past M inside the last tile are never read into a stored result).  NOTE: the tile count is ceil(M / 16), not
+ *   dl_pack_x_tiles' multiple of four.
+ *   epilogue 0: Y = cast(acc + bias) (bias may be NULL); 1: QuickGELU on the rounded sum, dl_quick_gelu's three roundings; 2: nn.GELU() (erf) on the rounded
+ *   sum; 3 (DL_LT_PARTS): Y is an fp32 buffer [k_split][M][ldy] of partial sums, range r of the k_split ranges in slice r, bias must be NULL (the consumer
+ *   -- dl_add_layernorm_parts -- adds the slices in order, then the bias).  k_split > 1 only with epilogue 3.
+ *   y_packed (epilogues 0..2, N % 64 == 0): Y is written in fragment order for the next call.
+ *   tile_shape: 0 = chosen here (one round of workgroups over the 256 CUs where the shape allows), else 100 TM + 10 WN + NUW: TM row tiles of 16 rows x
+ *   WN consumer waves x NUW units of 16 neurons per workgroup (built: 542, 532, 522, 512, 521, 541; measurement forms: + 10000 = the weights through the
+ *   LDS ring as well -- 542, 532, 521 --, + 20000 = five instead of three steps of weight fragments in flight -- 542, 532, 521, 541).
+ *   Deterministic: one fp32 accumulation per output in k order per range; row-position invariant. */
+#define DL_LT_BIAS 0
+#define DL_LT_QGELU 1
+#define DL_LT_GELU 2
+#define DL_LT_PARTS 3
+int64_t dl_tiles_x_bytes(int M, int K);
+/* LayerNorm launches around dl_linear_tiles (transformers CLIPEncoderLayer.forward: LN1 -> attention -> residual add -> LN2 -> MLP -> residual add), a wave
+ * per row, bf16 / f16: dl_layernorm_rows = dl_layernorm without the row gather; dl_add_layernorm_rows = dl_add_layernorm; dl_add_layernorm_parts:
+ * h[r,:] = cast(h[r,:] + cast(sum_s parts[s][r][:] + bias)) in place -- parts: the fp32 [n_slices][rows][H] output of dl_linear_tiles(DL_LT_PARTS), added in
+ * slice order; bias (may be NULL): the Linear's bias; one rounding of the sum = what F.linear returns -- then out[r,:] = LN(h[r,:]) * w + b
+ * (w = b = out = NULL: the residual add only).  out_packed != 0: out is written in dl_linear_tiles' fragment order (dl_tiles_x_bytes(rows, H) bytes,
+ * H % 64 == 0) -- the x_packed input of the next projection.  H / 8 <= 256 or H == 4096.  Same arithmetic as dl_layernorm (fp32 statistics, two passes over
+ * the registers), another summation tree: rounding class, not bits. */
+int dl_layernorm_rows(const void* x, const void* w, const void* b, void* out, int64_t rows, int H, float eps, int out_packed, int dtype, void* stream);
+int dl_add_layernorm_rows(void* h, const void* delta, const void* w, const void* b, void* out, int64_t rows, int H, float eps, int out_packed, int dtype,
+                          void* stream);
+int dl_add_layernorm_parts(void* h, const float* parts, int n_slices, const void* bias, const void* w, const void* b, void* out, int64_t rows, int H, float eps,
+                           int out_packed, int dtype, void* stream);
+int dl_pack_x_rows(const void* X, int64_t ldx, void* Xp, int M, int K, int dtype, void* stream);
+int dl_linear_tiles(const void* X, int64_t ldx, int x_packed, const void* Wp, const void* bias, void* Y, int64_t ldy, int y_packed, int M, int N, int K,
+                    int epilogue, int tile_shape, int k_split, int dtype, void* stream);
+/* The same launch with a per-wave timeline: stamps[(workgroup * 8 + wave) * 8 + k], k = entry / first step landed / k loop done / stores done / half of the
+ * k loop done; zeroed by the caller.  Results are unchanged.  Measurement only: epilogue | (w << 8) makes step t read the operands of step t % w (the buffers
+ * then only need w steps of K): the second pass over a short K is served by L2 (tools/bench_linear_tiles.py --stamps). */
+int dl_linear_tiles_stamped(const void* X, int64_t ldx, int x_packed, const void* Wp, const void* bias, void* Y, int64_t ldy, int y_packed, int M, int N,
+                            int K, int epilogue, int tile_shape, int k_split, int64_t* stamps, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

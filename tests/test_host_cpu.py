@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = hip_ops.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dl_version() == hip_ops.ABI_VERSION == 3
+    assert lib.dl_version() == hip_ops.ABI_VERSION == 4
     assert isinstance(lib.dl_last_error(), bytes)
     # workspace-size queries are pure host functions
     assert lib.dl_attn_decode_workspace_bytes(2, 32, 128, 8) == 2 * 32 * 8 * 132 * 8  # split partials (granules)
