@@ -520,14 +520,21 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
     real_ag = tdist.all_gather_into_tensor if tdist.is_initialized() else None
     if real_ag is not None:  # count what the batch's gather really issues (one collective per batch, asserted by the 8-rank test)
         tdist.all_gather_into_tensor = lambda *a, **k: (n_coll.append(1), real_ag(*a, **k))[1]
+    coll = {}
     t0 = time.perf_counter()
     out, lg = run(ids, am, imgs)
-    all_lg, all_ids = dd.gather_results(lg, out, max_rows=per, max_new_tokens=new_tokens)  # one all_gather_into_tensor: logits + ids + shapes
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0  # this rank's generate() alone
+    all_lg, all_ids = dd.gather_results(lg, out, max_rows=per, max_new_tokens=new_tokens, timing=coll)  # one all_gather_into_tensor: logits + ids + shapes
     if real_ag is not None:
         tdist.all_gather_into_tensor = real_ag
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     dd.barrier()
     el = dd.max_over_ranks(time.perf_counter() - t0, device)
+    own_min, own_max = dd.min_max_over_ranks(own, device)
+    cmp_min, cmp_max = dd.min_max_over_ranks(t_compute, device)
+    coll_min, coll_max = dd.min_max_over_ranks(float(coll.get("collective_us") or 0.0), device)
     tot = dd.max_over_ranks(float(n_prompt_tok), device)  # not summed: report per-rank max and the global count below
     ok, detail = True, None
     if rank == 0 and world > 1:
@@ -547,7 +554,13 @@ def configs3_leg(model, cfg, dd, rank, world, device, dtype, new_tokens=32):
     return {"workload": f"BASELINE configs[3]: {n_req} ragged requests ({per} per rank, question lengths ~U[8,64]), {new_tokens} new tokens each, one all-gather",
             "tokens_per_s": round(n_tok_all / el, 1), "seconds": round(el, 4), "gathered_rows": int(all_ids.shape[0]), "collectives_per_batch": len(n_coll),
             "rows_per_rank": [len(dd.get_chunk(list(range(n_req)), world, r_)) for r_ in range(world)], "dp_equals_rerun_of_last_rank": ok,
-            "rerun_detail": detail, "max_prompt_tokens_per_rank": int(tot)}
+            "rerun_detail": detail, "max_prompt_tokens_per_rank": int(tot),
+            # the one collective by itself, and the per-rank spread -- to be read against SURVEY 8e's estimate for 4.1 MB per rank
+            # (~27 us direct over the 7 xGMI links, ~190 us for a per-link-bound ring); a rank that arrives late makes the others' collective_us long
+            "collective": {**coll, "collective_us_min_max_over_ranks": [round(coll_min, 1), round(coll_max, 1)],
+                           "estimate_us": {"direct_one_message_per_xgmi_link": 27, "ring_bound_by_one_link": 190, "source": "SURVEY.md section 8e (153 GB/s per link)"}},
+            "rank_spread": {"seconds_fastest_rank": round(own_min, 4), "seconds_slowest_rank": round(own_max, 4), "generate_seconds_min_max": [round(cmp_min, 4), round(cmp_max, 4)],
+                            "note": "per rank: generate() + the gather, before the closing barrier; `seconds` is the max over ranks of the barrier-closed time"}}
 
 
 def _wall(fn, n=2):
@@ -597,6 +610,32 @@ def _weight_stream_bytes(model):
     return sum(p.numel() * p.element_size() for n, p in model.named_parameters() if ".layers." in n or n.startswith("lm_head"))
 
 
+def prefill_flops(cfg, n_tokens_per_row, clip_cfg=None):
+    """Dense-arithmetic FLOPs of ONE prefill as this path executes it (SURVEY 8d accounting): decoder GEMMs 2 (4 H^2 + 3 H I) per token-layer over
+    2 N + (L - 2) N' token-layers per row (N' = N - 461 after the compaction at layer `sparse_layer`), causal attention 2 T^2 H per layer, lm_head for the
+    LAST token of every row only (the product computes one row of logits per request, DML:2709 computes all N'), and per image the CLIP ViT-L/14-336 tower
+    (23 of 24 layers: select_layer = -2), the mlp2x_gelu projector and the vision predictor."""
+    H, I, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
+    SL = cfg.sparse_config["sparse_layer"]
+    drop = N_IMG - int(N_IMG * cfg.sparse_config["vision_keep_rate"])
+    per_tok_layer = 2 * (4 * H * H + 3 * H * I)
+    gemm = attn = 0
+    for n in n_tokens_per_row:
+        n2 = n - drop
+        gemm += per_tok_layer * (min(SL, L) * n + max(L - SL, 0) * n2) + 2 * H * V
+        attn += 2 * H * (min(SL, L) * n * n + max(L - SL, 0) * n2 * n2)
+    c = clip_cfg or cfg.clip
+    C, CI, CL, T = c["hidden_size"], c["intermediate_size"], c["num_hidden_layers"] - 1, (c["image_size"] // c["patch_size"]) ** 2 + 1
+    clip = CL * (2 * T * (4 * C * C + 2 * C * CI) + 4 * T * T * C) + 2 * (T - 1) * C * 3 * c["patch_size"] ** 2
+    proj = 2 * (T - 1) * (C * H + H * H)
+    sc = cfg.sparse_config
+    dm, ff, nl = sc["d_model"], sc["dim_feedforward"], sc["num_layers"]
+    pred = 2 * N_IMG * (H * dm + nl * (4 * dm * dm + 2 * dm * ff) + dm * dm // 2) + nl * 4 * N_IMG * N_IMG * dm
+    n_img = len(n_tokens_per_row)
+    return {"decoder_gemm": gemm, "decoder_attention": attn, "clip_tower": n_img * clip, "projector": n_img * proj, "vision_predictor": n_img * pred,
+            "total": gemm + attn + n_img * (clip + proj + pred)}
+
+
 def configs2_leg(model, cfg, device, dtype, new_tokens=128):
     """BASELINE configs[2], untimed by the driver but IN the driver's line: the bench's own 7B model, 32 ragged requests in one packed batch (question
     lengths ~U[8,64], seed 1), 128 greedy tokens each.  whole_step: (all streamed weights + the K/V rows the batch's attention reads at the final
@@ -622,7 +661,16 @@ def configs2_leg(model, cfg, device, dtype, new_tokens=128):
     SL, L, H = cfg.sparse_config["sparse_layer"], cfg.num_hidden_layers, cfg.hidden_size
     kv = sum(2 * int(lens[0 if i < SL else 1][b]) * H * 2 for i in range(L) for b in range(B))
     step_bytes = _weight_stream_bytes(model) + kv
-    return {"workload": f"BASELINE configs[2]: LLaVA-1.5-7B bf16, B={B} images in one packed ragged batch (question lengths ~U[8,64]), {new_tokens} greedy tokens per row, 1 GPU",
+    fl = prefill_flops(cfg, [35 + N_IMG + q for q in n_q])
+    pf_tflops = fl["total"] / t_pre / 1e12
+    prefill_roofline = {"bound": "mfma", "achieved": round(pf_tflops, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(pf_tflops / 2500.0, 4),
+                        "flops": {k: int(v) for k, v in fl.items()}, "prefill_ms": round(t_pre * 1e3, 2),
+                        "note": "the MFMA-bound leg of the path (VERDICT r5 item 6): dense FLOPs of the 32 ragged prompts' prefill -- decoder GEMMs over 2 N + 30 N' token-layers, "
+                                "causal attention, one lm_head row per request, CLIP tower + projector + vision predictor per image -- over prefill_ms (CLIP -> first token, "
+                                "host loop included), against the dense bf16 MFMA spec; frac_of_measured_gemm (filled in by main) prices it against this box's own 8192^3 "
+                                "hipBLASLt rate; per-GEMM MFMA-busy: profiles/r06_configs2_prefill_mfma_util.txt"}
+    return {"prefill_roofline": prefill_roofline,
+            "workload": f"BASELINE configs[2]: LLaVA-1.5-7B bf16, B={B} images in one packed ragged batch (question lengths ~U[8,64]), {new_tokens} greedy tokens per row, 1 GPU",
             "tokens_per_s": round((n_prompt + B * new_tokens) / t_full, 1), "step_ms": round(t_full * 1e3, 2), "prefill_ms": round(t_pre * 1e3, 2),
             "prefill_tokens_per_s": round(n_prompt / t_pre, 1), "decode_ms_per_step": round(dec_ms, 3), "decode_tokens_per_s": round(B * 1e3 / dec_ms, 1),
             "kv_len_full_max": int(lens[0].max()), "kv_len_sparse_min_max": [int(lens[1].min()), int(lens[1].max())],
@@ -723,8 +771,12 @@ def _main(args, partial):
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
     dd.barrier()
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
+    el_min, el_max = dd.min_max_over_ranks(own_elapsed, device)  # per-rank spread (one more all-reduce, outside the timed region): a slow rank explains a 1 -> N curve
+    rank_spread = {"ms_per_step_fastest_rank": round(el_min * 1e3 / args.steps, 3), "ms_per_step_slowest_rank": round(el_max * 1e3 / args.steps, 3),
+                   "note": "each rank's own time for the K steps (its collectives included), before the closing barrier; `ms_per_step` is the max over ranks of the barrier-closed time"}
     partial.update(ms_per_step=round(elapsed * 1e3 / args.steps, 3), value_if_valid=round(world * (n_prompt + T_new) * args.steps / elapsed, 2))
     model.check_device_errors()  # a launch with in-kernel hand-offs that gave up would have poisoned its output: never report such a run
     end_lens = model.last_cache.lens.cpu().tolist()  # KV lengths at the end of a full step (before the pooled slab is reset)
@@ -780,6 +832,16 @@ def _main(args, partial):
         pmc_rel = os.path.relpath(pmc_file, ROOT)
         with open(pmc_file) as f:
             pmc = {r["case"]: r for r in json.load(f)}
+        # a committed profile only speaks for the kernels it was taken on: the file records the digests of the sources its launches were
+        # built from; a tree whose gemv / attention sources have changed since gets NO traffic figure instead of a stale one
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_report import source_digests
+
+        meta = pmc.get("_meta")
+        if meta is None or meta.get("source_digests") != source_digests():
+            stale = [k for k, v in source_digests().items() if (meta or {}).get("source_digests", {}).get(k) != v]
+            traffic_src = f"REFUSED: {pmc_rel} was taken on other kernel sources (differs: {stale}); re-run tools/refresh_profiles.sh and commit profiles/rNN_pmc_traffic.json"
+            raise LookupError(traffic_src)
         rs = [pmc[k] for k in ("gemv qkv", "gemv o", "gemv gate_up", "gemv down")]
         ratio = sum(r["fetch_bytes_corrected"] + r["write_bytes"] for r in rs) / sum(r["algorithmic_bytes"] for r in rs)
         traffic = int(ratio * roof_main["bytes"])
@@ -788,8 +850,10 @@ def _main(args, partial):
         roof_attn["traffic_over_algorithmic_pmc"] = pmc["decode_attn B=1 T=226"]["traffic_over_algorithmic"]
         if roof_fused and "gemv_qkv_attn T=226" in pmc:
             roof_fused["traffic_over_algorithmic_pmc"] = pmc["gemv_qkv_attn T=226"]["traffic_over_algorithmic"]
-    except Exception:
-        pass
+    except LookupError:
+        traffic = None  # traffic_src says why
+    except Exception as e:  # noqa: BLE001 -- no committed profile at all
+        traffic, traffic_src = None, f"no usable profiles/r*_pmc_traffic.json ({e!r})"
     # the WHOLE decode step of the product (every launch of the captured graph, idle gaps included): algorithmic bytes = all streamed weights +
     # the K/V rows the step's attention reads (2 T H E per layer) over the measured time per token
     H_ = cfg.hidden_size
@@ -807,7 +871,7 @@ def _main(args, partial):
         "dtype": "bf16", "data": "synthetic (random-init LLaVA-1.5-7B + CLIP ViT-L/14-336 weights, randn 336x336 image, random token ids)",
         "config": {"workload": "BASELINE configs[1]: LLaVA-1.5-7B bf16, B=1 per GPU, 1 image, prompt 35+576+20=631 tokens (170 after layer 2), "
                                f"vision_keep_rate=0.2, output-text KV eviction on, greedy {T_new} new tokens; step = CLIP+projector+prefill+decode",
-                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dist": dist_view, "dp_rows_identical": dp_consistent, "dp_max_abs_logit_diff": (lg_diff if world > 1 else None), "hip_graph_decode": model.use_hip_graph,
+                   "tokens_per_step_per_gpu": n_prompt + T_new, "parallelism": f"dp{world}", "dist": dist_view, "dp_rows_identical": dp_consistent, "dp_max_abs_logit_diff": (lg_diff if world > 1 else None), "rank_spread": rank_spread, "hip_graph_decode": model.use_hip_graph,
                    "predictor_gain": args.predictor_gain, "text_predictor_calibrated_keep_fraction": calib, "knobs": model.knobs(),
                    "parity_note": "ids / kept sets / KV lengths bit-exact vs the oracle; logits: 1e-3 asserted literally in fp32, bf16 held to the reference's own "
                                   "eager-bf16 noise class against an fp32 truth (DESIGN.md section 5)"},
@@ -849,6 +913,8 @@ def _main(args, partial):
                 res[key] = leg()
             except Exception as e:  # a reported leg must never take the measurement down
                 res[key] = {"error": repr(e)}
+        if isinstance(res.get("measured_ceilings"), dict) and "bf16_gemm_TFLOPs" in res["measured_ceilings"] and isinstance(res.get("configs2"), dict) and "prefill_roofline" in res["configs2"]:
+            res["configs2"]["prefill_roofline"]["frac_of_measured_gemm"] = round(res["configs2"]["prefill_roofline"]["achieved"] / res["measured_ceilings"]["bf16_gemm_TFLOPs"], 4)
         if isinstance(res.get("measured_ceilings"), dict) and "hbm_copy_GBps" in res["measured_ceilings"]:
             m = res["measured_ceilings"]["hbm_copy_GBps"]
             res["roofline"]["frac_of_measured_copy"] = round(res["roofline"]["achieved"] / m, 4)

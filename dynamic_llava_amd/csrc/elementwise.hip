@@ -190,64 +190,106 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const void* x_, con
 // ---- LayerNorm, a WAVE per row (round 6: the CLIP tower's H = 1024 rows between dl_linear_tiles calls) ----
 // The block-per-row kernel above spends a 256-thread workgroup, two LDS reductions and two barriers on a 2 KB row (577 workgroups of half-idle
 // threads: 5.2 us per launch, twice per encoder layer).  Here a row lives in ONE wave (VPL 16-byte vectors per lane, lanes contiguous: 1 KiB per load
-// instruction), both reductions are DPP + readlane, four rows share a workgroup and nothing synchronises.
+// instruction), both reductions are DPP + readlane, one 64-thread workgroup per row (577 workgroups spread over all CUs) and nothing synchronises.
 // ADD = 1: x = cast(x + delta) first (16-bit delta rows).  ADD = 2: delta = cast(sum_s parts[s][row][:] + bias) -- the fp32 k-range partial sums of
 // dl_linear_tiles(DL_LT_PARTS), added in range order, then the Linear's bias, one rounding (what F.linear would have returned), then the residual add.
 // out_tiles > 0: the normalised row goes out in dl_linear_tiles' fragment order (its x_packed input).
-template <typename T, int ADD, int VPL>
-__global__ __launch_bounds__(256) void layernorm_wave_kernel(void* x_, const void* __restrict__ delta_, int n_slices, int64_t slice_stride,
-                                                              const void* __restrict__ bias_, const void* __restrict__ w_, const void* __restrict__ b_,
-                                                              void* __restrict__ out_, int64_t rows, int H, float eps, int out_tiles) {
+template <typename T, int ADD, int VPL, int NS>
+__global__ __launch_bounds__(64) void layernorm_wave_kernel(void* x_, const void* __restrict__ delta_, int n_slices, int64_t slice_stride,
+                                                             const void* __restrict__ bias_, const void* __restrict__ w_, const void* __restrict__ b_,
+                                                             void* __restrict__ out_, int64_t rows, int H, float eps, int out_tiles) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.x;
   S* xr = reinterpret_cast<S*>(x_) + row * H;
   const int nvec = H / V;
   float x[VPL][V];
   float s = 0.f;
+  if constexpr (ADD == 2) {
+    // every request of the row -- the residual vectors, all NS slices of both vectors, the bias -- is issued before the first addition: the launch is one
+    // memory round trip deep (first build, slice after slice: 8.2 us for 13 MB).  NS = 0: any slice count, slice by slice.
+    static_assert(V == 8, "16-bit types");
+    float4 pv[VPL][NS > 0 ? NS : 1][2];
+    float bb[VPL][V];
+    int vv[VPL];
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int v = lane + 64 * i;
-    if (v < nvec) {
-      load16<T>(xr + v * V, x[i]);
-      if constexpr (ADD == 1) {
-        float d[V];
-        load16<T>(reinterpret_cast<const S*>(delta_) + row * H + v * V, d);
+    for (int i = 0; i < VPL; ++i) {
+      const int v = lane + 64 * i;
+      vv[i] = v < nvec ? v : 0;  // out-of-range lanes re-read vector 0 so that the loads stay unconditional
+      load16<T>(xr + vv[i] * V, x[i]);
+      const float* pp = reinterpret_cast<const float*>(delta_) + row * H + vv[i] * V;
+      if constexpr (NS > 0) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
-        store16<T>(xr + v * V, x[i]);
-      } else if constexpr (ADD == 2) {
-        float d[V];
-        const float* pp = reinterpret_cast<const float*>(delta_) + row * H + v * V;
+        for (int sl = 0; sl < NS; ++sl) {
+          pv[i][sl][0] = *reinterpret_cast<const float4*>(pp + sl * slice_stride);
+          pv[i][sl][1] = *reinterpret_cast<const float4*>(pp + sl * slice_stride + 4);
+        }
+      }
+      if (bias_) load16<T>(reinterpret_cast<const S*>(bias_) + vv[i] * V, bb[i]);
+    }
 #pragma unroll
-        for (int j = 0; j < V; ++j) d[j] = 0.f;
+    for (int i = 0; i < VPL; ++i) {
+      float d[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = 0.f;
+      if constexpr (NS > 0) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          d[0] += pv[i][sl][0].x; d[1] += pv[i][sl][0].y; d[2] += pv[i][sl][0].z; d[3] += pv[i][sl][0].w;
+          d[4] += pv[i][sl][1].x; d[5] += pv[i][sl][1].y; d[6] += pv[i][sl][1].z; d[7] += pv[i][sl][1].w;
+        }
+      } else {
+        const float* pp = reinterpret_cast<const float*>(delta_) + row * H + vv[i] * V;
         for (int sl = 0; sl < n_slices; ++sl) {
-#pragma unroll
-          for (int q = 0; q < V / 4; ++q) {
-            const float4 pv = *reinterpret_cast<const float4*>(pp + sl * slice_stride + q * 4);
-            d[q * 4] += pv.x;
-            d[q * 4 + 1] += pv.y;
-            d[q * 4 + 2] += pv.z;
-            d[q * 4 + 3] += pv.w;
-          }
+          const float4 a = *reinterpret_cast<const float4*>(pp + sl * slice_stride), c = *reinterpret_cast<const float4*>(pp + sl * slice_stride + 4);
+          d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
+          d[4] += c.x; d[5] += c.y; d[6] += c.z; d[7] += c.w;
         }
-        if (bias_) {
-          float bb[V];
-          load16<T>(reinterpret_cast<const S*>(bias_) + v * V, bb);
+      }
+      if (bias_) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) d[j] += bb[j];
-        }
+        for (int j = 0; j < V; ++j) d[j] += bb[i][j];
+      }
+      if (lane + 64 * i < nvec) {
 #pragma unroll
         for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + Elem<T>::round(d[j]));
-        store16<T>(xr + v * V, x[i]);
-      }
+        store16<T>(xr + vv[i] * V, x[i]);
 #pragma unroll
-      for (int j = 0; j < V; ++j) s += x[i][j];
+        for (int j = 0; j < V; ++j) s += x[i][j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nvec) {
+        load16<T>(xr + v * V, x[i]);
+        if constexpr (ADD == 1) {
+          float d[V];
+          load16<T>(reinterpret_cast<const S*>(delta_) + row * H + v * V, d);
+#pragma unroll
+          for (int j = 0; j < V; ++j) x[i][j] = Elem<T>::round(x[i][j] + d[j]);
+          store16<T>(xr + v * V, x[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += x[i][j];
+      }
     }
   }
   if (w_ == nullptr) return;  // residual add only
+  // the affine parameters are requested BEFORE the two reductions (their round trip hides behind the statistics instead of following them)
+  const S* w = reinterpret_cast<const S*>(w_);
+  const S* b = reinterpret_cast<const S*>(b_);
+  uint4 wraw[VPL], braw[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = lane + 64 * i < nvec ? lane + 64 * i : 0;
+    wraw[i] = *reinterpret_cast<const uint4*>(w + v * V);
+    braw[i] = *reinterpret_cast<const uint4*>(b + v * V);
+    pin_reg(wraw[i]);
+    pin_reg(braw[i]);
+  }
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
@@ -261,16 +303,14 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(void* x_, const voi
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-  const S* w = reinterpret_cast<const S*>(w_);
-  const S* b = reinterpret_cast<const S*>(b_);
   S* out = reinterpret_cast<S*>(out_);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int v = lane + 64 * i;
     if (v < nvec) {
       float wv[V], bv[V], o[V];
-      load16<T>(w + v * V, wv);
-      load16<T>(b + v * V, bv);
+      load16<T>(&wraw[i], wv);
+      load16<T>(&braw[i], bv);
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = (x[i][j] - mean) * rstd * wv[j] + bv[j];
       if (out_tiles > 0)
@@ -287,12 +327,21 @@ static int ln_wave_launch(void* x, const void* delta, int n_slices, const void* 
   const int nvec = H / Elem<T>::kVec;
   const int vpl = (nvec + 63) / 64;
   const int out_tiles = out_packed ? (int)((rows + 15) / 16) : 0;
-  const dim3 grid((unsigned)((rows + 3) / 4));
-#define LN_WAVE_CASE(v_)                                                                                                                                  \
-  case v_:                                                                                                                                                \
-    hipLaunchKernelGGL((layernorm_wave_kernel<T, ADD, v_>), grid, dim3(256), 0, st, x, delta, n_slices, (int64_t)rows * H, bias, w, b, out, rows, H, eps, \
-                       out_tiles);                                                                                                                        \
-    return DL_OK
+  const dim3 grid((unsigned)rows);
+#define LN_WAVE_GO(v_, ns_)                                                                                                                                 \
+  {                                                                                                                                                         \
+    hipLaunchKernelGGL((layernorm_wave_kernel<T, ADD, v_, ns_>), grid, dim3(64), 0, st, x, delta, n_slices, (int64_t)rows * H, bias, w, b, out, rows, H,    \
+                       eps, out_tiles);                                                                                                                     \
+    return DL_OK;                                                                                                                                           \
+  }
+#define LN_WAVE_CASE(v_)                                         \
+  case v_:                                                       \
+    if constexpr (ADD == 2) {                                    \
+      if (v_ <= 2 && n_slices == 2) LN_WAVE_GO(v_, 2)            \
+      if (v_ <= 2 && n_slices == 4) LN_WAVE_GO(v_, 4)            \
+      LN_WAVE_GO(v_, 0)                                          \
+    } else                                                       \
+      LN_WAVE_GO(v_, 0)
   switch (vpl) {
     LN_WAVE_CASE(1);
     LN_WAVE_CASE(2);
@@ -301,6 +350,7 @@ static int ln_wave_launch(void* x, const void* delta, int n_slices, const void* 
     LN_WAVE_CASE(8);
   }
 #undef LN_WAVE_CASE
+#undef LN_WAVE_GO
   set_error("layernorm (wave per row): H=%d is not built (H / 8 <= 256 or == 512 vectors of 16 bytes)", H);
   return DL_ERR_ARG;
 }

@@ -337,7 +337,9 @@ __global__ __launch_bounds__(64 * (kLtLoaders + WN)) void linear_tiles_kernel(co
       for (int i = 0; i < NUW; ++i) {
         const int u = u0 + c * NUW + i;
         if (u >= p.n_units) continue;
-        *reinterpret_cast<float4*>(Pp + (int64_t)row * p.ldy + u * 16 + lg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        // non-temporal: the slices are read once, by another launch on (mostly) other XCDs -- written through as they are produced instead of sitting dirty
+        // in this XCD's L2 until the end-of-kernel write-back
+        __builtin_nontemporal_store(acc[i][j], reinterpret_cast<lt_f32x4*>(Pp + (int64_t)row * p.ldy + u * 16 + lg * 4));
       }
     }
   } else {
@@ -467,7 +469,7 @@ static int lt_shape(const LtParams& p, const LtShape& s, int epilogue, hipStream
 
 // one round over the chip where the shape allows it: the fewest workgroups <= 256 among the built shapes, the largest tile first
 static LtShape lt_pick(int row_tiles, int n_units, int k_split) {
-  static const LtShape kShapes[] = {{5, 4, 2, 1, 3}, {5, 3, 2, 1, 3}, {5, 2, 2, 1, 3}, {5, 1, 2, 1, 3}};
+  static const LtShape kShapes[] = {{5, 4, 2, 1, 3}, {5, 3, 2, 1, 3}, {5, 4, 1, 1, 3}, {5, 2, 1, 1, 3}};  // (4 units as 4 waves x 1 beat 2 x 2: tools/bench_linear_tiles.py)
   for (const LtShape& s : kShapes) {
     const int64_t g = (int64_t)((row_tiles + s.tm - 1) / s.tm) * ((n_units + s.wn * s.nuw - 1) / (s.wn * s.nuw)) * k_split;
     if (g >= 224) return s;  // at least 7/8 of the chip; smaller tiles only add traffic

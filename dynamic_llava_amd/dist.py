@@ -121,7 +121,7 @@ def _collective_active(force: bool) -> bool:
 
 
 def all_gather_packed(tensors: Sequence[torch.Tensor], max_shapes: Sequence[Sequence[int]], pad_values: Optional[Sequence] = None,
-                      force: bool = False) -> List[torch.Tensor]:
+                      force: bool = False, timing: Optional[dict] = None) -> List[torch.Tensor]:
     """ONE `all_gather_into_tensor` for several [B_local, ...] tensors whose B_local (and trailing dims, e.g. T_new) may differ between
     ranks but are bounded by the host-known `max_shapes`.  Per rank one byte message: a header of true shapes, then every tensor's bytes
     in a section sized for its bound.  Returns, per tensor, the concatenation along dim 0 in rank order (== the single-process order
@@ -129,6 +129,8 @@ def all_gather_packed(tensors: Sequence[torch.Tensor], max_shapes: Sequence[Sequ
     tensors = [t.contiguous() for t in tensors]
     pad_values = list(pad_values) if pad_values is not None else [0] * len(tensors)
     if not _collective_active(force):
+        if timing is not None:
+            timing.update(collective_us=None, bytes_per_rank=0, world_size=1, note="no process group: nothing was sent")
         return list(tensors)
     for t, ms in zip(tensors, max_shapes):
         if t.dim() != len(ms) or t.dim() >= _HDR_WORDS or any(a > b for a, b in zip(t.shape, ms)):
@@ -147,7 +149,30 @@ def all_gather_packed(tensors: Sequence[torch.Tensor], max_shapes: Sequence[Sequ
         if nb:
             msg[o : o + nb] = t.reshape(-1).view(torch.uint8)
     out = torch.empty(world * off[-1], dtype=torch.uint8, device=dev)  # flat: the layout every backend's all_gather_into_tensor accepts
-    dist.all_gather_into_tensor(out, msg)
+    if timing is None:
+        dist.all_gather_into_tensor(out, msg)
+    else:
+        # the collective BY ITSELF (packing and unpacking excluded): device events on the caller's stream around the call (the process group's own stream is
+        # joined to it before the call returns control of `out`), host clock for a host-side backend; to be read against the per-link estimate of
+        # SURVEY 8e (4.1 MB per rank: ~27 us direct over xGMI, ~190 us for a ring bound by one link)
+        import time as _time
+
+        on_dev = dev.type == "cuda" and dist.get_backend() == "nccl"
+        if on_dev:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = _time.perf_counter()
+        dist.all_gather_into_tensor(out, msg)
+        if on_dev:
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3
+        else:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            us = (_time.perf_counter() - t0) * 1e6
+        timing.update(collective_us=round(us, 1), bytes_per_rank=int(off[-1]), gathered_bytes=int(world * off[-1]), world_size=world, backend=dist.get_backend(),
+                      clock="device events on the caller's stream" if on_dev else "host clock around the call")
     out = out.view(world, off[-1])
     hdrs = out[:, : hdr.numel() * 8].cpu().contiguous().view(torch.int64).view(world, len(tensors), _HDR_WORDS)  # the one device->host copy
     res = []
@@ -168,10 +193,10 @@ def all_gather_packed(tensors: Sequence[torch.Tensor], max_shapes: Sequence[Sequ
 
 
 def gather_results(logits: torch.Tensor, ids: torch.Tensor, max_rows: int, max_new_tokens: int, pad_token_id: int = 0,
-                   force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                   force: bool = False, timing: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """The per-request-batch collective of the DP path: last-token logits [B_local, V] and generated ids [B_local, T_new] of every rank in
     ONE message (see module docstring).  `max_rows` = ceil(n_requests / world) (the chunk rule), `max_new_tokens` bounds T_new."""
-    lg, tk = all_gather_packed([logits, ids], [(max_rows, logits.shape[1]), (max_rows, max_new_tokens)], [0, pad_token_id], force=force)
+    lg, tk = all_gather_packed([logits, ids], [(max_rows, logits.shape[1]), (max_rows, max_new_tokens)], [0, pad_token_id], force=force, timing=timing)
     return lg, tk
 
 
@@ -193,6 +218,15 @@ def all_gather_rows(x: torch.Tensor, pad_value=0, max_shape: Optional[Sequence[i
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def min_max_over_ranks(value: float, device) -> Tuple[float, float]:
+    """(min, max) of a per-rank scalar with ONE all-reduce (MAX over [-v, v]): the spread a slow rank leaves in a weak-scaling run."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value, value
+    t = torch.tensor([-value, value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(-t[0].item()), float(t[1].item())
 
 
 def max_over_ranks(value: float, device) -> float:

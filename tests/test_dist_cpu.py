@@ -36,6 +36,14 @@ def _worker(rank, world, port, items, q):
     # the product's per-batch collective: logits + ids + true shapes in ONE message, sized by host-known bounds (chunk rule, max_new_tokens)
     per = -(-len(items) // w)
     one_lg, one_ids = dd.gather_results(logits, ids, max_rows=per, max_new_tokens=5, pad_token_id=-1)
+    # the same message with the collective timed by itself (bench.py's configs[3] leg): same result, a duration, the per-rank message size
+    coll = {}
+    timed_lg, timed_ids = dd.gather_results(logits, ids, max_rows=per, max_new_tokens=5, pad_token_id=-1, timing=coll)
+    assert torch.equal(timed_lg, one_lg) and torch.equal(timed_ids, one_ids)
+    assert coll["world_size"] == w and coll["collective_us"] > 0 and coll["backend"] == "gloo"
+    assert coll["bytes_per_rank"] >= per * 16 * 4 + per * 5 * 8 and coll["gathered_bytes"] == w * coll["bytes_per_rank"]
+    lo, hi = dd.min_max_over_ranks(float(rank + 1), "cpu")
+    assert (lo, hi) == (1.0, float(w))
     bounded = dd.all_gather_rows(ids, pad_value=-1, max_shape=(per, 5))
     t = dd.max_over_ranks(float(rank + 1), "cpu")
     view = dd.describe()

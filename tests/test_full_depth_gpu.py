@@ -86,7 +86,8 @@ def _compare_rows_vs_oracle(model, cfg, prompts, feats, rows, forced, label, dty
                 magnitude, on either side) may legitimately fall the other way: the step is then repeated with the HIP path's decision forced, so
                 that every LATER step is still compared.  Outside the band a difference is an error, and the number of forced steps is bounded."""
                 tok = forced[j][b : b + 1][:, None]
-                l_, p_ = orc.forward(tok, past_key_values=pkv_)
+                fresh = lambda: (pkv_[0], [t.clone() for t in pkv_[1]])  # the cache adds to its length tensors in place (CU:153-164): a step that may be repeated runs on a copy
+                l_, p_ = orc.forward(tok, past_key_values=fresh())
                 tl_ = orc.records["text_logit"]
                 gap_ = float((tl_[0, 0, 0] - tl_[0, 0, 1]).abs())
                 was_forced = False
@@ -95,7 +96,7 @@ def _compare_rows_vs_oracle(model, cfg, prompts, feats, rows, forced, label, dty
                         f"{label} row {b} step {j}: eviction decision differs away from the boundary (oracle logits {tl_[0, 0].tolist()}, hip logits {tl_hip[j][b].tolist()}, "
                         f"bands {fx.boundary_band(tl_[0, 0], orc.dtype):.3g} / {fx.boundary_band(tl_hip[j][b], dtype):.3g}, gaps {gap_} / {float(gap_hip[j][b])})")
                     orc.force_text_decision = torch.tensor([[int(dec_hip[j][b])]])
-                    l_, p_ = orc.forward(tok, past_key_values=pkv_)
+                    l_, p_ = orc.forward(tok, past_key_values=fresh())
                     orc.force_text_decision = None
                     was_forced = True
                 return l_, p_, was_forced
@@ -132,7 +133,7 @@ def _compare_rows_vs_oracle(model, cfg, prompts, feats, rows, forced, label, dty
                 assert e_lit < literal_tol, f"{label} row {b} step {j}: max |hip - oracle| = {e_lit} (literal bound {literal_tol})"
                 worst = max(worst, e_lit / literal_tol)
                 continue
-            bound = 2.0 * e_ref + 2 * ULP * float(truth[j].abs().max())
+            bound = 2.0 * e_ref + 2 * fx._ULP[dtype] * float(truth[j].abs().max())  # the reference's own noise class in THIS dtype (+ 2 ulp of the logit magnitude)
             assert e_hip <= bound, f"{label} row {b} step {j}: hip err {e_hip} vs reference err {e_ref}"
             worst = max(worst, e_hip / bound)
         n_forced = len(set(forced_steps["bf16"]) | set(forced_steps["fp32"]))
@@ -181,6 +182,31 @@ def test_configs1_32_layers_prefill_and_decode_vs_oracle(model7b):
     s = _compare_rows_vs_oracle(model, cfg, [prompt], feats, [0], forced, "configs[1] 7B x 32 layers")
     assert s[0]["steps_compared"] == 9
     assert 0 < s[0]["evicted"] < 8, "the eviction must go both ways inside the compared steps"
+
+
+def test_configs1_32_layers_fp16_vs_oracle():
+    """configs[1] at full depth in fp16 -- the dtype every loader of the reference's eval / bench scripts uses (BLD:62 `torch_dtype=torch.float16`,
+    VQAL:165-167 `.half()`): 7B x 32 layers, the bench prompt, prefill + 8 teacher-forced decode steps with eviction against the oracle computing in fp16 on the
+    host (and in fp32 on the same fp16 weights as ground truth).  Same bounds as the bf16 test with fp16 ulps: kept set / position ids / decisions / KV lengths
+    bit-exact (boundary cases forced and counted), logits in the reference's own fp16 noise class."""
+    from dynamic_llava_amd.builder import build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    cfg = DynamicLlavaConfig()
+    dtype = torch.float16
+    model = build_random_model(cfg, dtype=dtype, device="cuda", seed=0, predictor_gain=50.0)
+    _calibrate(model, cfg, 35, 20, 0, dtype)
+    g = torch.Generator().manual_seed(0)
+    prompt = fx.make_prompt(cfg, 35, 20, seed=0)
+    images = torch.randn((1, 3, 336, 336), generator=g).to(dtype)
+    feats = model.encode_images(images.cuda())
+    assert torch.isfinite(feats).all()
+    forced = fx.make_forced_tokens(cfg, 8, 1, seed=5)
+    s = _compare_rows_vs_oracle(model, cfg, [prompt], feats, [0], forced, "configs[1] 7B x 32 layers fp16", dtype=dtype)
+    assert s[0]["steps_compared"] == 9
+    assert 0 < s[0]["evicted"] < 8, "the eviction must go both ways inside the compared steps"
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_configs2_batch32_ragged_32_layers_two_rows_vs_oracle(model7b):

@@ -846,6 +846,65 @@ def test_harness_long_text_kv_length_curve_matches_reference_golden(golden_dir):
     assert len(rec["max_memory"]) == n and all(m > 0 for m in rec["max_memory"])
 
 
+def test_harness_model_memory_reports_operand_copies_separately():
+    """VERDICT r5 weak #8 / BIMG:59-67, 153-156: the harness counterpart prints `model memory` like the reference script; the operand-order weight copies this
+    engine keeps beside the parameters (dl_linear_packed, dl_linear_tiles) are reported separately, and the figure WITHOUT them equals the parameter bytes to
+    1 % -- with the copies built, and with --no-operand-copies (where nothing but the tower's fused q|k|v is left to subtract)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("harness_bimg", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "harness_image_time_and_mem.py"))
+    h = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(h)
+    recs = {}
+    env_before = {k: os.environ.get(k) for k in ("DL_PACKED_GEMM", "DL_CLIP_TILES")}
+    for flag in ((), ("--no-operand-copies",)):
+        torch.cuda.empty_cache()
+        recs[flag] = h.main(["--model", "7b", "--layers", "3", "--reps", "2", *flag])
+    assert {k: os.environ.get(k) for k in env_before} == env_before, "the harness must leave the process environment as it found it"
+    with_c, without = recs[()], recs[("--no-operand-copies",)]
+    oc = with_c["operand_copy_bytes"]
+    assert with_c["operand_copies_built"] and oc["decoder_operand_order"] == 3 * (12288 + 22016 + 11008) * 4096 * 2  # q|k|v + gate|up + down, three layers, fp16
+    assert oc["clip_operand_order"] == 24 * 12 * 1024 * 1024 * 2 and oc["projector_operand_order"] == (1024 * 4096 + 4096 * 4096) * 2
+    no = without["operand_copy_bytes"]
+    assert not without["operand_copies_built"] and no["decoder_operand_order"] == 0 and no["clip_operand_order"] == 0 and no["projector_operand_order"] == 0
+    for r in (with_c, without):
+        assert abs(r["model_memory_without_operand_copies"] - r["parameter_bytes"]) <= 0.01 * r["parameter_bytes"], (r["model_memory_without_operand_copies"], r["parameter_bytes"])
+    assert with_c["parameter_bytes"] == without["parameter_bytes"]
+    assert with_c["kv_cache_length_last_layer"] == without["kv_cache_length_last_layer"] == 2 + 115
+
+
+def test_weights_replaced_after_finalize_reach_every_path():
+    """the operand-order copies are detached from the parameters; a load_state_dict() after finalize() must not leave the packed prefill
+    (dl_linear_packed / dl_linear_tiles) on the old weights while the GEMV path uses the new ones.  Two models with different seeds; loading B's state dict
+    into A must make A generate exactly what B generates (prefill logits bit-equal), through the packed paths."""
+    from dynamic_llava_amd.builder import build_random_model
+    from dynamic_llava_amd.config import DynamicLlavaConfig
+
+    cfg = DynamicLlavaConfig(num_hidden_layers=3)
+    a = build_random_model(cfg, dtype=torch.bfloat16, device="cuda", seed=1, predictor_gain=50.0)
+    b = build_random_model(cfg, dtype=torch.bfloat16, device="cuda", seed=2, predictor_gain=50.0)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn((1, 3, 336, 336), generator=g).to(torch.bfloat16).cuda()
+    ids = fx.make_prompt(cfg, 35, 20, seed=0)[None].cuda()
+    out_a0 = a.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    la0 = a.last_prefill_logits.clone()
+    out_b = b.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    lb = b.last_prefill_logits.clone()
+    assert not torch.equal(la0, lb)
+    assert a.model.layers[2].wp_qkv is not None and a.get_vision_tower()._tiles[0] is not None, "the packed paths must be the ones under test"
+    a.load_state_dict(b.state_dict())
+    out_a1 = a.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    assert torch.equal(a.last_prefill_logits, lb) and torch.equal(out_a1, out_b)
+    # an in-place edit of ONE projection is noticed too
+    with torch.no_grad():
+        a.model.layers[2].mlp.down_proj.weight.mul_(0.5)
+        b.model.layers[2].mlp.down_proj.weight.mul_(0.5)
+    out_a2 = a.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    la2 = a.last_prefill_logits.clone()
+    out_b2 = b.generate(ids, images=images, max_new_tokens=6, eos_token_id=None)
+    assert torch.equal(la2, b.last_prefill_logits) and torch.equal(out_a2, out_b2) and not torch.equal(la2, lb)
+
+
 def test_harness_multi_round_ppl_drives_the_reference_loop(golden_dir):
     """SURVEY 8f row N2 / model_lvis_multi_round_for_ppl.py:108-220: tools/harness_multi_round_ppl.py runs the reference's multi-round perplexity loop
     (prefill, label tokens teacher-forced, every later round a multi-token chunk on the returned cache, a round's last label never fed) -- on the golden

@@ -68,7 +68,7 @@ def run(model, cfg, input_ids, label_ids, images, model_memory=0, result_file=No
     return curve.rows
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch-size", type=int, default=1)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
@@ -77,7 +77,11 @@ def main():
     ap.add_argument("--keep-rate", type=float, default=0.2)
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--result-file", default=None)
-    args = ap.parse_args()
+    ap.add_argument("--no-operand-copies", action="store_true", help="build without the operand-order weight copies: `model memory` = the parameters, as in the reference")
+    args = ap.parse_args(argv)
+    knob_env = {"DL_PACKED_GEMM": "0", "DL_CLIP_TILES": "0"} if args.no_operand_copies else {}
+    saved_env = {k: os.environ.get(k) for k in knob_env}
+    os.environ.update(knob_env)  # read by the model's constructor; restored right after the build (a caller's process keeps its own settings)
     from dynamic_llava_amd.builder import build_random_model
     from dynamic_llava_amd.config import DynamicLlavaConfig
 
@@ -88,9 +92,23 @@ def main():
         kw["num_hidden_layers"] = args.layers
     cfg = DynamicLlavaConfig(**kw)
     cfg.sparse_config["vision_keep_rate"] = args.keep_rate
+    import gc
+
+    gc.collect()  # (garbage of an earlier model in this process must not be freed in the middle of the measurement)
     torch.cuda.reset_peak_memory_stats()
+    live_before_build = torch.cuda.memory_allocated()  # (another model of this process may still be alive: the figures below are THIS model's)
     model = build_random_model(cfg, dtype=torch.float16, device="cuda", seed=0, predictor_gain=50.0)
+    for k, v in saved_env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     model_memory = torch.cuda.max_memory_allocated()
+    #  memory the reference does not hold for the same checkpoint, reported beside BLTM:64's figure
+    copies, param_bytes, live = model.operand_copy_bytes(), model.parameter_bytes(), torch.cuda.memory_allocated() - live_before_build
+    print("model memory: " + str(model_memory))
+    print("operand-order weight copies: " + str(copies["total"]) + " (" + ", ".join(f"{k} {v}" for k, v in copies.items() if k != "total") + ")")
+    print("model memory without operand-order weight copies: " + str(live - copies["total"]) + " (parameters + buffers: " + str(param_bytes) + ")")
     g = torch.Generator().manual_seed(0)
     ids = torch.randint(3, cfg.vocab_size, (args.prompt_len,), generator=g)
     row = torch.cat([torch.tensor([1]), ids[: args.prompt_len // 2], torch.tensor([-200]), ids[args.prompt_len // 2 :]])
@@ -99,6 +117,11 @@ def main():
     s = cfg.clip["image_size"]
     images = torch.randn((1, 3, s, s), generator=g).to("cuda", dtype=torch.float16).repeat(args.batch_size, 1, 1, 1)
     rec = run(model, cfg, input_ids, label_ids, images, model_memory, args.result_file)
+    rec.update(model_memory=model_memory, operand_copy_bytes=copies, parameter_bytes=param_bytes, model_memory_without_operand_copies=live - copies["total"],
+               operand_copies_built=not args.no_operand_copies)
+    if args.result_file:
+        with open(args.result_file, "w", encoding="utf-8") as f:
+            json.dump(rec, f, ensure_ascii=False, indent=4)
     n_img = (s // cfg.clip["patch_size"]) ** 2
     dense = args.prompt_len + n_img + args.gen_len - 1
     print(f"final: total_token_length {rec['total_token_length'][-1]}, kv_cache_length (last layer) {rec['kv_cache_length'][-1]} "

@@ -3,7 +3,19 @@
 tools/pmc_probe.py's launches.  FETCH_SIZE on gfx950 reports 1/2 of the bytes of a wide coalesced read stream
 (MI355X_MICROARCH.md, section HBM) -> corrected x2; WRITE_SIZE is reported as-is (uncalibrated).
 usage: python tools/pmc_report.py gpurun_out/pmc_fetch/p_results.db gpurun_out/pmc_write/p_results.db gpurun_out/pmc_fetch.log"""
-import json, re, sqlite3, sys
+import hashlib, json, os, re, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources the profiled launches are compiled from: bench.py refuses a committed profile whose digests differ from the tree it runs in (VERDICT r5 weak #9)
+PROFILED_SOURCES = ["gemv.hip", "gemv_dot.h", "attn_decode.hip", "attn_decode_body.h", "granule.h", "tp_body.h", "dl_common.h"]
+
+
+def source_digests():
+    out = {}
+    for f in PROFILED_SOURCES:
+        with open(os.path.join(ROOT, "dynamic_llava_amd", "csrc", f), "rb") as fh:
+            out[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out
 
 
 def per_dispatch(db, counter):
@@ -36,6 +48,8 @@ def main():
         alg = p["algorithmic_bytes"]
         print(f"{p['tag']:28s} {f[0][0][:34]:34s} {str(f[0][1:4]):>14s} {alg/1e6:15.2f} {fb/1e6:12.2f} {wb/1e6:9.3f} {(fb+wb)/alg:11.3f} {us:8.2f}")
         res.append({"case": p["tag"], "kernel": f[0][0], "algorithmic_bytes": alg, "fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_over_algorithmic": round((fb + wb) / alg, 4), "kernel_us_under_pmc": round(us, 2)})
+    res.append({"case": "_meta", "source_digests": source_digests(),
+                "note": "sha256[:16] of the csrc files the profiled kernels are built from, at the time of the PMC passes; bench.py recomputes them and refuses this file if one differs"})
     print("JSON " + json.dumps(res))
 
 
