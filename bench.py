@@ -821,7 +821,7 @@ def _main(args, partial):
     extra = ([roof_fused] if roof_fused else []) + [
         roof_attn,
         decode_attn_roofline(model, f"bench workload, layers 0-1 at the last decode step: B=1, T={t_full + 1}", 1, [t_full + 1], nH, d),
-        decode_attn_roofline(model, "configs[2]-like: B=32 ragged T~U[200,900]", 32, [200 + (i * 701) % 700 for i in range(32)], nH, d),
+        decode_attn_roofline(model, "configs[2]-like: B=32 ragged, T spread over [299, 887] (round 6: a real spread -- 200 + 229 i mod 700; up to round 5 the ladder 701 i mod 700 made this entry T = 200..231)", 32, [200 + (i * 229) % 700 for i in range(32)], nH, d),
         decode_attn_roofline(model, "configs[4]-like: 13B heads (40x128), B=1, T=2048", 1, [2048], 40, d),
         decode_attn_roofline(model, "B=32, T=2048", 32, [2048] * 32, nH, d),
     ] + gemv_shapes + linear_packed_roofline(model) + other_kernel_rooflines(model, n_prompt)

@@ -20,6 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # kernel on a second stream; this is what made two ranks sharing one GPU disagree -- DESIGN.md section 5).  Scalar fp32 VALU code has the
 # same rounding, so results do not change; tests/test_host_cpu.py disassembles the library and fails if such an instruction comes back.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("HIPCC_EXTRA", "").split()  # measurement builds (e.g. -DDL_LP_ABLATIONS); part of the stamp, so such a library is never mistaken for the product's
 
 
 def _sources():

@@ -116,11 +116,14 @@ def load_pretrained_model(model_path, model_base=None, model_name=None, load_8bi
         from transformers import CLIPImageProcessor, CLIPVisionModel
 
         local = os.path.isdir(str(vt_path))
+        ckpt_has_tower = any("vision_tower" in k for k in seen)
         try:
-            clip = CLIPVisionModel.from_pretrained(vt_path, local_files_only=not local, cache_dir=cache_dir)
+            #  a checkpoint that carries the tower's own (possibly fine-tuned: unfreeze_mm_vision_tower) tensors keeps them -- in the reference
+            # the checkpoint's tensors win because from_pretrained runs BEFORE load_model's copy (BLD:237-242) -- and only the image processor is loaded by name
+            clip = None if ckpt_has_tower else CLIPVisionModel.from_pretrained(vt_path, local_files_only=not local, cache_dir=cache_dir)
             image_processor = CLIPImageProcessor.from_pretrained(vt_path, local_files_only=not local, cache_dir=cache_dir)
-        except Exception as e:  # noqa: BLE001 -- re-raised below unless the checkpoint itself holds the tower
-            if not any("vision_tower" in k for k in seen):
+        except (OSError, EnvironmentError) as e:  # not found locally / not in the cache: re-raised below unless the checkpoint itself holds the tower
+            if not ckpt_has_tower:
                 raise FileNotFoundError(
                     f"vision tower {vt_path!r} (config.mm_vision_tower) is neither a local directory nor present in the local Hugging Face cache "
                     f"(cache_dir={cache_dir!r}, HF_HOME={os.environ.get('HF_HOME')!r}); there is no network to fetch it from, and the checkpoint holds no vision_tower tensors") from e

@@ -54,9 +54,25 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
   __shared__ float sm_o[NG * D];
 
   DL_STAMP(0, false);
-  const int split = blockIdx.x, n_splits = gridDim.x, h = blockIdx.y, b = blockIdx.z;
+  const int split = blockIdx.x, n_splits = gridDim.x, h = blockIdx.y;
   const int n_heads = gridDim.y;
   const int tid = threadIdx.x;
+  // Ragged batches, longest row first (round 6): workgroups are dispatched in blockIdx order (x, then y, then z), so slice z of the grid takes the row with
+  // the z-th LARGEST length (ties: lower row index) instead of row z -- the long rows start first and the short ones fill the tail, whatever order the caller's
+  // batch is in (a batch of 32 requests with 200..900 keys otherwise ends with a few CUs finishing their 900-key rows alone).  Every wave ranks the <= 64
+  // lengths itself (B readlanes); which slice computes a row does not change a bit of the result.
+  int b = blockIdx.z;
+  if (gridDim.z > 1 && gridDim.z <= 64) {
+    const int lane = tid & 63, Bn = (int)gridDim.z;
+    const int my = lane < Bn ? kv_len[lane] : -1;
+    int rank = 0;
+    for (int j = 0; j < Bn; ++j) {
+      const int lj = __builtin_amdgcn_readlane(my, j);
+      rank += (lj > my || (lj == my && j < lane)) ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(lane < Bn && rank == (int)blockIdx.z);
+    b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+  }
   const int kvh = h / n_rep;
   const S* row = reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride;
   const int T_old = kv_len[b];

@@ -30,7 +30,8 @@
 #include <mutex>
 #include <type_traits>
 
-#define DL_LP_ABLATIONS 1  // also builds the ablated variants tools/bench_linear_packed.py --ablate times (no MFMA / no X loads / loaders alone)
+// -DDL_LP_ABLATIONS (measurement builds only: HIPCC_EXTRA=-DDL_LP_ABLATIONS python -m dynamic_llava_amd.build_ext --force) also builds the ablated variants that
+// tools/bench_linear_packed.py --ablate times (no MFMA / no X loads / loaders alone); the product library does not contain them.
 
 #include "dl_common.h"
 
@@ -527,6 +528,11 @@ __global__ __launch_bounds__(256) void pack_x_tiles_kernel(const uint16_t* __res
   }
 }
 
+// The flag words sit in a FIXED region at the start of the workspace, whatever the call's (units per workgroup, k_split): one workspace shared by calls of
+// different shapes (model._lp_ws) then never has one call's fp32 tiles on top of another call's flag words, and "the flag words are zero before and after
+// every launch" holds literally.  256 unit sets x 7 partner ranges x 4 consumer waves x 4 bytes = 28 KiB at most.
+constexpr int64_t kLpFlagBytes = 64 * 1024;
+
 static int lp_tiles_per_wave(int M) { return ((M + 15) / 16 + dl::kLpConsumers - 1) / dl::kLpConsumers; }
 
 }  // namespace dl
@@ -569,8 +575,7 @@ extern "C" int64_t dl_linear_packed_workspace_bytes(int M, int N, int K, int epi
   const int nu = units_per_workgroup > 0 ? units_per_workgroup : lp_pick_units(N / 16, epilogue, k_split);
   const int64_t n_sets = (N / 16 + nu - 1) / nu;
   const int64_t n_slots = n_sets * (k_split - 1) * dl::kLpConsumers;
-  const int64_t flag_bytes = (n_slots * 4 + 255) / 256 * 256;
-  return flag_bytes + n_slots * nu * dl::lp_tiles_per_wave(M) * 1024;
+  return dl::kLpFlagBytes + n_slots * nu * dl::lp_tiles_per_wave(M) * 1024;
 }
 
 static int lp_entry(const void* X, int64_t ldx, int x_packed, const void* Wp, void* Y, int64_t ldy, const void* resid, int64_t ldr, int M, int N, int K, int epilogue,
@@ -617,7 +622,8 @@ static int lp_entry(const void* X, int64_t ldx, int x_packed, const void* Wp, vo
   p.trim256 = (k_split > 1 && epilogue != LP_EPI_PARTS) ? (trim_arg ? trim_arg - 1 : 24) : 0;  // default: partners 9 % short of an even share (tools/bench_lp_trim.py)
   const int64_t n_slots = (int64_t)p.n_sets * (k_split - 1) * kLpConsumers;
   p.flags = reinterpret_cast<int*>(workspace);
-  p.parts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (n_slots * 4 + 255) / 256 * 256);
+  DL_REQUIRE(n_slots * 4 <= kLpFlagBytes, "dl_linear_packed: %lld hand-over slots exceed the flag region", (long long)n_slots);
+  p.parts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kLpFlagBytes);
   p.err = err_flag;
   p.stamps = stamps;
   int rc = DL_ERR_ARG;

@@ -7,6 +7,10 @@ Everything else on the path is a hand-written HIP kernel behind the C ABI (inclu
 RMSNorm(+residual), RoPE+KV append, varlen prefill attention, ragged split-KV decode attention, SiLU*up,
 vision predictor, top-k select, token compaction, text predictor + eviction decision, greedy/advance.
 
+Round 6: this file is the API shell (construction, finalize(), forward(), generate() and their glue); the parameter tree and the vision side live in
+modules.py, the prompt layout / prefill planner / layer loop in prefill.py (PrefillEngine), the decode-step builders and their schedule in decode.py
+(DecodeScheduler) -- mixins of the one class the reference's harness sees.
+
 Design (not a translation of the reference's op sequence):
   * activations are PACKED varlen [total_tokens, H] + cu_seqlens, never padded [B, N, H];
   * after layer `sparse_layer` the packed batch is physically compacted (k image tokens per row survive);
@@ -31,475 +35,13 @@ from . import hip_ops as ops
 from .cache import KVSlabCache
 from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, DynamicLlavaConfig
 
-USER_IDS = [11889, 29901]  # "USER:" -- llava/model/dynamic_llava_arch.py:36
+from .decode import DecodeScheduler, _DecodeState  # noqa: F401
+from .modules import (CLIPVisionTower, CausalLMOutputWithPast, DynamicLlamaDecoderLayer, DynamicLlavaLlamaModel, TextPredictor,  # noqa: F401 (re-exported:
+                      VisionPredictor)  # tests, tools and the package's lazy attributes import these names from here)
+from .prefill import USER_IDS, PrefillEngine  # noqa: F401
 
 
-@dataclass
-class CausalLMOutputWithPast:
-    """Mirror of transformers.modeling_outputs.CausalLMOutputWithPast (fields the harness reads)."""
-
-    loss: Optional[torch.Tensor] = None
-    logits: Optional[torch.Tensor] = None
-    past_key_values: Optional[KVSlabCache] = None
-    hidden_states: Optional[tuple] = None
-    attentions: Optional[tuple] = None
-
-    def __getitem__(self, i):
-        return tuple(v for v in (self.loss, self.logits, self.past_key_values) if v is not None)[i]
-
-
-# ------------------------------------------------------------------------------------------------
-# parameter containers: same module tree / state-dict keys as the reference, so checkpoints load
-# ------------------------------------------------------------------------------------------------
-class _Attn(nn.Module):
-    def __init__(self, cfg):
-        super().__init__()
-        H, d = cfg.hidden_size, cfg.head_dim
-        self.q_proj = nn.Linear(H, cfg.num_attention_heads * d, bias=False)
-        self.k_proj = nn.Linear(H, cfg.num_key_value_heads * d, bias=False)
-        self.v_proj = nn.Linear(H, cfg.num_key_value_heads * d, bias=False)
-        self.o_proj = nn.Linear(cfg.num_attention_heads * d, H, bias=False)
-
-
-class _Mlp(nn.Module):
-    def __init__(self, cfg):
-        super().__init__()
-        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
-        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
-        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
-
-
-class _Norm(nn.Module):
-    def __init__(self, n):
-        super().__init__()
-        self.weight = nn.Parameter(torch.ones(n))
-
-
-class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-1234
-    def __init__(self, cfg):
-        super().__init__()
-        self.self_attn = _Attn(cfg)
-        self.mlp = _Mlp(cfg)
-        self.input_layernorm = _Norm(cfg.hidden_size)
-        self.post_attention_layernorm = _Norm(cfg.hidden_size)
-        self.w_qkv = None  # fused [nH*d + 2*nKV*d, H]; q/k/v_proj.weight become views of it (no extra memory)
-        self.w_gu = None  # fused [2*I, H]
-        # round 5: second copies of q|k|v, gate|up and down_proj in matrix-core operand order for dl_linear_packed (the prefill GEMMs at <= 256 packed
-        # rows, decode batches 4..32); gate|up with gate / up tiles interleaved for the SiLU * up epilogue.  +371 MB per 7B layer (q|k|v 101 + gate|up 180 +
-        # down 90: 11.9 GB over 32 layers, 23 GB at 13B) of 288 GB; the state dict is untouched; model.operand_copy_bytes() reports them.
-        self.wp_qkv = None
-        self.wp_gu = None
-        self.wp_down = None
-
-    def pack(self, operand_copies: bool = False):
-        a, m = self.self_attn, self.mlp
-        self.w_qkv = torch.cat([a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data], dim=0).contiguous()
-        nq, nk = a.q_proj.weight.shape[0], a.k_proj.weight.shape[0]
-        a.q_proj.weight.data = self.w_qkv[:nq]
-        a.k_proj.weight.data = self.w_qkv[nq : nq + nk]
-        a.v_proj.weight.data = self.w_qkv[nq + nk :]
-        self.w_gu = torch.cat([m.gate_proj.weight.data, m.up_proj.weight.data], dim=0).contiguous()
-        I = m.gate_proj.weight.shape[0]
-        m.gate_proj.weight.data = self.w_gu[:I]
-        m.up_proj.weight.data = self.w_gu[I:]
-        self.wp_qkv = self.wp_gu = self.wp_down = None
-        if operand_copies and self.w_qkv.dtype in (torch.bfloat16, torch.float16) and self.w_qkv.shape[1] % 64 == 0 and self.w_qkv.shape[0] % 16 == 0 and I % 16 == 0:
-            self.wp_qkv = ops.pack_weight_tiles(self.w_qkv)
-            self.wp_gu = ops.pack_weight_tiles(self.w_gu, gate_up_pairs=True)
-            if I % 64 == 0:  # down_proj reads the SiLU * up epilogue's fragment-order output and leaves fp32 partial sums for the residual-add / RMSNorm launch
-                self.wp_down = ops.pack_weight_tiles(m.down_proj.weight.data.contiguous())
-
-
-class _TransformerBlock(nn.Module):  # custom_transformer_layer.py:276-318 (parameters only)
-    def __init__(self, dim, ff):
-        super().__init__()
-        self.norm1 = nn.LayerNorm(dim)
-        self.attn = nn.Module()
-        self.attn.qkv = nn.Linear(dim, dim * 3, bias=False)
-        self.attn.proj = nn.Linear(dim, dim)
-        self.norm2 = nn.LayerNorm(dim)
-        self.mlp = nn.Module()
-        self.mlp.fc1 = nn.Linear(dim, ff)
-        self.mlp.fc2 = nn.Linear(ff, dim)
-
-
-class VisionPredictor(nn.Module):
-    """dynamic_modeling_llama.py:1308-1359.  forward(x [B,n,H], image_policy) -> logits [B,n,2], computed by
-    the HIP pipeline (dl_vision_predictor).  Hookable like the reference module (visualize.py:74)."""
-
-    def __init__(self, input_dim=4096, d_model=512, nhead=8, dim_feedforward=2048, num_layers=2):
-        super().__init__()
-        self.input_dim, self.d_model, self.nhead, self.dim_feedforward, self.num_layers = input_dim, d_model, nhead, dim_feedforward, num_layers
-        self.down_mlp = nn.Sequential(nn.LayerNorm(input_dim), nn.Linear(input_dim, d_model), nn.GELU())
-        self.transformer = nn.Sequential(*[_TransformerBlock(d_model, dim_feedforward) for _ in range(num_layers)])
-        self.output_mlp = nn.Sequential(
-            nn.Linear(d_model, d_model // 2), nn.GELU(), nn.Linear(d_model // 2, d_model // 4), nn.GELU(), nn.Linear(d_model // 4, 2)
-        )
-        self._w = None
-        self.last_score = None
-
-    def _weights(self):
-        key = self.down_mlp[1].weight.data_ptr()
-        if self._w is None or self._w[0] != key:
-            w = ops.VpWeights()
-            dp = lambda t: t.data_ptr()
-            w.ln_w, w.ln_b = dp(self.down_mlp[0].weight), dp(self.down_mlp[0].bias)
-            w.down_w, w.down_b = dp(self.down_mlp[1].weight), dp(self.down_mlp[1].bias)
-            w.out0_w, w.out0_b = dp(self.output_mlp[0].weight), dp(self.output_mlp[0].bias)
-            w.out2_w, w.out2_b = dp(self.output_mlp[2].weight), dp(self.output_mlp[2].bias)
-            w.out4_w, w.out4_b = dp(self.output_mlp[4].weight), dp(self.output_mlp[4].bias)
-            w.num_layers = self.num_layers
-            for j, blk in enumerate(self.transformer):
-                b = w.blocks[j]
-                b.norm1_w, b.norm1_b = dp(blk.norm1.weight), dp(blk.norm1.bias)
-                b.qkv_w = dp(blk.attn.qkv.weight)
-                b.proj_w, b.proj_b = dp(blk.attn.proj.weight), dp(blk.attn.proj.bias)
-                b.norm2_w, b.norm2_b = dp(blk.norm2.weight), dp(blk.norm2.bias)
-                b.fc1_w, b.fc1_b = dp(blk.mlp.fc1.weight), dp(blk.mlp.fc1.bias)
-                b.fc2_w, b.fc2_b = dp(blk.mlp.fc2.weight), dp(blk.mlp.fc2.bias)
-            self._w = (key, w)
-        return self._w[1]
-
-    def score_packed(self, hidden, cu_seqlens, img_start, n_img):
-        """packed hidden [total,H] -> (logits [B,n,2], score [B,n]); image rows gathered inside the LN kernel."""
-        return ops.vision_predictor(hidden, cu_seqlens, img_start, n_img, self._weights(), self.d_model, self.nhead, self.dim_feedforward)
-
-    def forward(self, x, image_policy=None):
-        B, n, H = x.shape
-        x = x.contiguous().view(B * n, H)
-        cu = torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device=x.device)
-        start = torch.zeros(B, dtype=torch.int32, device=x.device)
-        logits, self.last_score = self.score_packed(x, cu, start, n)
-        return logits
-
-
-class TextPredictor(nn.Module):
-    """dynamic_modeling_llama.py:1362-1387 (parameters) + the decision of DML:2388-2391 (dl_text_predictor_decide)."""
-
-    def __init__(self, input_dim=4096, d_model=512, **_):
-        super().__init__()
-        self.input_dim, self.d_model = input_dim, d_model
-        self.output_mlp = nn.Sequential(
-            nn.LayerNorm(input_dim), nn.Linear(input_dim, d_model), nn.GELU(), nn.Linear(d_model, d_model // 2), nn.GELU(),
-            nn.Linear(d_model // 2, d_model // 4), nn.GELU(), nn.Linear(d_model // 4, 2),
-        )
-        self._w = None
-
-    def _weights(self):
-        key = self.output_mlp[1].weight.data_ptr()
-        if self._w is None or self._w[0] != key:
-            w = ops.TpWeights()
-            m = self.output_mlp
-            w.ln_w, w.ln_b = m[0].weight.data_ptr(), m[0].bias.data_ptr()
-            w.l1_w, w.l1_b = m[1].weight.data_ptr(), m[1].bias.data_ptr()
-            w.l3_w, w.l3_b = m[3].weight.data_ptr(), m[3].bias.data_ptr()
-            w.l5_w, w.l5_b = m[5].weight.data_ptr(), m[5].bias.data_ptr()
-            w.l7_w, w.l7_b = m[7].weight.data_ptr(), m[7].bias.data_ptr()
-            self._w = (key, w)
-        return self._w[1]
-
-    def decide(self, x, workspace, logits_out, decision):
-        return ops.text_predictor_decide(x, self._weights(), self.d_model, workspace, logits_out, decision)
-
-    def forward(self, x):
-        """x [..., H] -> logits [..., 2] (fp32 values of the model-dtype logits)."""
-        shp = x.shape[:-1]
-        x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        B = x2.shape[0]
-        ws = ops.text_predictor_workspace(B, self.d_model, x.device)
-        lg = torch.empty((B, 2), dtype=torch.float32, device=x.device)
-        dec = torch.empty(B, dtype=torch.int32, device=x.device)
-        self.decide(x2, ws, lg, dec)
-        return lg.to(x.dtype).reshape(*shp, 2)
-
-
-class CLIPVisionTower(nn.Module):
-    """llava/model/multimodal_encoder/clip_encoder.py:7-102.  The HF CLIPVisionModel is the parameter container (state-dict keys
-    unchanged); forward() runs its encoder on the library GEMMs + this package's HIP kernels."""
-
-    def __init__(self, cfg: DynamicLlavaConfig):
-        super().__init__()
-        from transformers import CLIPVisionConfig, CLIPVisionModel
-
-        self.select_layer = cfg.mm_vision_select_layer
-        self.select_feature = cfg.mm_vision_select_feature
-        self.vision_tower_name = cfg.mm_vision_tower
-        c = cfg.clip
-        self.vision_tower = CLIPVisionModel(
-            CLIPVisionConfig(
-                hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
-                num_attention_heads=c["num_attention_heads"], image_size=c["image_size"], patch_size=c["patch_size"], projection_dim=c["hidden_size"],
-            )
-        )
-        self.vision_tower.requires_grad_(False)
-        self.is_loaded = True
-        # round 6 knobs: the tower's projections on dl_linear_tiles (False: the library GEMMs), up to how many images per call, k ranges of out_proj / fc2
-        self.tiles_gemm = os.environ.get("DL_CLIP_TILES", "1") != "0"
-        self.tiles_max_batch = 4
-        self.tiles_ksplit_out, self.tiles_ksplit_fc2 = 2, 4
-        self._patch_embed_as_gemm()
-
-    def _patch_embed_as_gemm(self):
-        """The ViT patch embedding is a stride-14 14x14 conv == one GEMM over unfolded patches.  MIOpen serves it with a
-        ~330 us naive fallback kernel in bf16; the same weights through F.linear take ~20 us.  Still plain PyTorch."""
-        import types
-
-        conv = next(m for n, m in self.vision_tower.named_modules() if n.endswith("patch_embedding"))  # module path differs across HF versions
-        ps = conv.kernel_size[0]
-
-        def gemm_forward(mod, x):
-            B, C, Hh, Ww = x.shape
-            gh, gw = Hh // ps, Ww // ps
-            patches = x.reshape(B, C, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ps * ps)
-            y = F.linear(patches, mod.weight.reshape(mod.weight.shape[0], -1), mod.bias)
-            return y.transpose(1, 2).reshape(B, -1, gh, gw)
-
-        conv.forward = types.MethodType(gemm_forward, conv)
-
-    def pack(self):
-        """Fuse q|k|v of every encoder layer into one [3C, C] weight (+bias) for a single projection GEMM, and (16-bit dtypes) keep the four projections of
-        every layer a second time in matrix-core operand order for dl_linear_tiles (+0.6 GB for ViT-L/14-336 in bf16; `tiles_bytes` says how much: the
-        harness counterparts report it).  Call after the weights are loaded / cast (finalize() does)."""
-        vm = next(m for n, m in self.vision_tower.named_modules() if hasattr(m, "encoder") and hasattr(m, "embeddings"))
-        self._vm = [vm]  # in a list: not a registered submodule (the parameter tree / state-dict keys stay HF's)
-        self._qkv = []
-        self._tiles = []  # per layer: (wp_qkv, wp_out, wp_fc1, wp_fc2) or None
-        self.tiles_bytes = 0
-        for l in vm.encoder.layers:
-            a = l.self_attn
-            wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()
-            self._qkv.append((wq, torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()))
-            ws = (wq, a.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)
-            if self.tiles_gemm and wq.is_cuda and all(ops.linear_tiles_ok(1, w.shape[0], w.shape[1], w.dtype) for w in ws):
-                self._tiles.append(tuple(ops.pack_weight_tiles(w.detach().contiguous()) for w in ws))
-                self.tiles_bytes += sum(t.numel() * t.element_size() for t in self._tiles[-1])
-            else:
-                self._tiles.append(None)
-        self._tiles_src = [(w.data_ptr(), w._version) for l in vm.encoder.layers for w in (l.self_attn.q_proj.weight, l.self_attn.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)]
-        self._cu = {}
-        return self
-
-    def _tiles_fresh(self):
-        """The operand-order copies are detached: replacing / editing a weight after pack() must not leave the tiled path on the old values."""
-        vm = self._vm[0]
-        now = [(w.data_ptr(), w._version) for l in vm.encoder.layers for w in (l.self_attn.q_proj.weight, l.self_attn.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)]
-        return now == self._tiles_src
-
-    def _n_layers_needed(self):
-        """hidden_states[k] is the stream after k encoder layers; select_layer = -2 needs L-1 of the L layers (HF computes all L
-        and throws the last one away)."""
-        L = len(self._vm[0].encoder.layers)
-        k = self.select_layer if self.select_layer >= 0 else L + 1 + self.select_layer
-        if not 0 <= k <= L:
-            raise ValueError(f"mm_vision_select_layer={self.select_layer} out of range for {L} layers")
-        return k
-
-    @torch.no_grad()
-    def forward(self, images):
-        """clip_encoder.py:53-71 (`feature_select(vision_tower(images, output_hidden_states=True))`).  The encoder runs packed
-        ([B*T, C] rows, cu_seqlens) on: hipBLASLt for the plain GEMMs (bias fused), dl_layernorm / dl_add_layernorm (residual add +
-        next LayerNorm in one pass), dl_attn_prefill (non-causal MFMA flash attention, head_dim 64) and dl_quick_gelu -- 8 launches
-        per layer instead of the ~18 of the eager module, each rounding to the model dtype where the eager module does."""
-        if getattr(self, "_vm", None) is None:
-            self.pack()
-        vm = self._vm[0]
-        cfgv = vm.config if hasattr(vm, "config") else self.config
-        if cfgv.hidden_act != "quick_gelu":
-            raise ops.HipOpsError(f"CLIP hidden_act={cfgv.hidden_act!r}: only quick_gelu (OpenAI CLIP) is implemented")
-        x = images.to(device=self.device, dtype=self.dtype)
-        B = x.shape[0]
-        emb = vm.embeddings(x)  # patch GEMM + class token + position embedding (once per image; plain torch)
-        T, C = emb.shape[1], emb.shape[2]
-        nH = cfgv.num_attention_heads
-        d = C // nH
-        eps = cfgv.layer_norm_eps
-        pre = getattr(vm, "pre_layrnorm", None) or getattr(vm, "pre_layernorm")
-        h = ops.layernorm(emb.reshape(B * T, C).contiguous(), pre.weight, pre.bias, eps)
-        cu = self._cu.get(B)
-        if cu is None:
-            cu = self._cu[B] = (torch.arange(B + 1, device=h.device, dtype=torch.int32) * T).contiguous()
-        if not (h.dtype == torch.float32 or d in (32, 64, 128)):
-            raise ops.HipOpsError(f"CLIP head_dim={d}: dl_attn_prefill tiles head dims 32 / 64 / 128 in 16-bit dtypes (no torch fallback exists)")
-        layers = vm.encoder.layers[: self._n_layers_needed()]
-        if not self._tiles_fresh():
-            self.pack()
-        if len(layers) and all(self._tiles[i] is not None for i in range(len(layers))) and B <= self.tiles_max_batch:
-            self._encoder_tiles(h, layers, cu, B, T, C, nH, d, eps)
-        else:
-            self._encoder_library(h, layers, cu, B, T, C, nH, d, eps)
-        f = h.view(B, T, C)
-        if self.select_feature == "patch":
-            f = f[:, 1:]
-        elif self.select_feature != "cls_patch":
-            raise ValueError(f"Unexpected select feature: {self.select_feature}")
-        return f.to(images.dtype) if images.is_floating_point() else f
-
-    def _encoder_library(self, h, layers, cu, B, T, C, nH, d, eps):
-        """Library GEMMs (bias fused) + this package's glue kernels: fp32 models, batches past `tiles_max_batch` images (the library's large-tile kernels
-        are MFMA-bound there), towers whose shapes dl_linear_tiles does not take."""
-        xn = ops.layernorm(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if len(layers) else None
-        for i, l in enumerate(layers):
-            wq, bq = self._qkv[i]
-            qkv = F.linear(xn, wq, bq)
-            attn = torch.empty((B * T, C), dtype=h.dtype, device=h.device)
-            ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
-            y = F.linear(attn, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias)
-            xn = ops.add_layernorm(h, y, l.layer_norm2.weight, l.layer_norm2.bias, eps)
-            g = ops.quick_gelu(F.linear(xn, l.mlp.fc1.weight, l.mlp.fc1.bias))
-            y = F.linear(g, l.mlp.fc2.weight, l.mlp.fc2.bias)
-            if i + 1 < len(layers):
-                nl = layers[i + 1]
-                xn = ops.add_layernorm(h, y, nl.layer_norm1.weight, nl.layer_norm1.bias, eps)
-            else:
-                ops.add_layernorm(h, y)
-
-    def _encoder_tiles(self, h, layers, cu, B, T, C, nH, d, eps):
-        """Round 6: every projection on dl_linear_tiles (own MFMA GEMM on operand-order weight copies; 7 launches per layer).  Activations between the
-        launches travel in the GEMM's fragment order wherever a producer can write it: LN -> q|k|v, LN -> fc1, fc1 (+ QuickGELU in the epilogue) -> fc2;
-        out_proj and fc2 leave fp32 k-range partial sums that the residual-add / LayerNorm launch adds in order (with the Linear's bias, one rounding:
-        F.linear's value)."""
-        M = B * T
-        I = layers[0].mlp.fc1.weight.shape[0]
-        xn = ops.layernorm_rows(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps, packed=True)
-        attn = torch.empty((M, C), dtype=h.dtype, device=h.device)
-        qkv = torch.empty((M, 3 * C), dtype=h.dtype, device=h.device)
-        ks_o, ks_2 = max(1, min(self.tiles_ksplit_out, C // 64)), max(1, min(self.tiles_ksplit_fc2, I // 64))  # (tiny test towers: K = 64 is one step)
-        for i, l in enumerate(layers):
-            wp_qkv, wp_out, wp_fc1, wp_fc2 = self._tiles[i]
-            ops.linear_tiles(xn, wp_qkv, 3 * C, bias=self._qkv[i][1], out=qkv, x_packed_mk=(M, C))
-            ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
-            parts = ops.linear_tiles(attn, wp_out, C, epilogue=ops.LT_PARTS, k_split=ks_o)
-            xn = ops.add_layernorm_parts(h, parts, l.self_attn.out_proj.bias, l.layer_norm2.weight, l.layer_norm2.bias, eps, packed=True)
-            g = ops.linear_tiles(xn, wp_fc1, I, bias=l.mlp.fc1.bias, epilogue=ops.LT_QGELU, x_packed_mk=(M, C), y_packed=True)
-            parts = ops.linear_tiles(g, wp_fc2, C, epilogue=ops.LT_PARTS, k_split=ks_2, x_packed_mk=(M, I))
-            if i + 1 < len(layers):
-                nl = layers[i + 1]
-                xn = ops.add_layernorm_parts(h, parts, l.mlp.fc2.bias, nl.layer_norm1.weight, nl.layer_norm1.bias, eps, packed=True)
-            else:
-                ops.add_layernorm_parts(h, parts, l.mlp.fc2.bias)
-
-    @torch.no_grad()
-    def forward_eager(self, images):
-        """The HF module as the reference runs it (tests compare the packed path against this)."""
-        out = self.vision_tower(images.to(device=self.device, dtype=self.dtype), output_hidden_states=True)
-        f = out.hidden_states[self.select_layer]
-        return f[:, 1:] if self.select_feature == "patch" else f
-
-    @property
-    def dtype(self):
-        return next(self.vision_tower.parameters()).dtype
-
-    @property
-    def device(self):
-        return next(self.vision_tower.parameters()).device
-
-    @property
-    def config(self):
-        return self.vision_tower.config
-
-    @property
-    def hidden_size(self):
-        return self.config.hidden_size
-
-    @property
-    def num_patches(self):
-        return (self.config.image_size // self.config.patch_size) ** 2
-
-
-class DynamicLlavaLlamaModel(nn.Module):
-    """Parameter tree of dynamic_modeling_llama.py:1586-1647 + dynamic_llava_arch.py:41-51."""
-
-    def __init__(self, cfg: DynamicLlavaConfig, with_vision_tower=True):
-        super().__init__()
-        self.config = cfg
-        sc = cfg.sparse_config
-        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
-        self.layers = nn.ModuleList([DynamicLlamaDecoderLayer(cfg) for _ in range(cfg.num_hidden_layers)])
-        self.norm = _Norm(cfg.hidden_size)
-        kw = dict(input_dim=cfg.hidden_size, d_model=sc["d_model"], nhead=sc["nhead"], dim_feedforward=sc["dim_feedforward"], num_layers=sc["num_layers"])
-        if sc["use_vision_predictor"]:
-            self.image_score_predictor = VisionPredictor(**kw)
-        if sc["use_text_predictor"]:
-            if sc["use_output_text_predictor"]:
-                self.output_text_score_predictor = TextPredictor(**kw)
-            if sc["use_instruct_predictor"]:
-                self.instruct_score_predictor = TextPredictor(**kw)
-        if with_vision_tower:
-            self.vision_tower = CLIPVisionTower(cfg)
-        if cfg.mm_projector_type != "mlp2x_gelu":
-            raise NotImplementedError("only the LLaVA-1.5 mlp2x_gelu projector is built (multimodal_projector/builder.py:172-179)")
-        self.mm_projector = nn.Sequential(nn.Linear(cfg.mm_hidden_size, cfg.hidden_size), nn.GELU(), nn.Linear(cfg.hidden_size, cfg.hidden_size))
-        self.answer_indice = None  # dynamic_modeling_llama.py:1644 -- state of the no-KV-cache decode mode (never reset by the reference)
-
-    def get_vision_tower(self):
-        return getattr(self, "vision_tower", None)
-
-
-# ------------------------------------------------------------------------------------------------
-# decode-step state (persistent device buffers: stable pointers for the hipGraph)
-# ------------------------------------------------------------------------------------------------
-class _DecodeState:
-    def __init__(self, model, B, device, dtype, out_cap):
-        cfg = model.config
-        H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
-        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        self.B = B
-        self.cur_ids = torch.zeros(B, dtype=torch.int64, device=device)
-        self.out_ids = torch.zeros((B, max(out_cap, 1)), dtype=torch.int64, device=device)
-        self.step = torch.zeros(B, dtype=torch.int32, device=device)
-        self.finished = torch.zeros(B, dtype=torch.int32, device=device)
-        self.decision = torch.ones(B, dtype=torch.int32, device=device)
-        self.tp_logits = torch.zeros((B, 2), dtype=torch.float32, device=device)
-        self.tp_ws = ops.text_predictor_workspace(B, cfg.sparse_config["d_model"], device)
-        self.tp_x = torch.empty((B, H), dtype=dtype, device=device)  # snapshot of the hidden state entering layer `sparse_layer`
-        self.tp_stream = torch.cuda.Stream(device=device)  # the predictor runs beside layers >= sparse_layer (graph fork/join)
-        self.cu = torch.arange(0, B + 1, dtype=torch.int32, device=device)
-        self.h = torch.empty((B, H), dtype=dtype, device=device)
-        self.h2 = torch.empty((B, H), dtype=dtype, device=device)  # residual ping-pong partner (dl_gemv ADDNORM)
-        self.x = torch.empty((B, H), dtype=dtype, device=device)
-        self.qkv = torch.empty((B, (nH + 2 * nKV) * d), dtype=dtype, device=device)
-        self.o = torch.empty((B, H), dtype=dtype, device=device)
-        self.gu = torch.empty((B, I), dtype=dtype, device=device)  # act = silu(gate)*up, produced by the gate|up GEMV epilogue
-        self.dn = torch.empty((B, H), dtype=dtype, device=device)
-        # weight-streaming GEMV path for small decode batches (else torch/hipBLASLt GEMMs)
-        self.use_gemv = B <= min(model.gemv_max_decode_batch, ops.gemv_max_batch(I, dtype), ops.gemv_max_batch(H, dtype))
-        self.attn = torch.empty((B, nH * d), dtype=dtype, device=device)
-        self.act = torch.empty((B, I), dtype=dtype, device=device)
-        self.logits = torch.empty((B, V), dtype=dtype, device=device)
-        # split-KV: enough workgroups to cover the chip (256 CUs) without drowning in partials
-        self.n_splits = max(1, min(32, 1024 // max(1, B * nH)))
-        self.attn_ws = ops.attn_decode_workspace(B, nH, d, 32, device)
-        # decode batches past the GEMV range: dl_gemm_smallm (weights streamed into the matrix cores) up to smallm_max_decode_batch rows
-        self.use_smallm = (not self.use_gemv) and B <= model.smallm_max_decode_batch and all(
-            ops.gemm_smallm_ok(B, n, k, dtype) for n, k in (((nH + 2 * nKV) * d, H), (H, nH * d), (2 * I, H), (H, I), (V, H))
-        )
-        self.lin_ws = torch.empty(8 * B * max(2 * I, V), dtype=torch.float32, device=device) if self.use_smallm else None
-        # round 5: decode batches of packed_decode_mlp_min_batch..32 rows (configs[2] / [3]: 32) run their MLP on dl_linear_packed -- gate|up with the SiLU * up
-        # epilogue writing `act` in fragment order, down_proj leaving 4 k ranges of fp32 partial sums for the residual-add / RMSNorm launch
-        # (tools/bench_linear_packed.py, M = 32: 38.4 vs 44.8 us and 25.5 vs 31.7 us against the library) -- whatever q|k|v and o_proj run on
-        l0 = model.model.layers[0]
-        self.use_lp_mlp = (not self.use_gemv and model.packed_decode_mlp_min_batch <= B <= 32 and model.packed_decode_mlp and getattr(l0, "wp_gu", None) is not None
-                           and getattr(l0, "wp_down", None) is not None)
-        if self.use_lp_mlp:
-            n_el = lambda cols: int(ops.lib().dl_packed_x_bytes(B, cols)) // 2
-            self.x_pk = torch.empty(n_el(H), dtype=dtype, device=device)
-            self.act_pk = torch.empty(n_el(I), dtype=dtype, device=device)
-            self.lp_parts = torch.empty(4 * B * H, dtype=torch.float32, device=device)
-        self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
-        # dl_gemv_gu_tp's granules (batch 1; the predictor's stage 1 stages the row in LDS: H <= 5120)
-        tpm = getattr(model.model, "output_text_score_predictor", None)
-        self.tp_gran = ops.gemv_gu_tp_workspace(tpm.d_model, device) if (B == 1 and tpm is not None and dtype in (torch.bfloat16, torch.float16) and H <= 5120 and H % 8 == 0 and tpm.d_model % 32 == 0) else None
-        # dl_gemv_qkv_attn's granules (batch 1, 16-bit dtypes at the decoder widths the kernel takes)
-        self.qa_gran = ops.gemv_qkv_attn_workspace(nH, nKV, d, device) if (B == 1 and dtype in (torch.bfloat16, torch.float16) and d in (64, 128) and H * 2 <= 48 * 1024) else None
-        self.blk_err = torch.zeros(1, dtype=torch.int32, device=device)
-        # generate(): ring of pinned host words [lens (2 x B) | finished (B)] + events -- the decode loop observes the evicted lengths and the
-        # EOS flags with non-blocking copies and reads them one chunk of steps late (the launch queue never drains)
-        self.obs_host = torch.empty((4, 3 * B), dtype=torch.int32).pin_memory()
-        self.obs_ev = [torch.cuda.Event() for _ in range(4)]
-        self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-
-
-class DynamicLlavaLlamaForCausalLM(nn.Module):
+class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
     """Drop-in for the reference class of the same name (dynamic_llava_llama.py:50-169)."""
 
     def __init__(self, config: DynamicLlavaConfig, with_vision_tower=True):
@@ -657,170 +199,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             self._dstate = None  # table pointers changed -> re-capture
         return self._rope
 
-    # ---- multimodal glue (dynamic_llava_arch.py:169-601) ---------------------------------------
-    def _segments(self, ids_row: List[int], labels_row: Optional[List[int]], n_img_feat: int):
-        """Host-side restatement of ARCH:330-340, 418-489 for one row (exactly one image)."""
-        img_pos = ids_row.index(IMAGE_TOKEN_INDEX)
-        n = len(ids_row)
-        if labels_row is None:
-            ans0 = n
-        else:
-            ans0 = max(i for i, v in enumerate(labels_row) if v == IGNORE_INDEX) + 1
-        ins = ids_row[img_pos + 1 : ans0]
-        starts = [i for i in range(len(ins) - len(USER_IDS) + 1) if ins[i : i + len(USER_IDS)] == USER_IDS]
-        last = starts[-1] if starts else 0
-        s = img_pos
-        i0 = s + n_img_feat
-        a0 = i0 + (ans0 - img_pos - 1)
-        tot = a0 + (n - ans0)
-        return {"system": [0, s], "image": [s, i0], "instruct": [i0, a0], "answer": [a0, tot], "last_instruct": [i0 + last, a0]}
-
-    def _layout(self, input_ids, attention_mask, labels, n_feat):
-        """Host pass over the prompt(s): where the text tokens and the image features land in the PACKED batch.
-        Returns a dict with `sig` (hashable shape signature -- token VALUES do not enter it), per-row lengths, segment
-        dicts, and index lists.  Costs one small device->host copy of input_ids (the reference does several .item()s)."""
-        ids_host = input_ids.detach().to("cpu")
-        B, W = ids_host.shape
-        am = None if attention_mask is None else attention_mask.detach().to("cpu").bool()
-        lab = None if labels is None else labels.detach().to("cpu")
-        lens, indices, text_src, text_dst, img_dst, img_rows, img_src = [], [], [], [], [], [], []
-        base, img_i = 0, 0
-        maxlen = getattr(self.config, "tokenizer_model_max_length", None)  # ARCH:493-506: every row is cut to this many embeddings
-        truncated = False
-        for b in range(B):
-            cols = list(range(W)) if am is None else torch.nonzero(am[b]).flatten().tolist()
-            r = [int(ids_host[b, c]) for c in cols]
-            lr = None if lab is None else [int(lab[b, c]) for c in cols]
-            n_images = r.count(IMAGE_TOKEN_INDEX)
-            if n_feat == 0 or n_images == 0:  # ARCH:315-324: a text-only row consumes (and ignores) one image feature
-                n = len(r) if maxlen is None else min(len(r), maxlen)
-                truncated |= n < len(r)
-                text_src += [b * W + c for c in cols[:n]]
-                text_dst += list(range(base, base + n))
-                lens.append(n)
-                indices.append(None)
-                base += n
-                img_i += 1
-                continue
-            if n_images != 1:
-                raise NotImplementedError("exactly one <image> per row (ARCH:330-332 calls .item() on the position)")
-            seg = self._segments(r, lr, n_feat)
-            p = seg["system"][1]
-            # row-local destinations, then the cut at tokenizer_model_max_length, then the packed offsets
-            t_src = [b * W + c for j, c in enumerate(cols) if j != p]
-            t_dst = list(range(0, p)) + list(range(p + n_feat, len(r) - 1 + n_feat))
-            i_dst = list(range(p, p + n_feat))
-            n = len(r) - 1 + n_feat
-            if maxlen is not None and n > maxlen:
-                truncated = True
-                n = maxlen
-                keep_t = [k for k, dd_ in enumerate(t_dst) if dd_ < n]
-                t_src, t_dst = [t_src[k] for k in keep_t], [t_dst[k] for k in keep_t]
-                i_dst = [dd_ for dd_ in i_dst if dd_ < n]
-                for key in seg:  # ARCH:502-506
-                    seg[key] = [min(seg[key][0], n), min(seg[key][1], n)]
-            text_src += t_src
-            text_dst += [base + dd_ for dd_ in t_dst]
-            img_dst += [base + dd_ for dd_ in i_dst]
-            img_src += [img_i * n_feat + (dd_ - p) for dd_ in i_dst]
-            img_rows.append(img_i)
-            img_i += 1
-            lens.append(n)
-            indices.append(seg)
-            base += n
-        if all(i is None for i in indices):
-            indices = None
-        sig = (B, W, tuple(lens), tuple(None if (indices is None or i is None) else i["image"][0] for i in (indices or [None] * B)), n_feat, tuple(text_src))
-        return dict(sig=sig, B=B, lens=lens, indices=indices, text_src=text_src, text_dst=text_dst, img_dst=img_dst, img_rows=img_rows, total=base, n_feat=n_feat,
-                    img_src=img_src if truncated else None)
-
-    def _assemble(self, lay, dev_idx, input_ids, image_features):
-        """Device-only: packed embeds [total,H] from token ids + projector output (index_copy, no host sync)."""
-        H = self.config.hidden_size
-        # zeros, not empty: with a width bucket `total` exceeds the rows the layout writes, and the rows past the last sequence travel through every
-        # row-wise launch of the prefill (ADVICE r4: they must hold finite values whatever the allocator handed out)
-        embeds = torch.zeros((lay["total"], H), dtype=self.dtype, device=self.device)
-        ids = input_ids.reshape(-1).index_select(0, dev_idx["text_src"])
-        if lay["sig"][0] == "dev":
-            # device layout (speculative: every row is ASSUMED to hold one image token).  A row with several leaves IMAGE_TOKEN_INDEX (-200)
-            # among the gathered ids; that run is discarded and repeated on the host layout (the kernel raises its error flag), but the
-            # gather itself must stay inside the embedding table
-            ids = ids.clamp_min(0)
-        embeds.index_copy_(0, dev_idx["text_dst"], self.model.embed_tokens(ids))
-        if lay["img_dst"] and lay.get("img_src") is not None:  # rows cut inside their image span: only some features are placed
-            f = image_features.to(self.dtype).reshape(-1, H).index_select(0, dev_idx["img_src"])
-            embeds.index_copy_(0, dev_idx["img_dst"], f)
-        elif lay["img_dst"]:
-            f = image_features.to(self.dtype)
-            if len(lay["img_rows"]) != f.shape[0] or lay["img_rows"] != list(range(f.shape[0])):
-                f = f.index_select(0, dev_idx["img_rows"])
-            embeds.index_copy_(0, dev_idx["img_dst"], f.reshape(-1, H))
-        return embeds
-
-    def _dev_idx(self, lay):
-        dev = self.device
-        t = lambda x: torch.tensor(x, dtype=torch.long, device=dev)
-        d = {"text_src": t(lay["text_src"]), "text_dst": t(lay["text_dst"]), "img_dst": t(lay["img_dst"]), "img_rows": t(lay["img_rows"])}
-        if lay.get("img_src") is not None:
-            d["img_src"] = t(lay["img_src"])
-        return d
-
-    def _n_feat(self, images, image_features):
-        if image_features is not None:
-            return image_features.shape[1]
-        if images is None:
-            return 0
-        if type(images) is list or images.ndim == 5:
-            raise NotImplementedError("anyres / multi-image lists are not on the LLaVA-1.5 Dynamic-LLaVA path")
-        return self.get_vision_tower().num_patches
-
-    def _prepare_packed(self, input_ids, attention_mask, labels, images, image_features=None):
-        """-> (packed embeds [total,H], lens [B], indices list[dict] or None)."""
-        lay = self._layout(input_ids.to(self.device), attention_mask, labels, self._n_feat(images, image_features))
-        if image_features is None and images is not None:
-            image_features = self.encode_images(images)
-        embeds = self._assemble(lay, self._dev_idx(lay), input_ids.to(self.device), image_features)
-        return embeds, lay["lens"], lay["indices"]
-
-    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes=None):
-        """Reference-format wrapper (dynamic_llava_arch.py:169-178, 594-601): right-padded [B,N,H] embeds."""
-        if self.get_vision_tower() is None or images is None or input_ids.shape[1] == 1:
-            return (input_ids, position_ids, attention_mask, past_key_values, None, labels), (None,)
-        if labels is not None:
-            raise NotImplementedError("labels / loss are training-side (DML:2713-2800), out of scope")
-        embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, labels, images)
-        B, N = len(lens), max(lens)
-        left = getattr(self.config, "tokenizer_padding_side", "right") == "left"  # ARCH:529-555: rows right-aligned, indices shifted by the pad
-        out = embeds.new_zeros((B, N, embeds.shape[-1]))
-        o = 0
-        for b, n in enumerate(lens):
-            if left:
-                out[b, N - n :] = embeds[o : o + n]
-                if indices is not None and indices[b] is not None:
-                    for key in indices[b]:
-                        indices[b][key] = [indices[b][key][0] + N - n, indices[b][key][1] + N - n]
-            else:
-                out[b, :n] = embeds[o : o + n]
-            o += n
-        new_mask = None
-        if attention_mask is not None:
-            new_mask = torch.zeros((B, N), dtype=attention_mask.dtype, device=attention_mask.device)
-            for b, n in enumerate(lens):
-                if left:
-                    new_mask[b, N - n :] = 1
-                else:
-                    new_mask[b, :n] = 1
-        new_pos = None
-        if position_ids is not None:
-            new_pos = torch.zeros((B, N), dtype=position_ids.dtype, device=position_ids.device)
-            for b, n in enumerate(lens):
-                ar = torch.arange(n, dtype=position_ids.dtype, device=position_ids.device)
-                if left:
-                    new_pos[b, N - n :] = ar
-                else:
-                    new_pos[b, :n] = ar
-        return (None, new_pos, new_mask, past_key_values, out, None), (indices,)
-
     # ---- decoder engine -----------------------------------------------------------------------
     def _check_ready(self):
         if not self._packed:
@@ -832,12 +210,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         if self._weights_fingerprint() != self._fp:
             self._packed = False
             self.finalize()
-
-    def _prefill_knob_key(self):
-        """The knobs that decide which launches a captured prefill contains."""
-        vt = self.get_vision_tower()
-        return (self.packed_prefill_gemm, self.packed_down_proj, self.packed_qkv_parts, self.splitk_o_proj, self.prefill_width_bucket, self.device_prompt_layout,
-                None if vt is None else (vt.tiles_gemm, vt.tiles_max_batch, vt.tiles_ksplit_out, vt.tiles_ksplit_fc2))
 
     def _weights_fingerprint(self):
         return tuple(v for p in self._fp_params for v in (p.data_ptr(), p._version))
@@ -864,248 +236,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
         return {"decoder_operand_order": dec, "clip_operand_order": clip_tiles, "clip_fused_qkv": clip_fused, "projector_operand_order": proj,
                 "total": dec + clip_tiles + clip_fused + proj}
 
-    def _instruct_on(self, indices, B):
-        sc = self.config.sparse_config
-        return bool(sc["use_text_predictor"] and sc["use_instruct_predictor"]) and indices is not None and len(indices) == B and all(i is not None for i in indices)
-
-    def _plan_prefill(self, lens, indices):
-        """Everything about a prefill that the host knows up front (all shapes: k is the same for every row), plus the
-        device-side metadata tensors.  Built OUTSIDE hipGraph capture; `_prefill_run` is then pure device work."""
-        cfg, sc = self.config, self.config.sparse_config
-        dev = self.device
-        B = len(lens)
-        vision_on = bool(sc["use_vision_predictor"]) and indices is not None and all(i is not None for i in indices) and len(indices) == B
-        vision_on = vision_on and sc["sparse_layer"] < cfg.num_hidden_layers  # the layer loop never reaches the sparsification point otherwise (DML:1826)
-        n_img = k = 0
-        if vision_on:
-            n_img = indices[0]["image"][1] - indices[0]["image"][0]
-            if any(i["image"][1] - i["image"][0] != n_img for i in indices):
-                raise NotImplementedError("all images must have the same token count (DML:1774-1778 assumes it too)")
-            k = int(n_img * sc["vision_keep_rate"])  # DML:1899-1901
-        i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=dev)
-        cu_list = [0]
-        for n in lens:
-            cu_list.append(cu_list[-1] + n)
-        p = dict(B=B, lens=list(lens), vision_on=vision_on, n_img=n_img, k=k, cu_list=cu_list, cu=i32(cu_list), zeros=i32([0] * B), max_len=max(lens))
-        p["instruct_on"] = self._instruct_on(indices, B) and sc["sparse_layer"] < cfg.num_hidden_layers
-        if p["instruct_on"]:
-            # DML:2269 -- the reference asserts B == 1 on this branch
-            assert B == 1, "Using text predictor must keep the batch size to 1"
-            drop_v = (n_img - k) if vision_on else 0
-            p["li"] = (indices[0]["last_instruct"][0] - drop_v, indices[0]["last_instruct"][1] - drop_v)
-        p["instruct_drop"] = 0
-        p["instruct_dev"] = None  # device-side {kept rows, last row} of the instruct compaction (generate(): no host copy)
-        p["nocache"] = False
-        p["nocache_lens"] = None
-        lens2 = list(lens)
-        if vision_on:
-            lens2 = [n - (n_img - k) for n in lens]
-            cu2 = [0]
-            for n in lens2:
-                cu2.append(cu2[-1] + n)
-            p.update(cu2_list=cu2, cu2=i32(cu2), img_start=i32([ix["image"][0] for ix in indices]), max_len2=max(lens2))
-        else:
-            p.update(cu2_list=cu_list, cu2=p["cu"], max_len2=p["max_len"])
-        SL, L = sc["sparse_layer"], cfg.num_hidden_layers
-        # rows the launches are SIZED for (>= the packed rows that exist).  Equally long rows are sized for their width bucket whatever path
-        # built the plan (device layout in generate(), host layout, forward()): the library GEMMs pick their kernel by row count, so the
-        # same request computes the same bits on every path; the rows past cu[B] hold zeros / padding that nobody consumes.
-        p["total"], p["total2"] = cu_list[-1], p["cu2_list"][-1]
-        if vision_on and not p["instruct_on"] and len(set(lens)) == 1:
-            W_ = lens[0] - n_img + 1
-            pad = (self._width_bucket(W_, n_img) - W_) * B
-            p["total"], p["total2"] = p["total"] + pad, p["total2"] + pad
-        p["lens2"] = lens2
-        p["lens_dev"] = i32([list(lens), lens2 if (SL < L) else list(lens)])
-        p["last_rows"] = torch.tensor([c - 1 for c in p["cu2_list"][1:]], dtype=torch.long, device=dev)
-        return p
-
-    def _prefill_run(self, p, embeds, cache: KVSlabCache, indices, last_only: bool):
-        """Packed prefill, device work only.  Returns the normed hidden state (all rows, or the last row of each sequence)."""
-        cfg, sc = self.config, self.config.sparse_config
-        dev, dt = self.device, self.dtype
-        B = p["B"]
-        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        eps = cfg.rms_norm_eps
-        L, SL = cfg.num_hidden_layers, sc["sparse_layer"]
-        vision_on, n_img, k = p["vision_on"], p["n_img"], p["k"]
-        cos, sin = self._rope
-        cu, cu_list, max_len, total = p["cu"], p["cu_list"], p["max_len"], (p["cu_list"][-1] if p["nocache"] else p["total"])
-        zeros_b = p["zeros"]
-        pos = None  # layers < SL: position = in-row index
-        h = embeds.to(dt).contiguous()
-        if h.shape[0] < total:  # sized for the width bucket (see _plan_prefill): the extra rows are zeros behind the last sequence
-            h = torch.cat([h, h.new_zeros((total - h.shape[0], h.shape[1]))], dim=0)
-        elif h.data_ptr() == embeds.data_ptr():
-            h = h.clone()  # the residual stream is updated in place; never touch the caller's tensor
-        rec = self.debug_records
-        # dl_linear_packed for q|k|v and gate|up of the layers whose packed row count fits its one tile (<= 256 rows: the post-compaction layers of a
-        # B = 1 request).  `x_pk`: x is in fragment order (written that way by the norm launch that produced it).
-        lp_ok = lambda rows_, layer_: (self.packed_prefill_gemm and layer_.wp_qkv is not None and 0 < rows_ <= ops.LP_MAX_ROWS and dt in (torch.bfloat16, torch.float16))
-        x_pk = lp_ok(total, self.model.layers[0]) and not (SL == 0 and (vision_on or p["instruct_on"] or p["nocache"]))
-        x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps, packed=x_pk)
-        attn_buf = None
-        qkv_buf = None
-        for i, layer in enumerate(self.model.layers):
-            if i == SL and vision_on:
-                # ---- F1..F5: predictor -> top-k -> compaction (DML:1826-1994) on the un-normed residual stream ----
-                vp = self.model.image_score_predictor
-                if len(vp._forward_hooks) or len(vp._forward_pre_hooks):  # keep the reference's hook point alive
-                    dense = torch.stack([h[cu_list[b] + indices[b]["image"][0] : cu_list[b] + indices[b]["image"][1]] for b in range(B)])
-                    logits = vp(dense, torch.ones(B, n_img, 1, dtype=dt, device=dev))
-                    score = vp.last_score
-                else:
-                    logits, score = vp.score_packed(h, cu, p["img_start"], n_img)
-                keep = ops.topk_select(score, k)
-                # compaction + this layer's input RMSNorm in one launch (unless a text-predictor compaction still follows at this layer)
-                fuse_norm = not p["instruct_on"] and not p["nocache"]
-                total2 = p["cu2_list"][-1] if p["nocache"] else p["total2"]
-                if fuse_norm:
-                    h, pos, x_fused = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, total2, layer.input_layernorm.weight, eps)
-                else:
-                    h, pos = ops.compact_tokens(h, keep, cu, p["cu2"], p["img_start"], n_img, k, total2)
-                if rec is not None:
-                    rec.update(vision_logit=logits, vision_score=score, keep_index=keep, position_ids=pos[: p["cu2_list"][-1]], cu_after=p["cu2"])
-                cu, cu_list, max_len, total = p["cu2"], p["cu2_list"], p["max_len2"], total2
-            if i == SL and p["instruct_on"]:
-                # ---- SURVEY 8f N2 / DML:2261-2375: prefill, first instruct -- the instruct predictor drops tokens of the last
-                # instruct span (its final token always stays).  The kept count is data dependent: one device->host copy, as in
-                # the reference (torch.where).  B == 1 only, like the reference.
-                li0, li1 = p["li"]
-                n_span = li1 - 1 - li0
-                if n_span > 0:
-                    tp = self.model.instruct_score_predictor
-                    dec = torch.empty(n_span, dtype=torch.int32, device=dev)
-                    lg = torch.empty((n_span, 2), dtype=torch.float32, device=dev)
-                    tp.decide(h[li0 : li1 - 1], ops.text_predictor_workspace(n_span, tp.d_model, dev), lg, dec)
-                    if p.get("device_instruct"):
-                        # generate(): the kept count stays on the device.  Every following launch is sized for the UPPER bound (no row
-                        # dropped) and reads the true length from device memory (cu); the rows past it are zeros that nobody consumes.
-                        # Host-visible bookkeeping (the reference shifts its index dicts by the drop count, DML:2365-2375) is internal here.
-                        h, pos, cu, counts = ops.compact_rows_by_mask(h, pos, dec, li0, n_span)
-                        p["instruct_dev"] = counts
-                        continue_host = False
-                    else:
-                        continue_host = True
-                if n_span > 0 and continue_host:
-                    keep_rel = torch.nonzero(dec).flatten()
-                    idx = torch.cat([torch.arange(0, li0, device=dev), keep_rel + li0, torch.arange(li1 - 1, total, device=dev)])
-                    if pos is None:
-                        pos = torch.arange(total, dtype=torch.int32, device=dev)
-                    h = h.index_select(0, idx)
-                    pos = pos.index_select(0, idx)
-                    total = int(idx.numel())
-                    p["instruct_drop"] = n_span - int(keep_rel.numel())
-                    cu_list, max_len = [0, total], total
-                    cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
-                    if rec is not None:
-                        rec.update(instruct_logit=lg, instruct_keep=keep_rel, position_ids=pos, cu_after=cu)
-            if i == SL and p["nocache"] and not p["instruct_on"] and indices is not None and sc["use_text_predictor"] and sc["use_output_text_predictor"]:
-                # ---- SURVEY 8f N3 / DML:2393-2504: decode WITHOUT KV cache.  The answer tokens [answer_indice, -1) of every row are
-                # compacted by top-k of the RAW keep logit with k = max kept count over the batch (data dependent: one host copy).
-                # First call: answer_indice == row length, so the last token is duplicated -- reproduced on purpose.
-                L_row = cu_list[1] - cu_list[0]
-                if any(cu_list[b + 1] - cu_list[b] != L_row for b in range(B)):
-                    raise NotImplementedError("use_cache=False expects equally long rows (the reference uses row 0's answer_indice for all, DML:2402-2409)")
-                if self.model.answer_indice is None:
-                    self.model.answer_indice = indices[0]["instruct"][1] - ((n_img - k) if vision_on else 0)
-                ai = self.model.answer_indice
-                n_span = max(0, L_row - 1 - ai)
-                num_keep = 0
-                keep = torch.zeros((B, 0), dtype=torch.int64, device=dev)
-                if n_span > 0:
-                    tp = self.model.output_text_score_predictor
-                    rows = (torch.tensor(cu_list[:-1], device=dev)[:, None] + ai + torch.arange(n_span, device=dev)[None, :]).reshape(-1)
-                    dec = torch.empty(B * n_span, dtype=torch.int32, device=dev)
-                    lg = torch.empty((B * n_span, 2), dtype=torch.float32, device=dev)
-                    tp.decide(h.index_select(0, rows), ops.text_predictor_workspace(B * n_span, tp.d_model, dev), lg, dec)
-                    num_keep = int(dec.view(B, n_span).sum(dim=1).max().item())
-                    if num_keep > 0:
-                        keep = ops.topk_select(lg[:, 0].to(dt).view(B, n_span).contiguous(), num_keep)
-                    if rec is not None:
-                        rec.update(nocache_logit=lg.view(B, n_span, 2), nocache_keep=keep)
-                left = torch.arange(min(ai, L_row), device=dev)
-                idx = torch.cat([torch.cat([left, ai + keep[b], torch.tensor([L_row - 1], device=dev)]) + cu_list[b] for b in range(B)])
-                if pos is None:
-                    pos = torch.cat([torch.arange(L_row, dtype=torch.int32, device=dev) for _ in range(B)])
-                h = h.index_select(0, idx)
-                pos = pos.index_select(0, idx)
-                L_new = int(left.numel()) + num_keep + 1
-                cu_list = [b * L_new for b in range(B + 1)]
-                cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
-                max_len, total = L_new, B * L_new
-                p["nocache_lens"] = [L_new] * B
-                if rec is not None:
-                    rec.update(position_ids=pos, cu_after=cu)
-            use_lp = lp_ok(total, layer)
-            if i == SL and vision_on and not p["instruct_on"] and not p["nocache"]:
-                # (the compaction launch normalises the rows it moves; for the packed GEMM they are normalised again into fragment order: one ~5 us
-                # launch at one layer buys that layer's two GEMMs)
-                x, x_pk = (ops.rmsnorm(h, layer.input_layernorm.weight, eps, packed=True), True) if use_lp else (x_fused, False)
-            elif i == SL and (vision_on or p["instruct_on"] or p["nocache"]):
-                x_pk = use_lp
-                x = ops.rmsnorm(h, layer.input_layernorm.weight, eps, packed=x_pk)
-            use_lp = use_lp and x_pk
-            Nq = layer.w_qkv.shape[0]
-            nu_q, ks_q = self._lp_config(Nq // 16, False)
-            if use_lp and self.packed_qkv_parts and ks_q > 1:
-                # the two k ranges of q|k|v leave fp32 partial sums instead of meeting inside the GEMM launch (its hand-over is 8-11 us of a 35 us launch); the
-                # RoPE / KV-append launch adds them -- the same sum, rounded once -- and writes q, k, v for the attention
-                if qkv_buf is None or qkv_buf.shape[0] != total or qkv_buf.shape[1] != Nq:
-                    qkv_buf = torch.zeros((total, Nq), dtype=dt, device=dev)  # (rows past the last sequence are never written, nor read)
-                parts_q = ops.linear_packed(x, layer.wp_qkv, Nq, out=self._qkv_parts_ws(ks_q * ops.LP_MAX_ROWS * Nq), epilogue=ops.LP_PARTS, units_per_workgroup=nu_q, k_split=ks_q,
-                                            x_packed_mk=(total, h.shape[1]))
-                qkv = qkv_buf
-                ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d, parts=parts_q)
-            else:
-                qkv = self._lp_linear(x, total, layer.wp_qkv, Nq, h.shape[1]) if use_lp else F.linear(x, layer.w_qkv)
-                ops.rope_kv_write(qkv, cos, sin, cu, pos, zeros_b, zeros_b, cache.k[i], cache.v[i], nH, nKV, d)
-            if attn_buf is None or attn_buf.shape[0] != total:
-                # one zero-filled buffer per row count, shared by the layers (the attention launch writes the rows of real sequences only: padding rows
-                # of a width bucket stay zero instead of holding whatever the allocator handed out -- ADVICE r4)
-                attn_buf = torch.zeros((total, nH * d), dtype=dt, device=dev)
-            attn = attn_buf
-            ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : (nH + nKV) * d], qkv[:, (nH + nKV) * d :], attn, cu, max_len, nH, nKV, d, True)
-            if self.splitk_o_proj and dt in (torch.bfloat16, torch.float16) and attn.shape[0] <= 192 and attn.shape[1] >= 1024 and attn.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
-                x = ops.add_rmsnorm_parts(h, ops.linear_splitk(attn, layer.self_attn.o_proj.weight, self._splitk_ws(h.shape[1]), 8), layer.post_attention_layernorm.weight, eps, packed=use_lp)
-            else:
-                o = F.linear(attn, layer.self_attn.o_proj.weight)
-                x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps, packed=use_lp)
-            lp_down = use_lp and layer.wp_down is not None and self.packed_down_proj
-            if use_lp:  # gate|up with silu(gate) * up in the epilogue: one launch, no [rows, 2 I] round trip
-                act = self._lp_linear(x, total, layer.wp_gu, layer.w_gu.shape[0], h.shape[1], ops.LP_SILU_PAIR, y_packed=lp_down)
-            else:
-                act = ops.silu_mul(F.linear(x, layer.w_gu))
-            nw_next = self.model.norm.weight if i + 1 == L else (None if i + 1 == SL and (vision_on or p["instruct_on"] or p["nocache"])  # residual add only: layer SL's norm runs after compaction
-                                                               else self.model.layers[i + 1].input_layernorm.weight)
-            pk_next = nw_next is not None and i + 1 < L and lp_ok(total, self.model.layers[i + 1])  # the next layer's q|k|v reads this norm's output
-            if lp_down:
-                # down_proj on the operand-order copy: 4 k ranges per unit set, fp32 partial sums added in range order by the residual-add / RMSNorm launch
-                I_ = layer.w_gu.shape[0] // 2
-                nu_, ks_ = self._lp_config_parts(h.shape[1] // 16, total)
-                parts_ = ops.linear_packed(act, layer.wp_down, h.shape[1], out=self._splitk_ws(h.shape[1])[: ks_ * total * h.shape[1]], epilogue=ops.LP_PARTS, units_per_workgroup=nu_,
-                                           k_split=ks_, x_packed_mk=(total, I_))
-                x_new = ops.add_rmsnorm_parts(h, parts_, nw_next, eps, packed=pk_next)
-            elif dt in (torch.bfloat16, torch.float16) and act.shape[0] <= 192 and act.shape[1] >= 1024 and act.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
-                # down_proj at <= 192 packed rows (the compacted layers at B=1): the library streams [H, I] at 1.8 TB/s there; dl_linear_splitk
-                # cuts K into 8 slices and the residual-add / RMSNorm launch adds them in order (tools/bench_linear_splitk.py: 44 vs 54 us)
-                x_new = ops.add_rmsnorm_parts(h, ops.linear_splitk(act, layer.mlp.down_proj.weight, self._splitk_ws(h.shape[1]), 8), nw_next, eps, packed=pk_next)
-            else:
-                x_new = ops.add_rmsnorm(h, F.linear(act, layer.mlp.down_proj.weight), nw_next, eps, packed=pk_next)
-            x = x if nw_next is None else x_new
-            x_pk = pk_next if nw_next is not None else x_pk
-        cache.lens.copy_(p["lens_dev"])  # layers < SL hold the full prompt, layers >= SL the compacted one
-        if p.get("instruct_dev") is not None:  # device-side instruct compaction (B == 1): kept rows / last row index live on the device
-            cache.lens[1].copy_(p["instruct_dev"][:1])
-            if last_only:
-                x = x.index_select(0, p["instruct_dev"][1:2])
-            return x
-        if p["instruct_drop"]:
-            cache.lens[1] -= p["instruct_drop"]
-        if last_only:
-            x = x.index_select(0, p["last_rows"] - p["instruct_drop"])
-        return x
-
     # DL_USE_HIP_GRAPH=0: debugging switch that wins over any assignment -- e.g. the GPU tests under PYTORCH_NO_CUDA_MEMORY_CACHING=1 (every tensor its own
     # allocation, so that an out-of-bounds read faults instead of landing in a neighbour; stream capture is impossible without the caching allocator)
     _force_eager = os.environ.get("DL_USE_HIP_GRAPH", "1") == "0"
@@ -1117,91 +247,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
     @use_hip_graph.setter
     def use_hip_graph(self, v):
         self._use_hip_graph = bool(v)
-
-    @staticmethod
-    def _lp_config(n_units: int, pairs: bool):
-        """(units per workgroup, k ranges) of a dl_linear_packed launch: one workgroup per CU; two k ranges per unit set where that still leaves at
-        most 8 units per workgroup (q|k|v: every CU then pulls half of X through its L1 beside the weight stream -- the bound of this kernel,
-        DESIGN.md section 4), else one (gate|up at 7B / 13B: 6 / 8 units, no hand-over)."""
-        for ks in (2, 1):
-            for nu in (1, 2, 3, 4, 6, 8):
-                if pairs and nu % 2:
-                    continue
-                if -(-n_units // nu) * ks <= 256:
-                    return nu, ks
-        return 8, 1
-
-    @staticmethod
-    def _lp_config_parts(n_units: int, rows: int = 0):
-        """(units per workgroup, k ranges) of a partial-sum launch (narrow N: o_proj / down_proj): as many k ranges as keep one workgroup per CU with at
-        most 4 units each -- every CU then pulls 1 / k_split of X through its L1 (256 units at 7B: 4 units x 4 ranges).  With more than 128 rows, where X is
-        what the launch waits for, 8 units x 8 ranges when that is exactly one workgroup per CU (7B down_proj at M = 170: 32.6 -> 28.5 us, with the consumer's
-        eight slices 39.5 -> 36.6; a tie at 117 rows, slower at 32)."""
-        if 128 < rows <= 192 and n_units % 8 == 0 and n_units // 8 * 8 == 256:
-            return 8, 8
-        for ks in (4, 2, 1):
-            for nu in (1, 2, 3, 4):
-                if -(-n_units // nu) * ks <= 256:
-                    return nu, ks
-        return 4, 1
-
-    def _lp_linear(self, x_pk, rows, wp, N, K, epilogue=ops.LP_STORE, y_packed=False):
-        """x [rows, K] in fragment order @ W^T on the operand-order copy wp."""
-        nu, ks = self._lp_config(N // 16, epilogue == ops.LP_SILU_PAIR)
-        return ops.linear_packed(x_pk, wp, N, epilogue=epilogue, units_per_workgroup=nu, k_split=ks, workspace=self._lp_ws if ks > 1 else None, err=self._lp_err,
-                                 x_packed_mk=(rows, K), y_packed=y_packed)
-
-    def _qkv_parts_ws(self, n):
-        """fp32 partial sums of the q|k|v projection (k ranges x LP_MAX_ROWS x columns: one size per model, so that captured graphs keep a valid pointer)."""
-        ws = getattr(self, "_qkv_parts_buf", None)
-        if ws is None or ws.numel() < n:
-            ws = self._qkv_parts_buf = torch.empty(n, dtype=torch.float32, device=self.device)
-        return ws
-
-    def _splitk_ws(self, H):
-        """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
-        ws = getattr(self, "_splitk_buf", None)
-        if ws is None or ws.numel() < 8 * 192 * H:
-            ws = self._splitk_buf = torch.empty(8 * 192 * H, dtype=torch.float32, device=self.device)
-        return ws
-
-    def _prefill_host_update(self, p, cache, indices):
-        """Host mirrors of what `_prefill_run` did on the device (also the reference's in-place index shift, DML:1986-1994)."""
-        cache.full_len_host = list(p["lens"])
-        cache.seen_tokens = max(p["lens"])
-        cache.sparse_cap = cache.logical_cap - (max(p["lens"]) - max(p["lens2"])) - p["instruct_drop"]  # host-known upper bound of the evicted group's lengths
-        cache.prefill_sparse_max = max(p["lens2"]) - p["instruct_drop"]  # longest row of layers >= sparse_layer after the prefill (upper bound when the instruct compaction stayed on the device)
-        cache.set_bounds(None, None)
-        cache.sched_begin(max(p["lens"]), cache.prefill_sparse_max, self.decode_sync_every)
-        if p["instruct_drop"]:  # DML:2365-2375
-            for ix in indices:
-                ix["instruct"][1] -= p["instruct_drop"]
-                ix["last_instruct"][1] -= p["instruct_drop"]
-                ix["answer"][0] -= p["instruct_drop"]
-                ix["answer"][1] -= p["instruct_drop"]
-        if p["vision_on"]:
-            drop = p["n_img"] - p["k"]
-            for ix in indices:
-                ix["image"][1] -= drop
-                for key in ("instruct", "last_instruct", "answer"):
-                    ix[key][0] -= drop
-                    ix[key][1] -= drop
-
-    def _prefill(self, embeds, lens, indices, cache: Optional[KVSlabCache], reserve: int, last_only: bool):
-        """Eager packed prefill (forward() API and first-time shapes).  Returns (x, cache, lens_after, cu_after)."""
-        cfg, sc = self.config, self.config.sparse_config
-        p = self._plan_prefill(lens, indices)
-        if cache is None:
-            cache = KVSlabCache(cfg.num_hidden_layers, sc["sparse_layer"], p["B"], cfg.num_key_value_heads, cfg.head_dim, max(lens) + reserve, self.dtype, self.device)
-        elif max(cache.full_len_host) != 0:
-            raise NotImplementedError("multi-token forward on a non-empty cache (new-instruct round, DML:2506-2521) is SURVEY 8f row N2")
-        self._rope_tables(max(lens) + reserve)
-        x = self._prefill_run(p, embeds, cache, indices, last_only)
-        self._prefill_host_update(p, cache, indices)
-        if p["instruct_drop"]:
-            n = p["lens2"][0] - p["instruct_drop"]
-            return x, cache, [n], [0, n]
-        return x, cache, p["lens2"], p["cu2_list"]
 
     # ---- one decode step; every buffer persistent, no host sync -> hipGraph-capturable ----
     def knobs(self) -> dict:
@@ -1220,274 +265,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,
             "test_hook_min_keys_per_split": getattr(self, "min_keys_per_split", None),
         }
-
-    def check_device_errors(self):
-        """Raises if a launch with in-kernel hand-offs (dl_gemv_qkv_attn, dl_gemv_gu_tp) gave up on a wait since the last check (such a launch
-        poisons its output instead of hanging).  Costs one device->host copy: call it where a sync is acceptable."""
-        if self._lp_err is not None and self._lp_ws is not None:
-            code = int(self._lp_err.item())
-            if code != 0:
-                self._lp_err.zero_()
-                self._lp_ws.zero_()
-                raise ops.HipOpsError("in-kernel hand-off aborted: dl_linear_packed (a k range's partial tiles never arrived)")
-        st = self._dstate
-        if st is not None:
-            code = int(st.blk_err.item())
-            if code != 0:
-                st.blk_err.zero_()
-                what = [n for bit, n in ((1, "dl_gemv_qkv_attn (attention never received its projection outputs)"), (2, "dl_gemv_gu_tp (a predictor stage never received its inputs)")) if code & bit]
-                if code & ~3:
-                    what.append(f"unknown error bits {code & ~3:#x}")
-                raise ops.HipOpsError("in-kernel hand-off aborted: " + "; ".join(what))
-
-    def _decode_step_kernels(self, st: _DecodeState, cache: KVSlabCache, advance: bool):
-        if st.use_gemv:
-            self._decode_step_gemv(st, cache)
-        else:
-            self._decode_step_gemm(st, cache)
-        if advance:
-            sc = self.config.sparse_config
-            use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and sc["sparse_layer"] < self.config.num_hidden_layers
-            ops.decode_advance(
-                st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, cache.len_full, cache.len_sparse,
-                st.decision if use_tp else None, min_new_tokens=getattr(self, "_min_new", 0),
-            )
-
-    def _decode_step_gemv(self, st: _DecodeState, cache: KVSlabCache):
-        """Small-batch decode step: 5 weight-streaming launches per layer (dl_gemv with fused residual-add+RMSNorm /
-        SiLU*up prologues) + RoPE/KV append + split-KV attention.  The residual stream ping-pongs between st.h / st.h2."""
-        cfg, sc = self.config, self.config.sparse_config
-        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
-        cos, sin = self._rope
-        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
-        torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
-        h_cur, h_alt, delta = st.h, st.h2, None
-        A = ops.GEMV_ADDNORM
-        for i, layer in enumerate(self.model.layers):
-            lens = cache.len_of_layer(i)
-            ns = cache.n_splits(i, st.B * nH)
-            # q|k|v projection + single-split attention of a batch-1 layer in ONE launch (dl_gemv_qkv_attn: the attention workgroups fetch their
-            # K/V rows while the weights stream and receive the projection as granules).  Same bodies as the two launches below, so the
-            # results are bit-identical to them WHEN the stand-alone attention also runs four waves (KVSlabCache.eight_wave_single_split =
-            # False, as the kernel tests set it); by default the stand-alone single-split launch of a small batch runs eight waves -- another
-            # (equally valid) summation order, so DL_FUSE_QKV_ATTN=0 is an A/B of speed, not of bits (tokens / KV lengths: tested equal)
-            fused_attn = self.fuse_qkv_attn and st.B == 1 and ns == 1 and st.qa_gran is not None
-            if fused_attn:
-                ops.gemv_qkv_attn(layer.w_qkv, st.qkv, h_cur, h_alt, delta, layer.input_layernorm.weight, eps, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i],
-                                  st.attn, st.qa_gran, i & 0xff, nH, nKV, d, err=st.blk_err, grid_cap=self.qkv_attn_grid_cap,
-                                  n_splits=cache.fused_attn_splits(i, self.fused_attn_max_splits))
-                if delta is not None:
-                    h_cur, h_alt = h_alt, h_cur
-            else:
-                ops.gemv(layer.w_qkv, st.qkv, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=layer.input_layernorm.weight, eps=eps)
-                if delta is not None:
-                    h_cur, h_alt = h_alt, h_cur
-            # the predictor as extra workgroups of this layer's gate|up launch (dl_gemv_gu_tp): its input is that launch's h_in
-            fused_tp = i == SL and use_tp and self.fuse_gu_tp and not self.tp_side_stream and st.B == 1 and st.tp_gran is not None
-            if i == SL and use_tp and not fused_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
-                # only the end-of-step length advance consumes the decision: run the predictor on a side stream (a parallel
-                # branch of the captured graph) on a snapshot of the residual stream, off the layer chain's critical path
-                if self.tp_side_stream:
-                    st.tp_x.copy_(h_cur)
-                    st.tp_stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(st.tp_stream):
-                        self.model.output_text_score_predictor.decide(st.tp_x, st.tp_ws, st.tp_logits, st.decision)
-                else:
-                    self.model.output_text_score_predictor.decide(h_cur, st.tp_ws, st.tp_logits, st.decision)
-            # F8+F10+F9: RoPE, KV append at slot len[b] and ragged attention in one launch (1024-thread workgroups; split-KV
-            # only when the row is long enough to need more than one workgroup per head)
-            if not fused_attn:
-                ops.attn_decode_rope(st.qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
-                                     call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
-            ops.gemv(layer.self_attn.o_proj.weight, st.o, x=st.attn)
-            if fused_tp:
-                tp = self.model.output_text_score_predictor
-                ops.gemv_gu_tp(layer.w_gu, st.gu, h_cur, h_alt, st.o, layer.post_attention_layernorm.weight, eps, tp._weights(), tp.d_model, st.tp_ws, st.tp_logits,
-                               st.decision, cache.len_full, st.tp_gran, i & 0xff, err=st.blk_err)
-            else:
-                ops.gemv(layer.w_gu, st.gu, mode=A | ops.GEMV_OUT_SILU_PAIR, h_in=h_cur, h_out=h_alt, delta=st.o, norm_w=layer.post_attention_layernorm.weight, eps=eps, grid_cap=self.gu_grid_cap)
-            h_cur, h_alt = h_alt, h_cur
-            ops.gemv(layer.mlp.down_proj.weight, st.dn, x=st.gu)
-            delta = st.dn
-        ops.gemv(self.lm_head.weight, st.logits, mode=A, h_in=h_cur, h_out=h_alt, delta=delta, norm_w=self.model.norm.weight, eps=eps)
-        if use_tp and self.tp_side_stream:
-            torch.cuda.current_stream().wait_stream(st.tp_stream)  # join before anything reads st.decision
-
-    def _decode_step_gemm(self, st: _DecodeState, cache: KVSlabCache):
-        """Decode step for batches past the GEMV range (round 5, `profiles/r05_decode_batch_paths.txt`).  Up to smallm_max_decode_batch (32) rows:
-        o_proj -- and q|k|v below packed_decode_qkv_min_batch (16) rows -- on dl_gemm_smallm (row-major weights streamed into the matrix cores, fp32
-        split-K partials added by the residual-add / RMSNorm launch); from packed_decode_mlp_min_batch (4) rows the MLP, from 16 rows q|k|v too, on
-        dl_linear_packed (operand-order weight copies; SiLU * up in the epilogue, down_proj as 4 k ranges of partial sums; the norm launches write the
-        GEMMs' input in fragment order): 7 launches per layer.  Larger batches, or a model without operand copies: library GEMMs."""
-        cfg, sc = self.config, self.config.sparse_config
-        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
-        cos, sin = self._rope
-        use_tp = bool(sc["use_text_predictor"] and sc["use_output_text_predictor"]) and SL < L
-        sm, ws = st.use_smallm, st.lin_ws
-        torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
-        lp_qkv = st.use_lp_mlp and st.B >= self.packed_decode_qkv_min_batch and getattr(self.model.layers[0], "wp_qkv", None) is not None
-        if lp_qkv:
-            nu_q, ks_q = self._lp_config(st.qkv.shape[1] // 16, False)
-        ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x_pk if lp_qkv else st.x, packed=lp_qkv)
-        for i, layer in enumerate(self.model.layers):
-            if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
-                self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
-            lens = cache.len_of_layer(i)
-            if lp_qkv:
-                qkv = ops.linear_packed(st.x_pk, layer.wp_qkv, st.qkv.shape[1], out=st.qkv, units_per_workgroup=nu_q, k_split=ks_q, workspace=self._lp_ws if ks_q > 1 else None, err=self._lp_err,
-                                        x_packed_mk=(st.B, st.h.shape[1]))
-            else:
-                qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws, n_slices=self.smallm_wide_slices) if sm else F.linear(st.x, layer.w_qkv)
-            ns = cache.n_splits(i, st.B * nH)
-            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
-                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
-            nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
-            lp = st.use_lp_mlp
-            x_mlp = st.x_pk if lp else st.x  # the packed MLP reads its input in fragment order: the norm launch writes it that way
-            if sm:  # (o_proj on dl_linear_packed's partial sums instead: a tie at 8..32 rows, measured and dropped)
-                parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)
-                ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
-            else:
-                o = F.linear(st.attn, layer.self_attn.o_proj.weight)
-                ops.add_rmsnorm(st.h, o, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
-            if lp:
-                H_, I2 = st.h.shape[1], layer.w_gu.shape[0]
-                nu_g, ks_g = self._lp_config(I2 // 16, True)
-                ops.linear_packed(st.x_pk, layer.wp_gu, I2, out=st.act_pk, epilogue=ops.LP_SILU_PAIR, units_per_workgroup=nu_g, k_split=ks_g, workspace=self._lp_ws if ks_g > 1 else None,
-                                  err=self._lp_err, x_packed_mk=(st.B, H_), y_packed=True)
-                nu_d, ks_d = self._lp_config_parts(H_ // 16)
-                parts = ops.linear_packed(st.act_pk, layer.wp_down, H_, out=st.lp_parts, epilogue=ops.LP_PARTS, units_per_workgroup=nu_d, k_split=ks_d, x_packed_mk=(st.B, I2 // 2))
-                nxt_pk = lp_qkv and i + 1 < L  # the final norm feeds lm_head: row-major
-                ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x_pk if nxt_pk else st.x, packed=nxt_pk)
-            elif sm:
-                parts, _ = ops.gemm_smallm_parts(st.x, layer.w_gu, ws, n_slices=self.smallm_wide_slices)
-                ops.silu_mul_parts(parts, st.act)
-                parts, _ = ops.gemm_smallm_parts(st.act, layer.mlp.down_proj.weight, ws)
-                ops.add_rmsnorm_parts(st.h, parts, nw, eps, out=st.x)
-            else:
-                ops.silu_mul(F.linear(st.x, layer.w_gu), out=st.act)
-                dn = F.linear(st.act, layer.mlp.down_proj.weight)
-                ops.add_rmsnorm(st.h, dn, nw, eps, out=st.x)
-        if sm:
-            ops.gemm_smallm(st.x, self.lm_head.weight, out=st.logits, workspace=ws)
-        else:
-            torch.matmul(st.x, self.lm_head.weight.t(), out=st.logits)
-
-    def _pooled_cache(self, B, t_need):
-        """generate() owns its cache, so the slab is reused across calls: stable pointers keep the captured hipGraphs valid."""
-        cfg = self.config
-        c = getattr(self, "_cache_pool", None)
-        if c is None or c.batch != B or c.t_cap < t_need or c.dtype != self.dtype or c.sparse_layer != cfg.sparse_config["sparse_layer"]:
-            # slots are allocated in steps of 128: a stream of requests of slightly different lengths (VQAL:123-196) keeps ONE slab -- and with it
-            # every captured graph that holds pointers into it -- instead of re-allocating whenever a prompt is a few tokens longer than any before
-            old_ptr = None if c is None else c.slab.data_ptr()
-            c = None
-            self._cache_pool = None
-            c = KVSlabCache(cfg.num_hidden_layers, cfg.sparse_config["sparse_layer"], B, cfg.num_key_value_heads, cfg.head_dim, -(-int(t_need) // 128) * 128, self.dtype, self.device)
-            self._cache_pool = c
-            if old_ptr is not None:  # graphs captured on the slab that has just been freed can never be replayed again
-                self._prefill_graphs = {k: v for k, v in self._prefill_graphs.items() if old_ptr not in k}
-                if self._dstate is not None:
-                    self._dstate.graphs = {k: v for k, v in self._dstate.graphs.items() if old_ptr not in k}
-        c.lens.zero_()
-        c.full_len_host = [0] * B
-        c.seen_tokens = 0
-        c.logical_cap = int(t_need)  # a pooled (possibly larger) slab must compute exactly like a fresh one of the requested size
-        c.sparse_cap = c.logical_cap
-        c.set_bounds(None, None)
-        return c
-
-    def _single_split_max_keys(self, st):
-        """-> (largest row, in keys, that the fused q|k|v + attention launch takes; largest row it takes with ONE attention workgroup per head).
-        Stand-alone launches: 256 keys as one workgroup per (row, head) (cache.py).  Inside dl_gemv_qkv_attn the slab part of the attention runs while
-        the q|k|v weights still stream, so the break-even against `dl_gemv` + a split launch moves out with the stream's length, and further with
-        several attention workgroups per head (round 4).  tools/bench_qkv_attn.py on 1x MI355X, one launch with 1 / 4 workgroups per head vs the two
-        launches: 7B (100.7 MB of q|k|v, 17.8 us) 22.8 / 23.4 vs 26.8 at 256 keys, 25.2 / 23.6 vs 28.0 at 448, 27.8 / 25.7 vs 28.5 at 640, 29.1 / 28.2 vs
-        28.3 at 768; 13B (157 MB, 28 us) 32.2 / 33.6 vs 37.5 at 384, 36.0 / 34.1 vs 38.1 at 640, 36.5 / 36.5 vs 39.0 at 768, 39.7 / 42.1 vs 39.9 at 1024."""
-        from .cache import _SINGLE_SPLIT_MAX_KEYS
-        if self.single_split_keys_override is not None:  # tests: force the schedule to change inside a short generation
-            return int(self.single_split_keys_override), int(self.single_split_keys_override)
-        if not (self.fuse_qkv_attn and st.B == 1 and st.use_gemv and st.qa_gran is not None):
-            return _SINGLE_SPLIT_MAX_KEYS, _SINGLE_SPLIT_MAX_KEYS
-        w = self.model.layers[0].w_qkv
-        big = (w.numel() * w.element_size()) >= 130e6  # 13B-class stream
-        if self.fused_attn_max_splits <= 1:
-            return (576 if big else 384), (576 if big else 384)
-        return (768 if big else 704), (576 if big else 256)
-
-    def _width_bucket(self, W: int, n_feat: int) -> int:
-        """Prompt-width bucket of the device-layout prefill: the smallest width >= W whose COMPACTED row count (W - 1 + kept image tokens: the
-        M of 30 of the 32 layers' GEMMs) is a multiple of `prefill_width_bucket` -- 16 by default, one MFMA tile of rows, so a bucket never
-        adds a row tile to those GEMMs that the true width would not have needed.  0 / 1 disables bucketing."""
-        g = int(self.prefill_width_bucket or 0)
-        if g <= 1:
-            return W
-        sc = self.config.sparse_config
-        kept = int(n_feat * sc["vision_keep_rate"]) if (sc["use_vision_predictor"] and sc["sparse_layer"] < self.config.num_hidden_layers) else n_feat
-        rows = W - 1 + kept
-        return W + (-rows) % g
-
-    def _evict_prefill_entries(self):
-        """Bound the prefill-shape cache: at most `max_prefill_graphs` captured graphs and as many seen-once entries (oldest first)."""
-        cap = self.max_prefill_graphs
-        graphs = [k for k, e in self._prefill_graphs.items() if e["graph"] is not None]
-        seen = [k for k, e in self._prefill_graphs.items() if e["graph"] is None]
-        for k in graphs[: max(0, len(graphs) - cap + 1)] + seen[: max(0, len(seen) - cap + 1)]:
-            self._prefill_graphs.pop(k)
-
-    def _get_dstate(self, B, out_cap):
-        st = self._dstate
-        if st is None or st.B != B or st.out_ids.shape[1] < out_cap:
-            st = self._dstate = _DecodeState(self, B, self.device, self.dtype, out_cap)
-            self._prefill_graphs = {}
-        return st
-
-    @staticmethod
-    def _capture(fn, warm):
-        """Warm `fn` up on a side stream (lazy hipBLASLt / allocator state), then capture it into a hipGraph."""
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            warm()
-        torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = fn()
-        return g, out
-
-    def _run_decode_steps(self, st, cache, n_steps):
-        """Enqueue n greedy steps (graph replay when enabled)."""
-        # what the captured launches depend on: the slab (pointers, strides), the split-KV factor of each length group (the only thing
-        # the REQUESTED capacity changes -- keying on logical_cap / sparse_cap themselves would re-capture for every new prompt
-        # length of a variable-length workload such as the VQA loader), tables, stop ids and the switches that pick kernels
-        cfg = self.config
-        nH, SL = cfg.num_attention_heads, cfg.sparse_config["sparse_layer"]
-        splits = (cache.n_splits(0, st.B * nH), cache.n_splits(min(SL, cfg.num_hidden_layers - 1), st.B * nH), cache.n_splits(cfg.num_hidden_layers - 1, st.B * nH))
-        fused_ns = (cache.fused_attn_splits(0, self.fused_attn_max_splits), cache.fused_attn_splits(cfg.num_hidden_layers - 1, self.fused_attn_max_splits)) if (st.B == 1 and st.qa_gran is not None) else (1, 1)
-        key = (cache.slab.data_ptr(), cache.t_cap, splits, fused_ns, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
-               repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split,
-               self.fused_attn_max_splits, self.qkv_attn_grid_cap, self.gu_grid_cap, self.packed_decode_qkv_min_batch)
-        if not self.use_hip_graph:
-            for _ in range(n_steps):
-                self._decode_step_kernels(st, cache, True)
-            return
-        g = st.graphs.get(key)
-        if g is None:
-            # the warm-up executes one real step: snapshot / restore the state it advances
-            snap = (st.cur_ids.clone(), st.out_ids.clone(), st.step.clone(), st.finished.clone(), cache.lens.clone(), st.decision.clone())
-
-            def warm():
-                self._decode_step_kernels(st, cache, True)
-
-            g, _ = self._capture(lambda: self._decode_step_kernels(st, cache, True), warm)
-            st.cur_ids.copy_(snap[0]); st.out_ids.copy_(snap[1]); st.step.copy_(snap[2]); st.finished.copy_(snap[3]); cache.lens.copy_(snap[4]); st.decision.copy_(snap[5])
-            if len(st.graphs) >= 12:  # a long generation walks through a few split factors as its rows grow (one capture each)
-                st.graphs.pop(next(iter(st.graphs)))
-            st.graphs[key] = g
-        for _ in range(n_steps):
-            g.replay()
 
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
@@ -1588,114 +365,6 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
             for b in range(B):
                 logits[b, : lens2[b]] = logits_packed[cu_list[b] : cu_list[b + 1]]
         return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
-
-    def _unpad_embeds(self, inputs_embeds, attention_mask, input_embeds_indices):
-        """Padded [B, N, H] embeddings (what prepare_inputs_labels_for_multimodal returns: right- OR left-padded, ARCH:529-579) ->
-        packed rows + per-row lengths + row-relative segment dicts."""
-        B, N = inputs_embeds.shape[:2]
-        if attention_mask is None:
-            return inputs_embeds.reshape(B * N, -1).to(self.dtype).contiguous(), [N] * B, input_embeds_indices
-        am = attention_mask.bool()
-        lens = am.sum(dim=1).tolist()
-        first = am.int().argmax(dim=1).tolist()  # first valid column of every row (0 when right-padded)
-        embeds = torch.cat([inputs_embeds[b, first[b] : first[b] + lens[b]] for b in range(B)], dim=0).to(self.dtype).contiguous()
-        indices = input_embeds_indices
-        if indices is not None and any(first):
-            indices = [None if ix is None else {k: [v[0] - first[b], v[1] - first[b]] for k, v in ix.items()} for b, ix in enumerate(indices)]
-        return embeds, lens, indices
-
-    def _forward_nocache(self, input_ids, attention_mask, past_key_values, inputs_embeds, images, image_features, input_embeds_indices):
-        """`model(total_input_ids, images=..., use_cache=False)` -- the whole sequence is re-run every step
-        (llava/dynamic_eval/bench_test/dynamic_llava_long_text_time_with_no_cache.py:336-343); no cache is returned."""
-        if past_key_values is not None:
-            raise NotImplementedError("use_cache=False with past_key_values")
-        cfg, sc = self.config, self.config.sparse_config
-        if inputs_embeds is not None:
-            embeds, lens, indices = self._unpad_embeds(inputs_embeds, attention_mask, input_embeds_indices)
-        else:
-            embeds, lens, indices = self._prepare_packed(input_ids, attention_mask, None, images, image_features)
-        p = self._plan_prefill(lens, indices)
-        p["nocache"] = True
-        need = max(lens) + 2
-        c = getattr(self, "_scratch_cache", None)  # K/V are still written (the kernels are fused), into a scratch slab that is dropped
-        if c is None or c.batch != p["B"] or c.t_cap < need or c.dtype != self.dtype:
-            c = self._scratch_cache = KVSlabCache(cfg.num_hidden_layers, sc["sparse_layer"], p["B"], cfg.num_key_value_heads, cfg.head_dim, need + 64, self.dtype, self.device)
-        self._rope_tables(need)
-        x = self._prefill_run(p, embeds, c, indices, False)
-        lens2 = p["nocache_lens"] or p["lens2"]
-        if len(set(lens2)) != 1:
-            raise NotImplementedError("use_cache=False expects equally long rows")
-        logits = F.linear(x, self.lm_head.weight).float().view(p["B"], lens2[0], -1)
-        return CausalLMOutputWithPast(logits=logits, past_key_values=None)
-
-    def _forward_chunk(self, input_ids, attention_mask, cache: KVSlabCache):
-        """T > 1 new tokens on a non-empty cache -- the multi-round "new instruct" call (DML:2506-2521: the instruct
-        predictor decides which of the chunk's tokens are stored in layers >= sparse_layer, the last one always) or, without the
-        instruct predictor, plain chunked prefill.  Every chunk token attends to the cache and causally to the chunk
-        (CU:256-268 `get_cache`), then only the kept K/V rows stay in the slab (CU:165-241, without the zero padding)."""
-        cfg, sc = self.config, self.config.sparse_config
-        if attention_mask is not None and not bool(attention_mask.bool().all()):
-            raise NotImplementedError("padded chunks on a cache")
-        dev, dt = self.device, self.dtype
-        B, T = input_ids.shape
-        nH, nKV, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        eps, L, SL = cfg.rms_norm_eps, cfg.num_hidden_layers, sc["sparse_layer"]
-        instruct = bool(sc["use_text_predictor"] and sc["use_instruct_predictor"]) and SL < L
-        cache.ensure_capacity(T + 1)
-        cos, sin = self._rope_tables(max(cache.full_len_host) + T + 1)
-        # no device->host copy (the reference syncs per row per layer, CU:197-199): the un-evicted length bounds both length groups
-        bound = max(cache.full_len_host) + T
-        total = B * T
-        cu = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=dev)
-        h = self.model.embed_tokens(input_ids.reshape(-1).to(dev)).clone()
-        x = ops.rmsnorm(h, self.model.layers[0].input_layernorm.weight, eps)
-        keep_idx = None
-        for i, layer in enumerate(self.model.layers):
-            if i == SL and instruct:
-                tp = self.model.instruct_score_predictor
-                dec = torch.empty(total, dtype=torch.int32, device=dev)
-                lg = torch.empty((total, 2), dtype=torch.float32, device=dev)
-                tp.decide(h, ops.text_predictor_workspace(total, tp.d_model, dev), lg, dec)
-                dec = dec.view(B, T)
-                dec[:, -1] = 1  # DML:2521
-                keep_idx = dec.contiguous()  # int32 [B, T] on the device: which chunk rows stay in layers >= SL
-                if self.debug_records is not None:
-                    self.debug_records.update(text_decision=dec.clone(), text_logit=lg.view(B, T, 2).clone())
-            g = cache.group(i)
-            lens = cache.lens[g]
-            qkv = F.linear(x, layer.w_qkv)
-            ops.rope_kv_write(qkv, cos, sin, cu, None, cache.len_full, lens, cache.k[i], cache.v[i], nH, nKV, d)
-            attn = torch.empty((total, nH * d), dtype=dt, device=dev)
-            ops.attn_prefill_cached(qkv[:, : nH * d], cache.k[i], cache.v[i], lens, attn, cu, T, bound, nH, nKV, d)
-            o = F.linear(attn, layer.self_attn.o_proj.weight)
-            x = ops.add_rmsnorm(h, o, layer.post_attention_layernorm.weight, eps)
-            act = ops.silu_mul(F.linear(x, layer.w_gu))
-            dn = F.linear(act, layer.mlp.down_proj.weight)
-            nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
-            x = ops.add_rmsnorm(h, dn, nw, eps)
-        cache.lens[0] += T
-        if keep_idx is not None:
-            # keep only the chosen rows of this chunk, packed in place right after the old ones: ONE launch for all layers >= SL
-            # (every layer's attention has already read its un-packed chunk rows), then the kept counts are added on the device
-            ops.kv_pack_rows(cache.k[SL], cache.v[SL], cache.slab.stride(0), L - SL, keep_idx, cache.lens[1], cache.t_cap)
-            cache.lens[1] += keep_idx.sum(dim=1).to(torch.int32)
-        else:
-            cache.lens[1] += T
-        cache.full_len_host = [n + T for n in cache.full_len_host]
-        cache.seen_tokens += T  # cache.sparse_cap stays a valid (host-known) upper bound of the evicted group's lengths
-        cache.sched_drop()  # the next decode step re-starts the schedule from the lengths it finds
-        logits = F.linear(x, self.lm_head.weight).float().view(B, T, -1)
-        return CausalLMOutputWithPast(logits=logits, past_key_values=cache)
-
-    def _first_token(self, st, x_last, min_new):
-        if st.use_gemv and x_last.dim() == 2 and x_last.is_contiguous():
-            # up to three rows: the weight-streaming GEMV the decode steps use for the same matrix (41 vs 61 us for the library's skinny GEMM at B=1)
-            ops.gemv(self.lm_head.weight, st.logits, x=x_last)
-        else:
-            torch.matmul(x_last, self.lm_head.weight.t(), out=st.logits)
-        self._prefill_logits_buf.copy_(st.logits)
-        # first token: argmax only (the prompt's KV lengths are already in place); EOS is banned while step < min_new (HF semantics)
-        ops.decode_advance(st.logits, st.cur_ids, st.out_ids, st.step, st.finished, self._eos, self._pad, None, None, None, min_new_tokens=min_new)
 
     def _gen_kwargs(self, kwargs, lens):
         """Shared parsing of the HF generate() kwargs this path honours (DLL:117-152 forwards **kwargs to HF): rejects what is not
@@ -2043,7 +712,9 @@ class DynamicLlavaLlamaForCausalLM(nn.Module):
                     st.obs_host[slot, 2 * B :].copy_(st.finished, non_blocking=True)
                 st.obs_ev[slot].record()
                 pending.append((slot, produced))
-        if B == 1:
+        if B == 1 or self._lp_ws is not None:
+            # (batched decode and the packed prefill also contain in-kernel hand-overs -- dl_linear_packed with k ranges, reporting through
+            # _lp_err -- so a reducer timeout must be seen for B > 1 too; generate() is about to synchronise for its result anyway)
             self.check_device_errors()
         if dev_layout and int(ent["didx"]["err"].item()) != 0:
             # a row without exactly one image token (text-only row, several images): what was computed is meaningless -- repeat the

@@ -30,7 +30,7 @@ def timed(fn, reps=40):
     return a.elapsed_time(b) / (5 * reps) * 1e3
 
 
-base = [200 + (i * 701) % 700 for i in range(32)]
+base = [200 + (i * 229) % 700 for i in range(32)]
 srt = sorted(base, reverse=True)
 snake = [0] * 32
 for r in range(8):
