@@ -215,6 +215,67 @@ def linear_packed_roofline(model):
     return out
 
 
+def linear_tiles_roofline(model):
+    """dl_linear_tiles (round 6) on the CLIP tower's four projections at one image (M = 577), walking the 23 encoder layers' operand-order weight copies in one
+    hipGraph (cold weights: 0.58 GB through a 256 MB cache), between events on the launch stream.  These launches are MFMA-shaped but small (1.2-4.8 GFLOP): the
+    entry reports TFLOP/s against the dense bf16 MFMA peak AND the bytes every CU pulls through its vector-memory path (2 KiB per row tile / unit per 64-k step),
+    which is what bounds the k loop (~29 cycles per 1-KiB wave request per CU, whether it is an LDS-DMA piece or a register load)."""
+    from dynamic_llava_amd import hip_ops as ops
+
+    vt = model.get_vision_tower()
+    tiles = [t for t in (getattr(vt, "_tiles", None) or []) if t is not None] if vt is not None else []
+    if not tiles:
+        return []
+    dev, dt = model.device, model.dtype
+    c = model.config.clip
+    C, I = c["hidden_size"], c["intermediate_size"]
+    M = (c["image_size"] // c["patch_size"]) ** 2 + 1
+    x = torch.randn((M, C), device=dev, dtype=dt)
+    xi = torch.randn((M, I), device=dev, dtype=dt) * 0.1
+    xp, xip = ops.pack_x_rows(x), ops.pack_x_rows(xi)
+    bq, b1 = torch.zeros(3 * C, device=dev, dtype=dt), torch.zeros(I, device=dev, dtype=dt)
+    y_q = torch.empty((M, 3 * C), device=dev, dtype=dt)
+    g_pk = torch.empty(ops.tiles_x_numel(M, I), device=dev, dtype=dt)
+    ks_o, ks_2 = vt.tiles_ksplit_out, vt.tiles_ksplit_fc2
+    p_o = torch.empty((ks_o, M, C), device=dev, dtype=torch.float32)
+    p_2 = torch.empty((ks_2, M, C), device=dev, dtype=torch.float32)
+    row_tiles = (M + 15) // 16
+    cases = [
+        ("q|k|v + bias (5 row tiles x 6 units per workgroup)", 3 * C, C, 1, (5, 6), lambda t: ops.linear_tiles(xp, t[0], 3 * C, bias=bq, out=y_q, x_packed_mk=(M, C))),
+        (f"out_proj, fp32 partial sums of {ks_o} k ranges (5 x 4)", C, C, ks_o, (5, 4), lambda t: ops.linear_tiles(x, t[1], C, out=p_o, epilogue=ops.LT_PARTS, k_split=ks_o)),
+        ("fc1 + bias + QuickGELU epilogue, fragment-order output (5 x 8)", I, C, 1, (5, 8), lambda t: ops.linear_tiles(xp, t[2], I, bias=b1, out=g_pk, epilogue=ops.LT_QGELU, x_packed_mk=(M, C), y_packed=True)),
+        (f"fc2, fp32 partial sums of {ks_2} k ranges (5 x 8)", C, I, ks_2, (5, 8), lambda t: ops.linear_tiles(xip, t[3], C, out=p_2, epilogue=ops.LT_PARTS, k_split=ks_2, x_packed_mk=(M, I))),
+    ]
+    out = []
+    for name, N, K, ks, (tm, nu), fn in cases:
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            fn(tiles[0])
+        torch.cuda.current_stream().wait_stream(s_)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for t in tiles:
+                fn(t)
+        g.replay()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(5):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / (5 * len(tiles)) * 1e3
+        flops = 2 * M * N * K
+        n_wg = -(-row_tiles // tm) * -(-(N // 16) // nu) * ks
+        cu_bytes = n_wg * (tm + nu) * 2048 * (K // 64 // ks)  # what the workgroups pull through their CUs' vector-memory paths: X tiles + W units, 2 KiB each per step
+        out.append({"kernel": "dl_linear_tiles " + name, "shape": f"M={M} x [{N}, {K}] bf16, {len(tiles)} layers' weight copies in one graph", "bound": "mfma", "flops": flops, "us": round(us, 3),
+                    "achieved": round(flops / us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 2500.0, 4), "workgroups": n_wg,
+                    "bytes_into_the_CUs": cu_bytes, "cu_fill_GBps_over_the_whole_launch": round(cu_bytes / us / 1e3, 1),
+                    "cu_fill_bytes_per_clk_per_cu": round(cu_bytes / min(n_wg, 256) / (us * 2400.0), 2), "hbm_bytes": N * K * 2 + M * K * 2 + (ks * M * N * 4 if ks > 1 or "partial" in name else M * N * 2)})
+    return out
+
+
 def gemv_roofline(model):
     """dl_gemv on the decode step's four weight shapes, walking all 32 layers' weights (13 GB >> 256 MB Infinity Cache)."""
     from dynamic_llava_amd import hip_ops as ops
@@ -824,7 +885,7 @@ def _main(args, partial):
         decode_attn_roofline(model, "configs[2]-like: B=32 ragged, T spread over [299, 887] (round 6: a real spread -- 200 + 229 i mod 700; up to round 5 the ladder 701 i mod 700 made this entry T = 200..231)", 32, [200 + (i * 229) % 700 for i in range(32)], nH, d),
         decode_attn_roofline(model, "configs[4]-like: 13B heads (40x128), B=1, T=2048", 1, [2048], 40, d),
         decode_attn_roofline(model, "B=32, T=2048", 32, [2048] * 32, nH, d),
-    ] + gemv_shapes + linear_packed_roofline(model) + other_kernel_rooflines(model, n_prompt)
+    ] + gemv_shapes + linear_packed_roofline(model) + linear_tiles_roofline(model) + other_kernel_rooflines(model, n_prompt)
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_probe.py under rocprofv3 --pmc, see profiles/)
         import glob

@@ -143,7 +143,7 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
         if getattr(self, "_proj_src", None) != [(w.data_ptr(), w._version) for w in (pj[0].weight, pj[2].weight)]:
             self._pack_projector()
         B = f.shape[0] if f.dim() == 3 else 1
-        if self._proj_tiles is None or f.dtype != pj[0].weight.dtype or not f.is_cuda or B > (vt.tiles_max_batch if vt is not None else 4) or pj[0].bias is None or pj[2].bias is None:
+        if self._proj_tiles is None or f.dtype != pj[0].weight.dtype or not f.is_cuda or B > (vt.tiles_max_batch if vt is not None else 1) or pj[0].bias is None or pj[2].bias is None:
             return pj(f)
         C = f.shape[-1]
         x = f.reshape(-1, C)  # a view for one image (the CLS row is skipped by the offset), a copy for several

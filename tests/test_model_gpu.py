@@ -692,6 +692,17 @@ def test_clip_tower_packed_path_matches_eager_module(dtype):
     e_ref, e_hip = (eager - truth), (hip - truth)
     assert float(e_hip.abs().max()) <= 2.0 * float(e_ref.abs().max()) + 1e-3, (float(e_hip.abs().max()), float(e_ref.abs().max()))
     assert float(e_hip.pow(2).mean().sqrt()) <= 1.5 * float(e_ref.pow(2).mean().sqrt()) + 1e-4
+    # round 6: one image runs every projection on dl_linear_tiles (operand-order weight copies, QuickGELU in fc1's epilogue, out_proj / fc2 as fp32 k-range
+    # partial sums added by the residual-add + LayerNorm launch); two images (above) stay on the library GEMMs.  Same bounds, against the same fp32 truth.
+    assert t._tiles[0] is not None and t.tiles_max_batch >= 1
+    hip1 = t(x[:1]).float()
+    e_hip1 = hip1 - truth[:1]
+    assert float(e_hip1.abs().max()) <= 2.0 * float(e_ref[:1].abs().max()) + 1e-3, (float(e_hip1.abs().max()), float(e_ref[:1].abs().max()))
+    assert float(e_hip1.pow(2).mean().sqrt()) <= 1.5 * float(e_ref[:1].pow(2).mean().sqrt()) + 1e-4
+    t.tiles_max_batch = 2  # and the tiled path at two images (two rounds of workgroups): rows of the second image equal its own one-image run, bit for bit
+    hip2 = t(x).float()
+    assert torch.equal(hip2[:1], hip1) and torch.equal(hip2[1:], t(x[1:]).float())
+    t.tiles_max_batch = 1
     # unused last layer is really skipped, CLS token dropped
     t.select_feature = "cls_patch"
     assert t(x).shape == (2, 577, 1024)

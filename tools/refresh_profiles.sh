@@ -31,6 +31,14 @@ rocprofv3 --kernel-trace --pmc TA_ADDR_STALLED_BY_TC_CYCLES TCC_BUSY TCC_EA0_RDR
 rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $RAW/lp_l2 -o s -- python tools/pmc_linear_packed_probe.py > /dev/null 2>&1
 python tools/pmc_linear_packed_report.py gpurun_out/lp_probe.log $(find $RAW/lp_sq $RAW/lp_tc $RAW/lp_l2 -name '*.db') > gpurun_out/linear_packed_counters.txt 2>&1
 (hipcc --offload-arch=gfx950 -O3 tools/l2_read_bw.hip -o /tmp/l2bw 2>/dev/null && /tmp/l2bw > gpurun_out/l2_read_ceilings.txt 2>&1) || true
+# round 6: dl_linear_tiles (CLIP tower / projector GEMMs) -- microbench vs hipBLASLt with cold weights, per-wave timelines incl. the two-pass (L2-hit) and
+# 32-workgroup experiments; the prefill's kernel inventory; MFMA-busy of the configs[2] prefill (the MFMA-bound leg)
+python tools/bench_linear_tiles.py > gpurun_out/linear_tiles_bench.txt 2>/dev/null
+python tools/bench_linear_tiles.py --stamps > gpurun_out/linear_tiles_timelines.txt 2>/dev/null
+rocprofv3 --kernel-trace -d $RAW/prof_pf -o pf -- python tools/prefill_kernels.py > /dev/null 2>&1
+python tools/prof_summary.py "$(find $RAW/prof_pf -name '*.db' | head -1)" 60 --after spin_kernel > gpurun_out/prefill_kernel_inventory.txt
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $RAW/pmc_mfma_c2 -o m -- python tools/prefill_kernels_c2.py > /dev/null 2>&1
+python tools/mfma_report.py "$(find $RAW/pmc_mfma_c2 -name '*.db' | head -1)" > gpurun_out/mfma_report_c2.txt
 # then, back in the development container (gpurun merges gpurun_out/):
 #   cp gpurun_out/bench_default.json profiles/${R}_bench_b1.json; cp gpurun_out/kernel_stats.txt profiles/${R}_bench_kernel_stats.txt
 #   grep -v '^JSON' gpurun_out/pmc_report.txt > profiles/${R}_pmc_traffic.txt; grep '^JSON' gpurun_out/pmc_report.txt | sed 's/^JSON //' > profiles/${R}_pmc_traffic.json
@@ -38,4 +46,5 @@ python tools/pmc_linear_packed_report.py gpurun_out/lp_probe.log $(find $RAW/lp_
 #   cp gpurun_out/stream_var.json profiles/${R}_varlen_stream.json; cp gpurun_out/stream_fixed.json profiles/${R}_varlen_stream_fixed_width.json
 #   cp gpurun_out/linear_packed_{bench,timelines,counters}.txt gpurun_out/l2_read_ceilings.txt -> profiles/${R}_*
 #   cp gpurun_out/bench_configs_2_4.json profiles/${R}_bench_configs_2_4.json; cp gpurun_out/bench_dp2_one_gpu.json profiles/${R}_bench_dp2_one_gpu.json
+#   cp gpurun_out/linear_tiles_{bench,timelines}.txt gpurun_out/prefill_kernel_inventory.txt -> profiles/${R}_*; grep -v '^JSON' gpurun_out/mfma_report_c2.txt > profiles/${R}_configs2_prefill_mfma_util.txt
 echo "done: gpurun_out/{bench_default.json,kernel_stats.txt,pmc_report.txt,mfma_report.txt}"
