@@ -543,6 +543,7 @@ __global__ __launch_bounds__(RW * KW * 64) void attn_prefill_keysplit_kernel(con
   for (int rd = 0; rd < n_rounds; ++rd) {
     const bool more = rd + 1 < n_rounds;
     if (more) fetch((rd + 1) * NKEY);
+    if (rd == 1) DL_PSTAMP(8);  // (timing builds) round 1: next round's loads issued AND landed (the stamp drains vmcnt)
     const int key0 = rd * NKEY + kw * kBN;  // this wave's 64 keys of the round
     if (key0 < row_keys) {                  // wave-uniform
       f32x4_t acc_s[NT];
@@ -606,10 +607,14 @@ __global__ __launch_bounds__(RW * KW * 64) void attn_prefill_keysplit_kernel(con
         }
       }
     }
+    if (rd == 1) DL_PSTAMP(9);   // round 1: S, softmax, P, PV done
     __syncthreads();  // the round's K / V^T are dead
+    if (rd == 1) DL_PSTAMP(10);  // barrier
     if (more) {
       stash();
+      if (rd == 1) DL_PSTAMP(11);  // stash (registers -> K | V^T)
       __syncthreads();
+      if (rd == 1) DL_PSTAMP(12);
     }
   }
   DL_PSTAMP(2);  // all rounds

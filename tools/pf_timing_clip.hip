@@ -37,6 +37,9 @@ int main(int argc, char** argv) {
     long long s[16];
     hipMemcpyFromSymbol(s, HIP_SYMBOL(dl::g_pf_stamps), sizeof(s));
     if (it >= 5)
+      printf("   round 1 (since the round's start = stamp 12 of round 0 is not taken; relative to entry): loads landed %.2f | compute done %.2f | barrier %.2f | stash %.2f | barrier %.2f us\n",
+             (s[8] - s[0]) * 0.01, (s[9] - s[0]) * 0.01, (s[10] - s[0]) * 0.01, (s[11] - s[0]) * 0.01, (s[12] - s[0]) * 0.01);
+    if (it >= 5)
       printf("T=%d: event %.2f us | last query tile of head 0, since its entry: first round staged %.2f | all rounds %.2f | partials exchanged %.2f | stores done %.2f us\n", T, ms * 1e3,
              (s[1] - s[0]) * 0.01, (s[2] - s[0]) * 0.01, (s[3] - s[0]) * 0.01, (s[7] - s[0]) * 0.01);
   }
