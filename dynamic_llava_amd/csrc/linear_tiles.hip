@@ -1,26 +1,31 @@
-// dl_linear_tiles: Y[M, N] = X[M, K] Wp^T (+ bias, activation) for the nn.Linear calls of the vision side at M = 577 B rows (B <= 4 images):
+// dl_linear_tiles: Y[M, N] = X[M, K] Wp^T (+ bias, activation) for the nn.Linear calls of the vision side at M = 577 rows (one image):
 // the CLIP ViT-L/14-336 encoder layer's four projections (llava/model/multimodal_encoder/clip_encoder.py:53-71 runs transformers' CLIPEncoderLayer:
-// q|k|v [3072, 1024], out_proj [1024, 1024], fc1 [4096, 1024] + QuickGELU, fc2 [1024, 4096]), the mlp2x_gelu projector
-// (llava/model/multimodal_projector/builder.py:172-179) and the vision predictor's linears (DML:1348-1359, CTL:153-180).
+// q|k|v [3072, 1024], out_proj [1024, 1024], fc1 [4096, 1024] + QuickGELU, fc2 [1024, 4096]) and the mlp2x_gelu projector
+// (llava/model/multimodal_projector/builder.py:172-179).
 //
 // Why not the library and not dl_linear_packed.  These GEMMs are SMALL (1.2-4.8 GFLOP, 2-8 MB of weights that the 23 layers stream once each): the
 // launch is a latency / tiling problem.  hipBLASLt picks 64x160 / 64x64 / 128x64 macro tiles: 260, 160 and 240 workgroups on 256 CUs (fc1: two rounds
 // for four workgroups; fc2 / out_proj: 96 CUs idle) and 12.5-21.9 us per GEMM = 0.10 of the MFMA peak (profiles/r05_prefill_mfma_util.txt).
 // dl_linear_packed keeps ALL rows in one tile (M <= 256) and streams weights past them; at 577 rows the accumulators do not fit.
-// Here the output is cut into (80 rows x 16 NU neurons) tiles chosen so that ONE round covers the chip (fc1: 8 x 32 = 256 workgroups), both operands
-// travel HBM / L2 -> LDS by LDS-DMA in matrix-core fragment order (a 16 x 32 fragment = one contiguous KiB for W -- dl_pack_weight_tiles -- and for X when the
-// producer wrote fragment order; row-major X is fetched as 16 rows x 64 B per piece), and the k range of a long-K GEMM (fc2) is split over workgroups as
-// fp32 partial sums for the residual-add / LayerNorm launch that reads them anyway.
+// Here the output is cut into (80 rows x 16 NU neurons) tiles chosen so that ONE round covers the chip (fc1: 8 x 32 = 256 workgroups), the k range of a
+// long-K GEMM (fc2, out_proj) is split over workgroups as fp32 partial sums for the residual-add / LayerNorm launch that reads them anyway, and bias /
+// activation are the epilogue.
 //
 // One workgroup: 4 LOADER waves + WN CONSUMER waves.
-//   loaders   : per 64-k step 2 (TM + NU) DMA pieces of 1 KiB, dealt round-robin to the four loaders, into a ring of RD steps; they never touch a register
-//               or look at data; loader h waits with a counted vmcnt so that step t + 1 has landed at barrier B(t) and RD - 3 steps stay in flight.
-//   consumer c: all TM row tiles x units [c NUW, (c + 1) NUW) of the workgroup: per 32-k half step TM + NUW ds_read_b128 (lane-linear: conflict-free)
-//               feed TM x NUW v_mfma_f32_16x16x32; the next half's fragments are requested before the current half multiplies.
+//   loaders   : X -- the operand all consumers share -- by LDS-DMA (one 16-row x 32-k fragment = one KiB per wave instruction; fragment-order X: one contiguous
+//               KiB, row-major X: 16 rows x 64 B) into a ring of RD 64-k steps, pieces dealt round-robin to the four loaders; they never touch a register or look
+//               at data; loader h waits with a counted vmcnt so that step t + 1 has landed at barrier B(t).  The ring fills while the first steps multiply.
+//   consumer c: all TM row tiles x units [c NUW, (c + 1) NUW) of the workgroup.  Its weight fragments (operand-order copy: one contiguous KiB each) go STRAIGHT to
+//               registers DW steps ahead -- no other wave multiplies them -- (template WDIR = 0 sends them through the ring too: measurement); per 32-k half step
+//               TM ds_read_b128 (lane-linear: conflict-free) feed TM x NUW v_mfma_f32_16x16x32; the next half's fragments are requested before the current
+//               half multiplies (order pinned with sched_barrier).
 //   one s_barrier per step, as in dl_linear_packed.
 // Workgroup b -> XCD b % 8 (observed placement; speed only): the grid is renumbered so that one XCD's workgroups share a k range and a neuron range, i.e.
 // W is read from HBM once and X lives in the XCD's L2.
-// Result: a fixed function of (tile shape, k_split): one fp32 accumulation per output in k order per range, ranges added in order by the consumer.
+// What bounds the k loop is neither MFMA (340 of 750-1000 cycles per step) nor the path (DMA or registers) but the ~100 outstanding 128-byte requests one CU's
+// L1 keeps at L2 at ~470 cycles each: ~26-30 B/clk per CU (profiles/r06_linear_tiles_{timelines,counters}.txt).
+// Result: a fixed function of the k order: one fp32 accumulation per output in k order per range (every tile shape returns the same bits), ranges added in
+// order by the consumer launch; a row's result does not depend on its position.
 #include <mutex>
 #include <type_traits>
 
