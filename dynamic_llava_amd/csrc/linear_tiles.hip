@@ -167,10 +167,10 @@ __global__ __launch_bounds__(64 * (kLtLoaders + WN)) void linear_tiles_kernel(co
     // ---------------- loader h: pieces h, h + 4, h + 8, ... of every step ----------------
     auto run = [&](auto hc) {
       constexpr int H = decltype(hc)::value;
-      constexpr int PH = (P - H + kLtLoaders - 1) / kLtLoaders;
+      constexpr int PH = (P - H + kLtLoaders - 1) / kLtLoaders;  // (0 for the last loaders of a one-row-tile workgroup: they only keep the barriers)
       static_assert((RD - 3) * PH <= 63, "ring too deep for the 6-bit vmcnt");
-      const DL_GLOBAL char* base[PH];
-      uint32_t voff[PH];
+      const DL_GLOBAL char* base[PH > 0 ? PH : 1];
+      uint32_t voff[PH > 0 ? PH : 1];
       const int n_real = (p.M + 15) >> 4;
       const uint32_t x_step = p.x_packed ? (uint32_t)p.x_tiles * 2048u : 128u;
       lt_static_for<0, PH>([&](auto qc) {
@@ -468,6 +468,22 @@ static int lt_shape(const LtParams& p, const LtShape& s, int epilogue, hipStream
   LT_CASE(5, 4, 1, 1, 3);
   LT_CASE(5, 4, 1, 1, 5);
 #undef LT_CASE
+  // partial-sum form only (round 6, late): the decoder's o_proj [H, H] at <= 256 rows -- the post-compaction prefill layers (M = 117..192: 8..12 row tiles as one or two
+  // row blocks) and decode batches of 16..32 rows (1..2 row tiles) -- as TM row tiles x 8 units x k ranges, the slices added by dl_add_rmsnorm_parts
+#define LT_CASE_PARTS(tm_, dw_)                                                                                      \
+  if (s.tm == tm_ && s.wn == 4 && s.nuw == 2 && s.wdir == 1 && s.dw == dw_ && epilogue == LT_EPI_PARTS)            \
+  return lt_launch<T, tm_, 4, 2, LT_EPI_PARTS, 1, dw_>(p, st)
+  LT_CASE_PARTS(1, 3);
+  LT_CASE_PARTS(1, 5);
+  LT_CASE_PARTS(2, 3);
+  LT_CASE_PARTS(2, 5);
+  LT_CASE_PARTS(3, 3);
+  LT_CASE_PARTS(4, 3);
+  LT_CASE_PARTS(6, 3);
+  LT_CASE_PARTS(7, 3);
+  LT_CASE_PARTS(8, 3);
+  LT_CASE_PARTS(8, 5);
+#undef LT_CASE_PARTS
   set_error("dl_linear_tiles: tile shape %d row tiles x %d waves x %d units (weights %s, %d steps ahead) is not built", s.tm, s.wn, s.nuw, s.wdir ? "direct" : "through LDS", s.dw);
   return DL_ERR_ARG;
 }

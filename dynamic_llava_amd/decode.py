@@ -65,6 +65,7 @@ class _DecodeState:
             self.x_pk = torch.empty(n_el(H), dtype=dtype, device=device)
             self.act_pk = torch.empty(n_el(I), dtype=dtype, device=device)
             self.lp_parts = torch.empty(4 * B * H, dtype=torch.float32, device=device)
+        self.o_parts = torch.empty(8 * B * H, dtype=torch.float32, device=device) if (self.use_smallm and B <= 32 and getattr(l0, "wp_o", None) is not None) else None  # o_proj's k-range slices (dl_linear_tiles)
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
         # dl_gemv_gu_tp's granules (batch 1; the predictor's stage 1 stages the row in LDS: H <= 5120)
         tpm = getattr(model.model, "output_text_score_predictor", None)
@@ -207,7 +208,13 @@ class DecodeScheduler:
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             lp = st.use_lp_mlp
             x_mlp = st.x_pk if lp else st.x  # the packed MLP reads its input in fragment order: the norm launch writes it that way
-            if sm:  # (o_proj on dl_linear_packed's partial sums instead: a tie at 8..32 rows, measured and dropped)
+            if sm and self.tiles_o_proj and st.o_parts is not None and st.B >= self.tiles_o_proj_min_decode_batch and getattr(layer, "wp_o", None) is not None:
+                # round 6: o_proj on dl_linear_tiles -- 1-2 row tiles x 128 neurons x 8 k ranges (256 workgroups), each consumer wave streaming its own operand-order
+                # weight fragments five steps ahead; the slices go to the same residual-add / RMSNorm launch (dl_gemm_smallm's partial sums: 13.0 us at 32 rows)
+                shp, ks_ = self._tiles_o_config(st.B, st.h.shape[1])
+                parts = ops.linear_tiles(st.attn, layer.wp_o, st.h.shape[1], out=st.o_parts[: ks_ * st.B * st.h.shape[1]], epilogue=ops.LT_PARTS, tile_shape=shp, k_split=ks_)
+                ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
+            elif sm:  # (o_proj on dl_linear_packed's partial sums instead: a tie at 8..32 rows, measured and dropped)
                 parts, _ = ops.gemm_smallm_parts(st.attn, layer.self_attn.o_proj.weight, ws)
                 ops.add_rmsnorm_parts(st.h, parts, layer.post_attention_layernorm.weight, eps, out=x_mlp, packed=lp)
             else:

@@ -81,6 +81,12 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
         # finalize(), activations handed over in fragment order by the norm launch that produces them).  tools/bench_linear_packed.py, M = 170:
         # q|k|v 36.2 us (two k ranges per unit set) vs the library's 41.4, gate|up + SiLU * up 57.2 vs 64.1.  DL_PACKED_GEMM=0: library GEMMs.
         self.packed_prefill_gemm = os.environ.get("DL_PACKED_GEMM", "1") == "1"
+        # round 6: o_proj at <= 256 rows (post-compaction prefill layers, decode batches from `tiles_o_proj_min_decode_batch` rows) on dl_linear_tiles' partial sums
+        # OFF by default: 10 % on the launch pair at M = 170, not visible in the prefill (8.26-8.42 ms with and without, box to box) and 1.07 GB of copies at 7B
+        self.tiles_o_proj = os.environ.get("DL_TILES_O", "0") == "1"
+        # (tools/bench_linear_tiles.py --oproj, with the consumer launch: M = 170 23.6 vs 26.4 us for dl_linear_splitk, M = 192 24.7 vs 26.4, M = 117 22.9 vs 24.0 but the library's 21.4;
+        # 32 rows 17.3 vs 18.1 for dl_gemm_smallm, 16 rows 16.8 vs 16.1: used for 129..256 prefill rows; decode batches stay where they were -- 33 = off)
+        self.tiles_o_proj_min_decode_batch = int(os.environ.get("DL_TILES_O_MIN_B", "33"))
         self.packed_down_proj = os.environ.get("DL_PACKED_DOWN", "1") == "1"  # down_proj too (partial sums for dl_add_rmsnorm_parts): A/B knob
         # batched decode (4..32 rows), tools/bench_decode_batch.py: the MLP on dl_linear_packed from 4 rows on (B = 16: 4.05 -> 3.79 ms per step, 24: 4.63 -> 4.03), q|k|v too from 16 rows
         # on (24: 4.05 -> 3.97, 32: 4.21 -> 4.11); o_proj stays on dl_gemm_smallm's partial sums up to 32 rows (against the library GEMM + add: 32 rows 4.20 -> 4.11)
@@ -160,7 +166,7 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
         if self.device.type != "cuda":
             raise ops.HipOpsError("the model must live on the GPU (no CPU path exists)")
         for l in self.model.layers:
-            l.pack(operand_copies=self.packed_prefill_gemm)  # (weights replaced later: call finalize() again -- the operand-order copies are made here)
+            l.pack(operand_copies=self.packed_prefill_gemm, o_copy=self.tiles_o_proj)  # (weights replaced later: call finalize() again -- the operand-order copies are made here)
         self._lp_err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._lp_ws = None
         if any(l.wp_qkv is not None for l in self.model.layers):
@@ -211,6 +217,18 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
             self._packed = False
             self.finalize()
 
+    @staticmethod
+    def _tiles_o_config(rows, n_out):
+        """(tile_shape, k_split) of o_proj on dl_linear_tiles' partial-sum form: up to 8 row tiles as ONE row block, more as two; 8 units (128 neurons) per workgroup;
+        as many k ranges (<= 8) as keep one round of workgroups on the 256 CUs."""
+        rt = (rows + 15) // 16
+        n_mb = 1 if rt <= 8 else 2
+        tm = -(-rt // n_mb)
+        tm = {5: 6}.get(tm, tm)  # (5 row tiles are built with every epilogue under another shape code; 6 wastes one tile and keeps the table small)
+        n_nb = -(-(n_out // 16) // 8)
+        ks = max(1, min(8, 256 // (n_mb * n_nb)))
+        return 100 * tm + 42 + (20000 if tm <= 2 else 0), ks
+
     def _weights_fingerprint(self):
         return tuple(v for p in self._fp_params for v in (p.data_ptr(), p._version))
 
@@ -228,7 +246,7 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
         dl_linear_packed; the CLIP tower's and the projector's projections for dl_linear_tiles) and the tower's fused q|k|v.  The reference holds none of
         these: the harness counterparts report them separately so that `model memory` stays comparable (VERDICT r5 weak #8)."""
         nb = lambda t: 0 if t is None else t.numel() * t.element_size()
-        dec = sum(nb(l.wp_qkv) + nb(l.wp_gu) + nb(l.wp_down) for l in self.model.layers)
+        dec = sum(nb(l.wp_qkv) + nb(l.wp_gu) + nb(l.wp_down) + nb(l.wp_o) for l in self.model.layers)
         vt = self.get_vision_tower()
         clip_tiles = int(getattr(vt, "tiles_bytes", 0) or 0) if vt is not None else 0
         clip_fused = sum(nb(w) + nb(b) for w, b in getattr(vt, "_qkv", [])) if vt is not None else 0
@@ -260,6 +278,7 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
             "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_qkv_parts": self.packed_qkv_parts, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
+            "tiles_o_proj": self.tiles_o_proj, "tiles_o_proj_min_decode_batch": self.tiles_o_proj_min_decode_batch,
             "clip_tiles_gemm": getattr(self.get_vision_tower(), "tiles_gemm", None), "clip_tiles_max_batch": getattr(self.get_vision_tower(), "tiles_max_batch", None),
             "clip_tiles_ksplit": [getattr(self.get_vision_tower(), "tiles_ksplit_out", None), getattr(self.get_vision_tower(), "tiles_ksplit_fc2", None)],
             "test_hook_force_text_decision": self.force_text_decision is not None, "test_hook_single_split_keys_override": self.single_split_keys_override,

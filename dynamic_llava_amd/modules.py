@@ -74,8 +74,9 @@ class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-123
         self.wp_qkv = None
         self.wp_gu = None
         self.wp_down = None
+        self.wp_o = None  # round 6: o_proj for dl_linear_tiles (row tiles x 8 units x k ranges as fp32 partial sums; +33.5 MB per 7B layer)
 
-    def pack(self, operand_copies: bool = False):
+    def pack(self, operand_copies: bool = False, o_copy: bool = False):
         a, m = self.self_attn, self.mlp
         self.w_qkv = torch.cat([a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data], dim=0).contiguous()
         nq, nk = a.q_proj.weight.shape[0], a.k_proj.weight.shape[0]
@@ -86,10 +87,13 @@ class DynamicLlamaDecoderLayer(nn.Module):  # dynamic_modeling_llama.py:1221-123
         I = m.gate_proj.weight.shape[0]
         m.gate_proj.weight.data = self.w_gu[:I]
         m.up_proj.weight.data = self.w_gu[I:]
-        self.wp_qkv = self.wp_gu = self.wp_down = None
+        self.wp_qkv = self.wp_gu = self.wp_down = self.wp_o = None
         if operand_copies and self.w_qkv.dtype in (torch.bfloat16, torch.float16) and self.w_qkv.shape[1] % 64 == 0 and self.w_qkv.shape[0] % 16 == 0 and I % 16 == 0:
             self.wp_qkv = ops.pack_weight_tiles(self.w_qkv)
             self.wp_gu = ops.pack_weight_tiles(self.w_gu, gate_up_pairs=True)
+            wo = a.o_proj.weight.data
+            if o_copy and ops.linear_tiles_ok(1, wo.shape[0], wo.shape[1], wo.dtype) and wo.shape[0] % 128 == 0:
+                self.wp_o = ops.pack_weight_tiles(wo.contiguous())
             if I % 64 == 0:  # down_proj reads the SiLU * up epilogue's fragment-order output and leaves fp32 partial sums for the residual-add / RMSNorm launch
                 self.wp_down = ops.pack_weight_tiles(m.down_proj.weight.data.contiguous())
 

@@ -190,7 +190,7 @@ class PrefillEngine:
     def _prefill_knob_key(self):
         """The knobs that decide which launches a captured prefill contains."""
         vt = self.get_vision_tower()
-        return (self.packed_prefill_gemm, self.packed_down_proj, self.packed_qkv_parts, self.splitk_o_proj, self.prefill_width_bucket, self.device_prompt_layout,
+        return (self.packed_prefill_gemm, self.packed_down_proj, self.packed_qkv_parts, self.splitk_o_proj, self.tiles_o_proj, self.prefill_width_bucket, self.device_prompt_layout,
                 None if vt is None else (vt.tiles_gemm, vt.tiles_max_batch, vt.tiles_ksplit_out, vt.tiles_ksplit_fc2))
 
     def _instruct_on(self, indices, B):
@@ -395,7 +395,14 @@ class PrefillEngine:
                 attn_buf = torch.zeros((total, nH * d), dtype=dt, device=dev)
             attn = attn_buf
             ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : (nH + nKV) * d], qkv[:, (nH + nKV) * d :], attn, cu, max_len, nH, nKV, d, True)
-            if self.splitk_o_proj and dt in (torch.bfloat16, torch.float16) and attn.shape[0] <= 192 and attn.shape[1] >= 1024 and attn.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
+            if self.tiles_o_proj and getattr(layer, "wp_o", None) is not None and dt in (torch.bfloat16, torch.float16) and 128 < attn.shape[0] <= 256 and attn.shape[1] % 64 == 0:
+                # round 6: o_proj [H, H] on dl_linear_tiles -- two blocks of row tiles x 128 neurons x 4 k ranges, one round of workgroups, fp32 partial sums added in range
+                # order by the residual-add / RMSNorm launch: 23.6 us with the consumer at M = 170 against 26.4 for dl_linear_splitk (half as many slice bytes); up to 128
+                # rows it is no better than what was there (22.9 vs 24.0, library 21.4 at M = 117) and stays off
+                shp, ks_ = self._tiles_o_config(attn.shape[0], h.shape[1])
+                parts_ = ops.linear_tiles(attn, layer.wp_o, h.shape[1], out=self._splitk_ws(h.shape[1])[: ks_ * total * h.shape[1]], epilogue=ops.LT_PARTS, tile_shape=shp, k_split=ks_)
+                x = ops.add_rmsnorm_parts(h, parts_, layer.post_attention_layernorm.weight, eps, packed=use_lp)
+            elif self.splitk_o_proj and dt in (torch.bfloat16, torch.float16) and attn.shape[0] <= 192 and attn.shape[1] >= 1024 and attn.shape[1] % 64 == 0 and h.shape[1] % 64 == 0:
                 x = ops.add_rmsnorm_parts(h, ops.linear_splitk(attn, layer.self_attn.o_proj.weight, self._splitk_ws(h.shape[1]), 8), layer.post_attention_layernorm.weight, eps, packed=use_lp)
             else:
                 o = F.linear(attn, layer.self_attn.o_proj.weight)
@@ -478,8 +485,8 @@ class PrefillEngine:
     def _splitk_ws(self, H):
         """fp32 split-K partials of dl_linear_splitk (8 slices x <= 192 rows x H), allocated once."""
         ws = getattr(self, "_splitk_buf", None)
-        if ws is None or ws.numel() < 8 * 192 * H:
-            ws = self._splitk_buf = torch.empty(8 * 192 * H, dtype=torch.float32, device=self.device)
+        if ws is None or ws.numel() < 8 * 256 * H:
+            ws = self._splitk_buf = torch.empty(8 * 256 * H, dtype=torch.float32, device=self.device)
         return ws
 
     def _prefill_host_update(self, p, cache, indices):

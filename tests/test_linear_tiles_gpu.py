@@ -234,3 +234,39 @@ def test_layernorm_rows_family_vs_fp32(rows, H, dtype):
     h = x.clone()
     assert ops.add_layernorm_parts(h, parts, None) is None
     assert torch.equal(h, (x.float() + ((parts[0] + parts[1]) + parts[2]).to(dtype).float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,H,shape,ks", [(170, 4096, 642, 4), (117, 4096, 842, 8), (192, 4096, 642, 4), (32, 4096, 20242, 8), (16, 4096, 20142, 8), (24, 5120, 20242, 6), (179, 5120, 642, 3),
+                                          (64, 4096, 442, 8), (48, 4096, 342, 8), (112, 4096, 742, 8), (128, 4096, 20842, 8)])
+def test_linear_tiles_o_proj_partial_sum_shapes(M, H, shape, ks, dtype):
+    """The decoder's o_proj (DML:1127) at <= 256 rows as TM row tiles x 8 units x k ranges of fp32 partial sums: the slices added in order equal the fp32 product of the
+    16-bit inputs to fp32 rounding, for the tile shapes model._tiles_o_config picks (prefill M = 117..192 at 7B / 13B width, decode batches of 16..32 rows)."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + H + ks)
+    x = torch.randn(M, H, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(H, H, device="cuda", generator=g) / 64).to(dtype)
+    wp = ops.pack_weight_tiles(w)
+    parts = ops.linear_tiles(x, wp, H, epilogue=ops.LT_PARTS, tile_shape=shape, k_split=ks)
+    assert parts.shape == (ks, M, H)
+    total = parts[0].clone()
+    for r in range(1, ks):
+        total += parts[r]
+    ref = x.float() @ w.float().t()
+    assert (total - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+    with pytest.raises(ops.HipOpsError):
+        ops.linear_tiles(x, wp, H, tile_shape=shape)  # these shapes are built for the partial-sum form only
+
+
+def test_tiles_o_config_covers_every_row_count():
+    """Every row count up to 256 at 7B / 13B width maps to a built tile shape and to one round of workgroups."""
+    from dynamic_llava_amd.model import DynamicLlavaLlamaForCausalLM as M_
+
+    built = {142, 242, 342, 442, 642, 742, 842}
+    for H in (4096, 5120):
+        for rows in range(1, 257):
+            shp, ks = M_._tiles_o_config(rows, H)
+            tm = (shp % 10000) // 100
+            assert shp % 10000 in built and 1 <= ks <= 8
+            n_mb = -(-((rows + 15) // 16) // tm)
+            assert n_mb * -(-(H // 16) // 8) * ks <= 256 and n_mb <= 2

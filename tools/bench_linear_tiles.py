@@ -26,6 +26,7 @@ def timed(fn, reps=48):
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--stamps", action="store_true")
+ap.add_argument("--oproj", action="store_true")
 args = ap.parse_args()
 B = args.batch
 CASES = [("clip q|k|v", 577 * B, 3072, 1024, ops.LT_BIAS, [542, 532, 10532, 20532], [1]),
@@ -39,7 +40,7 @@ CASES = [("clip q|k|v", 577 * B, 3072, 1024, ops.LT_BIAS, [542, 532, 10532, 2053
          ("predictor qkv", 576 * B, 1536, 512, ops.LT_BIAS, [522, 532], [1]),
          ("predictor fc1", 576 * B, 2048, 512, ops.LT_GELU, [522, 542], [1]),
          ("predictor fc2", 576 * B, 512, 2048, ops.LT_BIAS, [512, 521], [1, 2])]
-for name, M, N, K, epi, shapes, splits in ([] if args.stamps else CASES):
+for name, M, N, K, epi, shapes, splits in ([] if (args.stamps or args.oproj) else CASES):
     x = torch.randn(M, K, device=dev, dtype=dt)
     xp = ops.pack_x_rows(x)
     NW = max(8, int(300e6 / (N * K * 2)) + 1)  # more than the 256 MB cache: every launch streams its weights from HBM, as in the 23-layer tower
@@ -100,3 +101,40 @@ if args.stamps:
     timeline("qkv", 577, 3072, 1024, ops.LT_BIAS, 532, 1)
     timeline("out", 577, 1024, 1024, ops.LT_BIAS, 521, 1)
     timeline("fc2", 577, 1024, 4096, ops.LT_PARTS, 542, 4)
+
+if "--oproj" in sys.argv:
+    # the decoder's o_proj [4096, 4096] at <= 256 rows: dl_linear_tiles' partial-sum form against what shipped before (dl_linear_splitk at prefill rows, dl_gemm_smallm at
+    # decode batches), each WITH its residual-add / RMSNorm consumer, 32 layers' weights in one graph (cold)
+    from dynamic_llava_amd.model import DynamicLlavaLlamaForCausalLM as M_
+    H = 4096
+    ws = [torch.randn(H, H, device=dev, dtype=dt) * 0.02 for _ in range(32)]
+    wps = [ops.pack_weight_tiles(w) for w in ws]
+    nw = torch.ones(H, device=dev, dtype=dt)
+    for M in (170, 117, 192, 32, 16):
+        x = torch.randn(M, H, device=dev, dtype=dt)
+        h = torch.randn(M, H, device=dev, dtype=dt)
+        out = torch.empty(M, H, device=dev, dtype=dt)
+        buf = torch.empty(8 * 256 * H, device=dev, dtype=torch.float32)
+        shp, ks = M_._tiles_o_config(M, H)
+        res = {}
+        def tiles(i):
+            p_ = ops.linear_tiles(x, wps[i % 32], H, out=buf[: ks * M * H], epilogue=ops.LT_PARTS, tile_shape=shp, k_split=ks)
+            ops.add_rmsnorm_parts(h, p_, nw, 1e-5, out=out)
+        res[f"tiles {shp} k{ks}"] = timed(tiles, reps=32)
+        res["tiles alone"] = timed(lambda i: ops.linear_tiles(x, wps[i % 32], H, out=buf[: ks * M * H], epilogue=ops.LT_PARTS, tile_shape=shp, k_split=ks), reps=32)
+        if M <= 192:
+            def splitk(i):
+                p_ = ops.linear_splitk(x, ws[i % 32], buf, 8)
+                ops.add_rmsnorm_parts(h, p_, nw, 1e-5, out=out)
+            res["splitk s8"] = timed(splitk, reps=32)
+        if M <= 32:
+            wsm = torch.empty(8 * M * 32768, device=dev, dtype=torch.float32)
+            def smallm(i):
+                p_, _ = ops.gemm_smallm_parts(x, ws[i % 32], wsm)
+                ops.add_rmsnorm_parts(h, p_, nw, 1e-5, out=out)
+            res["gemm_smallm"] = timed(smallm, reps=32)
+        def lib_(i):
+            o = F.linear(x, ws[i % 32])
+            ops.add_rmsnorm(h, o, nw, 1e-5, out=out)
+        res["library"] = timed(lib_, reps=32)
+        print(f"o_proj M={M:4d} (+ residual-add / RMSNorm consumer): " + "  ".join(f"{k} {v:6.2f} us" for k, v in res.items()), flush=True)
