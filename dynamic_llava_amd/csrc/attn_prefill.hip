@@ -8,6 +8,8 @@
 // f32: simple wave-per-query kernel (parity/debug path, exact fp32 arithmetic).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dl_common.h"
 
 namespace dl {
@@ -25,6 +27,18 @@ __device__ __forceinline__ f32x4_t mfma16<bf16_t>(const uint4& a, const uint4& b
 template <>
 __device__ __forceinline__ f32x4_t mfma16<f16_t>(const uint4& a, const uint4& b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// two fp32 -> one packed pair of the 16-bit type, round-to-nearest-even (bf16: v_cvt_pk_bf16_f32, the same bits as Elem<bf16_t>::from_f for finite values)
+template <typename T>
+__device__ __forceinline__ uint32_t pf_pack2(float a, float b) {
+  if constexpr (Elem<T>::kBf16) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, bf2));
+  } else {
+    return (uint32_t)Elem<T>::from_f(a) | ((uint32_t)Elem<T>::from_f(b) << 16);
+  }
 }
 
 constexpr int kBN = 64, kPad = 8;
@@ -674,6 +688,242 @@ __global__ __launch_bounds__(RW * KW * 64) void attn_prefill_keysplit_kernel(con
   DL_PSTAMP(7);
 }
 
+// ---- whole-row variant for head_dim 64, non-causal, 257..608 keys (round 6): the CLIP ViT-L/14-336 tower (577 tokens, CTL / clip_encoder.py:53-71) and the vision
+// predictor (576, DML:1348-1359).  The key-split kernel above walks such a row in three rounds of 256 keys, and a round costs its 16 waves ~3.3 us of latency
+// (tools/pf_timing_clip.hip: fetch -> S -> softmax -> P through LDS -> PV -> barrier -> stash -> barrier), 17 us per launch for 1.4 GFLOP.  Here ALL keys of the head are
+// on chip at once -- 76 KiB of K and 76 KiB of V^T in matrix-core FRAGMENT order (a 16 x 32 fragment = one lane-linear KiB: conflict-free ds_read_b128, nothing to swizzle) --
+// staged in one round trip: K by LDS-DMA (per-lane global addresses, no register pass), V through registers (4 keys x 8 dims per thread -> eight 8-byte writes: the
+// transpose).  Then no barrier until the end.  Both products keep the per-QUERY operand in registers and take the matrix operand from LDS:
+//   S^T = K Q^T  (A = K fragment, B = the wave's 16 query rows)      -> lane (lr, lg) holds S^T[key 16 kt + 4 lg + r][query lr]: all of a lane's values belong to ONE query
+//   O^T = V^T P^T (A = V^T fragment, B = P^T straight from the S^T accumulators: no trip through LDS) -> lane holds O^T[dim 16 dt + 4 lg + r][query lr]
+// so the online softmax is in-register: the row maximum crosses lanes (xor 16, xor 32) once per 32 keys, the row sum only at the end.  The k order inside a 32-key chunk is
+// the accumulators' own (keys 4 lg + r of the chunk's two tiles); the V^T image is written in that order, so nothing is permuted at run time.
+// 8 waves = 4 row tiles (64 query rows per workgroup) x 2 key halves; the halves' (m, l, O) meet through LDS once, in half order (deterministic).
+template <typename T, int KW>
+__global__ __launch_bounds__(256 * KW) void attn_prefill_whole_d64_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_, int64_t q_rs,
+                                                                     int64_t kv_rs, void* __restrict__ out_, int64_t out_rs, const int32_t* __restrict__ cu, int n_rep,
+                                                                     float scale) {
+  using S = uint16_t;
+  constexpr int D = 64, KT = 38, KC = 19;  // up to 608 keys
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  typedef __attribute__((address_space(1))) void glob_v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S* Kf = reinterpret_cast<S*>(smem);  // [key tile][dims half][64 lanes][8]
+  S* Vf = Kf + KT * 2 * 512;           // [dim tile][32-key chunk][64 lanes][8]
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  const int q0 = qt * 64;
+  if (q0 >= L) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NWV = 4 * KW, NT_ = 64 * NWV;
+  const int rw = w & 3, kw = w >> 2;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kvh = h / n_rep;
+  const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
+  const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const int n_kc = (L + 31) >> 5;  // 32-key chunks (= pairs of key tiles); keys past L are staged as copies of key L - 1 and masked
+  DL_PSTAMP(0);
+  // ---- K: one DMA piece per (key tile, dims half) ----
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)smem;
+    for (int kt = w; kt < n_kc * 2; kt += NWV) {  // both dims halves of a key tile by the same wave, back to back: the second piece's 128-byte lines are the first one's
+      int key = kt * 16 + lr;
+      key = key < L ? key : L - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t voff = (uint32_t)key * (uint32_t)kv_rs * 2u + (uint32_t)(ks * 32 + lg * 8) * 2u;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(kt * 2 + ks) * 1024u);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"((const glob_v*)kb), "s"(dst)
+                     : "memory");
+      }
+    }
+  }
+  DL_PSTAMP(8);  // (timing builds) K pieces issued and landed
+  // ---- V: 4 keys x 8 dims per task -> V^T fragments (the 8-byte slot of key quad (h2, lg') in lane 16 lg' + dim) ----
+  {
+    // every load of the thread's (up to two per pass) tasks is requested before the first transpose: the staging is one memory round trip deep, not one per task
+    const int n_tasks = n_kc * 64;
+    for (int t0 = tid; t0 < n_tasks; t0 += 2 * NT_) {
+      uint4 vr[2][4];
+      int tt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t0 + u * NT_;
+        tt[u] = t < n_tasks ? t : t0;  // (a thread without a second task re-loads its first: unconditional loads, nothing is written twice)
+        const int qd = tt[u] >> 3, ch = tt[u] & 7;
+        const int kc = qd >> 3, h2 = (qd >> 2) & 1, lgf = qd & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int key = kc * 32 + h2 * 16 + lgf * 4 + j;
+          key = key < L ? key : L - 1;
+          vr[u][j] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * kv_rs + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && t0 + NT_ >= n_tasks) break;
+        const int qd = tt[u] >> 3, ch = tt[u] & 7;
+        const int kc = qd >> 3, h2 = (qd >> 2) & 1, lgf = qd & 3;
+        const uint32_t w0[4] = {vr[u][0].x, vr[u][0].y, vr[u][0].z, vr[u][0].w}, w1[4] = {vr[u][1].x, vr[u][1].y, vr[u][1].z, vr[u][1].w};
+        const uint32_t w2[4] = {vr[u][2].x, vr[u][2].y, vr[u][2].z, vr[u][2].w}, w3[4] = {vr[u][3].x, vr[u][3].y, vr[u][3].z, vr[u][3].w};
+        // Slot of dim `lrf` inside its 16-dim x 4-group fragment: 16 B per (group, dim), XOR-swizzled in the low three dim bits by (dim tile, dim bit 3).  Unswizzled, the
+        // 64 lanes of one of these 8-byte writes (8 dim chunks x 8 key quads) all land on the same two bank pairs -- 32-way, 3 us of staging (first build); the swizzle is a
+        // permutation inside each aligned 16-lane block, which keeps the consumers' ds_read_b128 conflict-free.
+        S* frag = Vf + ((ch >> 1) * KC + kc) * 512 + lgf * 16 * 8 + h2 * 4;
+        const int swz = ((ch >> 1) << 1 | (ch & 1)) & 7, hi8 = (ch & 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // dims 2e, 2e + 1 of the chunk: 4 keys each -> one 8-byte write per dim
+          uint2 lo, hi;
+          lo.x = (w0[e] & 0xffffu) | (w1[e] << 16);
+          lo.y = (w2[e] & 0xffffu) | (w3[e] << 16);
+          hi.x = (w0[e] >> 16) | (w1[e] & 0xffff0000u);
+          hi.y = (w2[e] >> 16) | (w3[e] & 0xffff0000u);
+          *reinterpret_cast<uint2*>(frag + (hi8 + ((2 * e) ^ swz)) * 8) = lo;
+          *reinterpret_cast<uint2*>(frag + (hi8 + ((2 * e + 1) ^ swz)) * 8) = hi;
+        }
+      }
+    }
+  }
+  DL_PSTAMP(9);  // V staged
+  // ---- Q: the wave's 16 rows as the B operand (lane: query lr, dims 32 ks + 8 lg ..) ----
+  uint4 qf[2];
+  {
+    int qrow = q0 + rw * 16 + lr;
+    qrow = qrow < L ? qrow : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * q_rs + ks * 32 + lg * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+  __syncthreads();
+  DL_PSTAMP(1);  // everything staged
+
+  f32x4_t acc_o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc_o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const float scale2 = scale * 1.44269504088896340736f;
+  float m = -INFINITY, l = 0.f;  // (m in units of log2 e) l: this lane's share of the row sum (its 8 keys per chunk); the four lane groups meet at the end
+  const int c0 = (n_kc * kw) / KW, c1 = (n_kc * (kw + 1)) / KW;  // this wave's share of the 32-key chunks
+  const S* vrd[4];  // this lane's 16 bytes of a V^T fragment, per dim tile (the staging's swizzle)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vrd[dt] = Vf + dt * KC * 512 + (lg * 16 + (lr ^ (((dt << 1) | (lr >> 3)) & 7))) * 8;
+  // one softmax update per NCH chunks (64 keys where the wave's share allows: half the cross-lane maxima and rescale decisions per key; a last single chunk otherwise)
+  auto step = [&](int kc, auto nch_) {
+    constexpr int NCH = decltype(nch_)::value;
+    float sv[NCH][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 a0 = *reinterpret_cast<const uint4*>(Kf + ((2 * (kc + c)) * 2 + ks) * 512 + lane * 8);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(Kf + ((2 * (kc + c) + 1) * 2 + ks) * 512 + lane * 8);
+        s0 = mfma16<T>(a0, qf[ks], s0);
+        s1 = mfma16<T>(a1, qf[ks], s1);
+      }
+      // scores in units of log2(e): p = exp2(s' - m') (one v_exp_f32 each, no multiply), the roundings of P are the hardware's RNE for bf16
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sv[c][j] = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale2;
+      if ((kc + c) * 32 + 32 > L) {  // (wave-uniform) only the row's last chunk holds keys past L (staged as copies of key L - 1): masked
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if ((kc + c) * 32 + (j >> 2) * 16 + lg * 4 + (j & 3) >= L) sv[c][j] = -INFINITY;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, sv[c][j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    const float alpha = __builtin_amdgcn_exp2f(m - ms);
+    float rs = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sv[c][j] = __builtin_amdgcn_exp2f(sv[c][j] - ms);
+        rs += sv[c][j];
+      }
+    l = l * alpha + rs;
+    if (__any(mn != m)) {  // (wave-uniform branch) the running maximum moved for some query of the wave: rescale; after the first chunks it rarely does
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha;
+    }
+    m = mn;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      uint4 pf;
+      pf.x = pf_pack2<T>(sv[c][0], sv[c][1]);
+      pf.y = pf_pack2<T>(sv[c][2], sv[c][3]);
+      pf.z = pf_pack2<T>(sv[c][4], sv[c][5]);
+      pf.w = pf_pack2<T>(sv[c][6], sv[c][7]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(vrd[dt] + (kc + c) * 512);
+        acc_o[dt] = mfma16<T>(vf, pf, acc_o[dt]);
+      }
+    }
+  };
+  {
+    int kc = c0;
+    for (; kc + 2 <= c1; kc += 2) step(kc, std::integral_constant<int, 2>{});
+    if (kc < c1) step(kc, std::integral_constant<int, 1>{});
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  DL_PSTAMP(2);  // all keys
+  // ---- the key ranges meet: ranges 1.. publish (m, l, O^T) in the K region (dead after the barrier), range 0 merges them in range order ----
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(smem) + (rw * (KW - 1)) * 18 * 64;
+  if (kw > 0) {
+    float* pp = part + (kw - 1) * 18 * 64;
+    pp[lane] = m;
+    pp[64 + lane] = l;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[(2 + dt * 4 + r) * 64 + lane] = acc_o[dt][r];
+  }
+  __syncthreads();
+  if (kw > 0) return;
+#pragma unroll
+  for (int o = 0; o < KW - 1; ++o) {
+    const float* pp = part + o * 18 * 64;
+    const float m1 = pp[lane], l1 = pp[64 + lane];
+    const float mn = fmaxf(m, m1);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    const float a0 = __builtin_amdgcn_exp2f(m - ms), a1 = __builtin_amdgcn_exp2f(m1 - ms);
+    l = l * a0 + l1 * a1;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_o[dt][r] = acc_o[dt][r] * a0 + pp[(2 + dt * 4 + r) * 64 + lane] * a1;
+  }
+  DL_PSTAMP(3);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const int qi = q0 + rw * 16 + lr;
+  if (qi < L) {
+    S* ob = reinterpret_cast<S*>(out_) + (int64_t)(tok0 + qi) * out_rs + (int64_t)h * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 o;
+      o.x = (uint32_t)Elem<T>::from_f(acc_o[dt][0] * inv) | ((uint32_t)Elem<T>::from_f(acc_o[dt][1] * inv) << 16);
+      o.y = (uint32_t)Elem<T>::from_f(acc_o[dt][2] * inv) | ((uint32_t)Elem<T>::from_f(acc_o[dt][3] * inv) << 16);
+      *reinterpret_cast<uint2*>(ob + dt * 16 + lg * 4) = o;
+    }
+  }
+  DL_PSTAMP(7);
+}
+
 // ---- generic path: one wave per query row, lanes over keys (scores) then over dims (output) ----
 template <typename T>
 __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
@@ -789,6 +1039,31 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
   // workgroups -- at larger batches the plain kernel's three resident workgroups per CU win.
   //   head_dim 128, causal, 64 < rows <= 192 (decoder layers >= 2 at B=1): 32 rows x (2 | 3) key tiles, one round  (T=170: 15.2 -> 8.9 us)
   //   head_dim 64, full, rows > 128 (CLIP tower, vision predictor): 64 rows x 4 key tiles, rounds of 256 keys
+  if constexpr (D == 64) {
+    // whole-row kernel (round 6): all keys of a head on chip in fragment order, no rounds (CLIP tower: 17.4 -> see profiles/r06_attn_whole_row.txt)
+    bool whole = !causal && !kv_len && max_seqlen > 256 && max_seqlen <= 608 && q_rs % 8 == 0 && kv_rs % 8 == 0 && out_rs % 4 == 0 &&
+                 (int64_t)max_seqlen * kv_rs * 2 < ((int64_t)1 << 31);
+    if (const char* e = getenv("DL_PF_WHOLE")) whole = whole && atoi(e) != 0;  // A/B against the key-split kernel
+    if (whole) {
+      const size_t smem = (size_t)(38 * 2 + 4 * 19) * 1024;
+      int kwv = 4;
+      if (const char* e = getenv("DL_PF_WHOLE_KW")) kwv = atoi(e) == 2 ? 2 : 4;  // tuning experiments only
+#define DL_LAUNCH_WHOLE(KWV)                                                                                                             \
+  {                                                                                                                                      \
+    auto kfn = attn_prefill_whole_d64_kernel<T, KWV>;                                                                                    \
+    static bool attr_set = false;                                                                                                        \
+    if (!attr_set) {                                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);             \
+      attr_set = true;                                                                                                                   \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((max_seqlen + 63) / 64), (unsigned)n_heads, (unsigned)B), dim3(256 * KWV), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, \
+                       n_rep, scale);                                                                                                    \
+  }
+      if (kwv == 2) DL_LAUNCH_WHOLE(2) else DL_LAUNCH_WHOLE(4)
+#undef DL_LAUNCH_WHOLE
+      return;
+    }
+  }
   if constexpr (D == 128 || D == 64) {
     bool ksplit = false;
     if (D == 128) ksplit = causal && !kv_len && max_seqlen > 64 && max_seqlen <= 192 && (int64_t)B * n_heads * ((max_seqlen + 31) / 32) <= 256;

@@ -37,6 +37,10 @@ int main(int argc, char** argv) {
     long long s[16];
     hipMemcpyFromSymbol(s, HIP_SYMBOL(dl::g_pf_stamps), sizeof(s));
     if (it >= 5)
+      printf("   whole-row kernel: K landed %.2f | V staged %.2f (since entry)\n", (s[8] - s[0]) * 0.01, (s[9] - s[0]) * 0.01);
+    if (it >= 5 && getenv("DL_PF_WHOLE") && atoi(getenv("DL_PF_WHOLE")) == 0)
+      printf("   whole-row kernel: K landed %.2f | V staged %.2f (since entry)\n", (s[8] - s[0]) * 0.01, (s[9] - s[0]) * 0.01);
+    if (it >= 5 && getenv("DL_PF_WHOLE") && atoi(getenv("DL_PF_WHOLE")) == 0)
       printf("   round 1 (since the round's start = stamp 12 of round 0 is not taken; relative to entry): loads landed %.2f | compute done %.2f | barrier %.2f | stash %.2f | barrier %.2f us\n",
              (s[8] - s[0]) * 0.01, (s[9] - s[0]) * 0.01, (s[10] - s[0]) * 0.01, (s[11] - s[0]) * 0.01, (s[12] - s[0]) * 0.01);
     if (it >= 5)
