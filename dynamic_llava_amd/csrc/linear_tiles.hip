@@ -456,17 +456,19 @@ static int lt_shape(const LtParams& p, const LtShape& s, int epilogue, hipStream
   if (s.tm == tm_ && s.wn == wn_ && s.nuw == nuw_ && s.wdir == wdir_ && (!wdir_ || s.dw == dw_)) return lt_epi<T, tm_, wn_, nuw_, wdir_, dw_>(p, epilogue, st)
   LT_CASE(5, 4, 2, 1, 3);
   LT_CASE(5, 4, 2, 1, 5);
-  LT_CASE(5, 4, 2, 0, 3);
   LT_CASE(5, 3, 2, 1, 3);
   LT_CASE(5, 3, 2, 1, 5);
-  LT_CASE(5, 3, 2, 0, 3);
   LT_CASE(5, 2, 2, 1, 3);
   LT_CASE(5, 1, 2, 1, 3);
   LT_CASE(5, 2, 1, 1, 3);
   LT_CASE(5, 2, 1, 1, 5);
-  LT_CASE(5, 2, 1, 0, 3);
   LT_CASE(5, 4, 1, 1, 3);
   LT_CASE(5, 4, 1, 1, 5);
+#ifdef DL_LT_MEASURE  // measurement builds only (HIPCC_EXTRA=-DDL_LT_MEASURE): the weights through the LDS ring as well (tile_shape + 10000), DESIGN.md section 4d
+  LT_CASE(5, 4, 2, 0, 3);
+  LT_CASE(5, 3, 2, 0, 3);
+  LT_CASE(5, 2, 1, 0, 3);
+#endif
 #undef LT_CASE
   // partial-sum form only (round 6, late): the decoder's o_proj [H, H] at <= 256 rows -- the post-compaction prefill layers (M = 117..192: 8..12 row tiles as one or two
   // row blocks) and decode batches of 16..32 rows (1..2 row tiles) -- as TM row tiles x 8 units x k ranges, the slices added by dl_add_rmsnorm_parts

@@ -72,6 +72,12 @@ if args.stamps:
     # s_memtime counters of different XCDs are not synchronised: every wave is reported relative to ITS OWN entry stamp; ticks = shader clocks (~2.4 GHz)
     tick_us = 1 / 2400.0
     def timeline(name, M, N, K, epi, sh, ks, wrap=0, K_alloc=None):
+        try:
+            return _timeline(name, M, N, K, epi, sh, ks, wrap, K_alloc)
+        except ops.HipOpsError as e:  # (the "W via LDS" shapes exist only in a library built with HIPCC_EXTRA=-DDL_LT_MEASURE)
+            print(f"{name}: skipped ({str(e)[:120]})")
+
+    def _timeline(name, M, N, K, epi, sh, ks, wrap=0, K_alloc=None):
         Ka = K_alloc or K
         x = torch.randn(M, Ka, device=dev, dtype=dt); xp = ops.pack_x_rows(x)
         w = torch.randn(N, Ka, device=dev, dtype=dt) * 0.02; wp = ops.pack_weight_tiles(w)

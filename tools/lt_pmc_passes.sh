@@ -1,6 +1,7 @@
 #!/bin/bash
 # Counter passes over tools/pmc_linear_tiles_probe.py (one counter group per pass, --kernel-trace only): what bounds dl_linear_tiles' k loop
 set -e
+# (the 'W through LDS' rows of the dl_linear_tiles tables need a library built with HIPCC_EXTRA=-DDL_LT_MEASURE python -m dynamic_llava_amd.build_ext --force; without it they are skipped)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 RAW=/tmp/dl_lt_raw
 rm -rf "$RAW"; mkdir -p gpurun_out "$RAW"

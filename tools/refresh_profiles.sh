@@ -3,6 +3,7 @@
 #   default bench line, rocprofv3 kernel-trace summary of the same command, PMC HBM-traffic passes, MFMA utilisation of the prefill.
 # PMC passes are separate runs with --kernel-trace only (no other trace domains), one counter group per pass.
 set -e
+# (the 'W through LDS' rows of the dl_linear_tiles tables need a library built with HIPCC_EXTRA=-DDL_LT_MEASURE python -m dynamic_llava_amd.build_ext --force; without it they are skipped)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 R=${1:-r01}
 RAW=/tmp/dl_prof_raw   # raw rocprofv3 databases stay off gpurun_out/ (64 MiB merge limit): only the summaries go there
