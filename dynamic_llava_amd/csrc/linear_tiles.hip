@@ -464,6 +464,10 @@ static int lt_shape(const LtParams& p, const LtShape& s, int epilogue, hipStream
   LT_CASE(5, 2, 1, 1, 5);
   LT_CASE(5, 4, 1, 1, 3);
   LT_CASE(5, 4, 1, 1, 5);
+  // two to four images (M = 1154 .. 2308): 160-row tiles -- 18 instead of 2 x 13 KiB-pairs per step and MAC pair, one round of workgroups at two images
+  LT_CASE(10, 4, 2, 1, 3);
+  LT_CASE(10, 3, 2, 1, 3);
+  LT_CASE(10, 4, 1, 1, 3);
 #ifdef DL_LT_MEASURE  // measurement builds only (HIPCC_EXTRA=-DDL_LT_MEASURE): the weights through the LDS ring as well (tile_shape + 10000), DESIGN.md section 4d
   LT_CASE(5, 4, 2, 0, 3);
   LT_CASE(5, 3, 2, 0, 3);
@@ -493,6 +497,14 @@ static int lt_shape(const LtParams& p, const LtShape& s, int epilogue, hipStream
 // one round over the chip where the shape allows it: the fewest workgroups <= 256 among the built shapes, the largest tile first
 static LtShape lt_pick(int row_tiles, int n_units, int k_split) {
   static const LtShape kShapes[] = {{5, 4, 2, 1, 3}, {5, 3, 2, 1, 3}, {5, 4, 1, 1, 3}, {5, 2, 1, 1, 3}};  // (4 units as 4 waves x 1 beat 2 x 2: tools/bench_linear_tiles.py)
+  static const LtShape kShapes10[] = {{10, 4, 2, 1, 3}, {10, 3, 2, 1, 3}, {10, 4, 1, 1, 3}};
+  if (row_tiles > 40) {  // more than one image: 160-row tiles halve the bytes per MAC that enter a CU, and two images still fit one round of workgroups
+    for (const LtShape& s : kShapes10) {
+      const int64_t g = (int64_t)((row_tiles + s.tm - 1) / s.tm) * ((n_units + s.wn * s.nuw - 1) / (s.wn * s.nuw)) * k_split;
+      if (g >= 224) return s;
+    }
+    return kShapes10[2];
+  }
   for (const LtShape& s : kShapes) {
     const int64_t g = (int64_t)((row_tiles + s.tm - 1) / s.tm) * ((n_units + s.wn * s.nuw - 1) / (s.wn * s.nuw)) * k_split;
     if (g >= 224) return s;  // at least 7/8 of the chip; smaller tiles only add traffic

@@ -223,7 +223,7 @@ class CLIPVisionTower(nn.Module):
         self.is_loaded = True
         # round 6 knobs: the tower's projections on dl_linear_tiles (False: the library GEMMs), up to how many images per call, k ranges of out_proj / fc2
         self.tiles_gemm = os.environ.get("DL_CLIP_TILES", "1") != "0"
-        self.tiles_max_batch = 1  # tools/bench_linear_tiles.py --batch 2 / 4: a tie at two images (the 80-row tiles need two rounds), the library's large tiles win from there
+        self.tiles_max_batch = 2  # tools/clip_tower_batch_time.py: 0.85 of the library path at one image, 0.95 at two (160-row tiles, one round of workgroups); 1.26 / 1.17 at three / four
         self.tiles_ksplit_out, self.tiles_ksplit_fc2 = 2, 4
         self._patch_embed_as_gemm()
 

@@ -422,7 +422,7 @@ int dl_linear_packed_stamped(const void* X, int64_t ldx, int x_packed, const voi
  *   -- dl_add_layernorm_parts -- adds the slices in order, then the bias).  k_split > 1 only with epilogue 3.
  *   y_packed (epilogues 0..2, N % 64 == 0): Y is written in fragment order for the next call.
  *   tile_shape: 0 = chosen here (one round of workgroups over the 256 CUs where the shape allows), else 100 TM + 10 WN + NUW: TM row tiles of 16 rows x
- *   WN consumer waves x NUW units of 16 neurons per workgroup (built: 542, 532, 522, 512, 521, 541; + 20000 = five instead of three steps of weight
+ *   WN consumer waves x NUW units of 16 neurons per workgroup (built: 542, 532, 522, 512, 521, 541, and for two to four images 1042, 1032, 1041; + 20000 = five instead of three steps of weight
  *   fragments in flight -- 542, 532, 521, 541; a library built with -DDL_LT_MEASURE also holds + 10000 = the weights through the LDS ring as well -- 542, 532, 521); with epilogue 3 only:
  *   142, 242, 342, 442, 642, 742, 842 (+ 20142, 20242, 20842) -- the decoder's o_proj (DML:1127) at <= 256 rows as TM row tiles x 8 units x k ranges.
  *   Deterministic: one fp32 accumulation per output in k order per range; row-position invariant. */

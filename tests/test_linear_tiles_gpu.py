@@ -62,7 +62,7 @@ def test_linear_tiles_bias_vs_fp32(M, N, K, dtype):
     assert (y3.float() - ref3).abs().le(_tol(ref3, dtype)).all()
 
 
-@pytest.mark.parametrize("shape", [542, 532, 522, 512, 521, 541, 20542, 20532, 20521, 20541])
+@pytest.mark.parametrize("shape", [542, 532, 522, 512, 521, 541, 20542, 20532, 20521, 20541, 1042, 1032, 1041])
 def test_linear_tiles_every_built_tile_shape_same_bits(shape):
     """The result is a function of the k order only: every tile shape returns the same bits (one fp32 chain per output, k ascending)."""
     ops = _ops()

@@ -684,26 +684,32 @@ def test_clip_tower_packed_path_matches_eager_module(dtype):
     t = tower.to("cuda", dtype).pack()
     x = imgs.cuda().to(dtype)
     eager = t.forward_eager(x).float()
+    default_max = t.tiles_max_batch
+    t.tiles_max_batch = 0  # the library-GEMM path (what three or more images, and fp32, run)
     hip = t(x).float()
+    t.tiles_max_batch = default_max
     assert hip.shape == (2, 576, 1024) and torch.isfinite(hip).all()
     if dtype == torch.float32:
         assert float((hip - truth).abs().max()) < 1e-4 * max(1.0, float(truth.abs().max()))
+        assert float((t(x).float() - truth).abs().max()) < 1e-4 * max(1.0, float(truth.abs().max()))  # (fp32 never takes the tiled path)
         return
     e_ref, e_hip = (eager - truth), (hip - truth)
     assert float(e_hip.abs().max()) <= 2.0 * float(e_ref.abs().max()) + 1e-3, (float(e_hip.abs().max()), float(e_ref.abs().max()))
     assert float(e_hip.pow(2).mean().sqrt()) <= 1.5 * float(e_ref.pow(2).mean().sqrt()) + 1e-4
-    # round 6: one image runs every projection on dl_linear_tiles (operand-order weight copies, QuickGELU in fc1's epilogue, out_proj / fc2 as fp32 k-range
-    # partial sums added by the residual-add + LayerNorm launch); two images (above) stay on the library GEMMs.  Same bounds, against the same fp32 truth.
-    assert t._tiles[0] is not None and t.tiles_max_batch >= 1
+    # round 6: up to `tiles_max_batch` (2) images run every projection on dl_linear_tiles (operand-order weight copies, QuickGELU in fc1's epilogue, out_proj /
+    # fc2 as fp32 k-range partial sums added by the residual-add + LayerNorm launch; 80-row tiles at one image, 160-row tiles at two).  Same bounds, against
+    # the same fp32 truth.
+    assert t._tiles[0] is not None and t.tiles_max_batch == 2
     hip1 = t(x[:1]).float()
     e_hip1 = hip1 - truth[:1]
     assert float(e_hip1.abs().max()) <= 2.0 * float(e_ref[:1].abs().max()) + 1e-3, (float(e_hip1.abs().max()), float(e_ref[:1].abs().max()))
     assert float(e_hip1.pow(2).mean().sqrt()) <= 1.5 * float(e_ref[:1].pow(2).mean().sqrt()) + 1e-4
-    t.tiles_max_batch = 2  # and the tiled path at two images (two rounds of workgroups; the attention launch picks another kernel at this grid size, so same
-    hip2 = t(x).float()    # bounds rather than the one-image run's bits -- the GEMM itself is row-position invariant: tests/test_linear_tiles_gpu.py)
-    e_hip2 = hip2 - truth
+    hip2 = t(x).float()  # (the attention launch picks another kernel at this grid size, so same bounds rather than the one-image run's bits -- the GEMM
+    e_hip2 = hip2 - truth  # itself is row-position invariant: tests/test_linear_tiles_gpu.py)
     assert float(e_hip2.abs().max()) <= 2.0 * float(e_ref.abs().max()) + 1e-3 and float(e_hip2.pow(2).mean().sqrt()) <= 1.5 * float(e_ref.pow(2).mean().sqrt()) + 1e-4
-    t.tiles_max_batch = 1
+    x3 = torch.cat([x, x[:1]])  # three images: library path; rows of the first two images must not depend on the batch they rode in beyond kernel choice
+    hip3 = t(x3).float()
+    assert float((hip3[:2] - truth).abs().max()) <= 2.0 * float(e_ref.abs().max()) + 1e-3
     # unused last layer is really skipped, CLS token dropped
     t.select_feature = "cls_patch"
     assert t(x).shape == (2, 577, 1024)

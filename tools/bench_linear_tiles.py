@@ -29,13 +29,14 @@ ap.add_argument("--stamps", action="store_true")
 ap.add_argument("--oproj", action="store_true")
 args = ap.parse_args()
 B = args.batch
-CASES = [("clip q|k|v", 577 * B, 3072, 1024, ops.LT_BIAS, [542, 532, 10532, 20532], [1]),
-         ("clip out_proj", 577 * B, 1024, 1024, ops.LT_BIAS, [521, 10521, 20521, 522, 541, 20541], [1, 2]),
-         ("clip fc1+qgelu", 577 * B, 4096, 1024, ops.LT_QGELU, [542, 10542, 20542], [1]),
-         ("clip fc1 (bias only)", 577 * B, 4096, 1024, ops.LT_BIAS, [542, 10542, 20542], [1]),
-         ("clip fc2", 577 * B, 1024, 4096, ops.LT_BIAS, [542, 10542, 20542, 522], [2, 4]),
-         ("projector 1+gelu", 576 * B, 4096, 1024, ops.LT_GELU, [542, 20542], [1]),
-         ("projector 2", 576 * B, 4096, 4096, ops.LT_BIAS, [542, 10542, 20542], [1]),
+T10 = [1042, 1032, 1041] if B > 1 else []
+CASES = [("clip q|k|v", 577 * B, 3072, 1024, ops.LT_BIAS, [542, 532, 10532, 20532] + T10, [1]),
+         ("clip out_proj", 577 * B, 1024, 1024, ops.LT_BIAS, [521, 10521, 20521, 522, 541, 20541] + T10, [1, 2]),
+         ("clip fc1+qgelu", 577 * B, 4096, 1024, ops.LT_QGELU, [542, 10542, 20542] + T10, [1]),
+         ("clip fc1 (bias only)", 577 * B, 4096, 1024, ops.LT_BIAS, [542, 10542, 20542] + T10, [1]),
+         ("clip fc2", 577 * B, 1024, 4096, ops.LT_BIAS, [542, 10542, 20542, 522] + T10, [1, 2, 4]),
+         ("projector 1+gelu", 576 * B, 4096, 1024, ops.LT_GELU, [542, 20542] + T10, [1]),
+         ("projector 2", 576 * B, 4096, 4096, ops.LT_BIAS, [542, 10542, 20542] + T10, [1]),
          ("predictor in", 576 * B, 512, 4096, ops.LT_GELU, [521, 522], [2, 4]),
          ("predictor qkv", 576 * B, 1536, 512, ops.LT_BIAS, [522, 532], [1]),
          ("predictor fc1", 576 * B, 2048, 512, ops.LT_GELU, [522, 542], [1]),
