@@ -41,12 +41,12 @@ __device__ long long g_attn_stamps[8];
 // slot come from the previous layer / step, so a stale granule never carries the expected tag.  Needs every workgroup of the grid
 // resident (the host selects INK only for grids the device can hold at once: ink_resident_capacity); the wait is bounded and poisons the
 // output with NaN on give-up.
-template <typename T, int D, int NW, bool FUSED, int U, bool INK = false>
+template <typename T, int D, int NW, bool FUSED, int U, bool INK = false, int NP = 0>
 __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     const void* __restrict__ q_, int64_t q_row_stride, const void* k_slab_, const void* v_slab_, int64_t stride_b, int64_t stride_h,
     const int32_t* __restrict__ kv_len, int extra, float* __restrict__ ws, void* __restrict__ out_, int64_t out_row_stride, int n_rep,
     float scale, const void* __restrict__ cos_, const void* __restrict__ sin_, int n_pos, const int32_t* __restrict__ pos_base, int T_cap,
-    int n_kv_heads, int chunk_keys, int call_tag = 0) {
+    int n_kv_heads, int chunk_keys, int call_tag = 0, int64_t part_stride = 0) {
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename Elem<T>::storage;
   constexpr int NG = St::NG;
@@ -74,14 +74,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
   }
   const int kvh = h / n_rep;
-  const S* row = reinterpret_cast<const S*>(q_) + (int64_t)b * q_row_stride;
+  // the new token's q|k|v row: elements of T, or (dl_attn_decode_rope_parts) the fp32 partial sums of the projection's k ranges
+  constexpr int64_t esz = NP > 0 ? 4 : (int64_t)sizeof(S);
+  const char* row = reinterpret_cast<const char*>(q_) + (int64_t)b * q_row_stride * esz;
   const int T_old = kv_len[b];
   St st;
   attn_split_issue<T, D, NW, FUSED, U>(st, tid, k_slab_, v_slab_, stride_b, stride_h, T_old, extra, b, kvh, split, n_splits, T_cap, chunk_keys);
   float M, L, O;
-  attn_split_finish<T, D, NW, FUSED, U>(st, tid, row + (int64_t)h * D, row + (int64_t)(n_heads + kvh) * D,
-                                        row + (int64_t)(n_heads + n_kv_heads + kvh) * D, cos_, sin_, n_pos, FUSED ? pos_base[b] : 0, scale,
-                                        h % n_rep == 0, T_cap, sm_m, sm_l, sm_o, M, L, O);
+  attn_split_finish<T, D, NW, FUSED, U, AttnNoWait, NP>(st, tid, row + (int64_t)h * D * esz, row + (int64_t)(n_heads + kvh) * D * esz,
+                                        row + (int64_t)(n_heads + n_kv_heads + kvh) * D * esz, cos_, sin_, n_pos, FUSED ? pos_base[b] : 0, scale,
+                                        h % n_rep == 0, T_cap, sm_m, sm_l, sm_o, M, L, O, AttnNoWait(), part_stride);
   if constexpr (INK) {
     extern __shared__ __attribute__((aligned(16))) float comb[];  // [n_splits][D + kAttnPartPad]: the layout attn_split_merge reads
     constexpr int PG = D + 2;                                      // granules of one partial: M, L, O[D]
@@ -187,11 +189,11 @@ static int64_t ink_resident_capacity(const void* kfn, int threads, size_t smem) 
   return cap;
 }
 
-template <typename T, int D, int NW, bool FUSED, int U>
+template <typename T, int D, int NW, bool FUSED, int U, int NP = 0>
 static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab, const void* v_slab, int64_t stride_b, int64_t stride_h,
                          const int32_t* kv_len, int extra, void* out, int64_t out_row_stride, void* workspace, int n_splits, int B,
                          int n_heads, int n_kv_heads, const void* cos_tab, const void* sin_tab, int n_pos, const int32_t* pos_base,
-                         int T_cap, int chunk_keys, hipStream_t st, int call_tag = -1) {
+                         int T_cap, int chunk_keys, hipStream_t st, int call_tag = -1, int64_t part_stride = 0) {
   const float scale = 1.0f / sqrtf((float)D);
   if constexpr (FUSED) {
     // in-kernel combine: only when every workgroup of the grid is certainly resident -- what THIS device (CU count of the current
@@ -199,18 +201,18 @@ static void launch_split(const void* q, int64_t q_row_stride, const void* k_slab
     // (occupancy is queried ONCE per kernel and device, with the merge buffer of the LARGEST split count the ABI accepts for this path: a later
     // launch with more splits than the first one must not inherit a capacity computed for a smaller LDS footprint -- it bounds a spin-wait)
     if (call_tag >= 0 && n_splits > 1 && n_splits <= 32 &&
-        (int64_t)n_splits * n_heads * B <= ink_resident_capacity((const void*)attn_decode_split_kernel<T, D, NW, true, U, true>, NW * 64,
+        (int64_t)n_splits * n_heads * B <= ink_resident_capacity((const void*)attn_decode_split_kernel<T, D, NW, true, U, true, NP>, NW * 64,
                                                                   (size_t)32 * (D + kAttnPartPad) * sizeof(float))) {
       const size_t smem = (size_t)n_splits * (D + kAttnPartPad) * sizeof(float);
-      hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, true, U, true>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64),
+      hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, true, U, true, NP>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64),
                          smem, st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,
-                         out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads, chunk_keys, call_tag);
+                         out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads, chunk_keys, call_tag, part_stride);
       return;
     }
   }
-  hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, FUSED, U>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64), 0,
+  hipLaunchKernelGGL((attn_decode_split_kernel<T, D, NW, FUSED, U, false, NP>), dim3((unsigned)n_splits, (unsigned)n_heads, (unsigned)B), dim3(NW * 64), 0,
                      st, q, q_row_stride, k_slab, v_slab, stride_b, stride_h, kv_len, extra, reinterpret_cast<float*>(workspace), out,
-                     out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads, chunk_keys);
+                     out_row_stride, n_heads / n_kv_heads, scale, cos_tab, sin_tab, n_pos, pos_base, T_cap, n_kv_heads, chunk_keys, 0, part_stride);
   if (n_splits > 1)
     hipLaunchKernelGGL((attn_decode_combine_kernel<T, D>), dim3((unsigned)n_heads, (unsigned)B), dim3(D), 0, st,
                        reinterpret_cast<const float*>(workspace), out, out_row_stride, n_splits);
@@ -248,11 +250,11 @@ extern "C" int dl_attn_decode(const void* q, int64_t q_row_stride, const void* k
   return DL_OK;
 }
 
-extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
-                                   const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
-                                   int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
-                                   int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
-                                   void* stream) {
+static int attn_decode_rope_impl(const void* qkv, int64_t qkv_row_stride, int n_parts, int64_t part_stride, const void* cos_tab, const void* sin_tab, int n_pos,
+                                 const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
+                                 int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
+                                 int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
+                                 void* stream) {
   DL_REQUIRE(keys_in_flight == 64 || keys_in_flight == 128 || keys_in_flight == 256, "dl_attn_decode_rope: keys_in_flight must be 64, 128 (eight waves) or 256");
   DL_REQUIRE(chunk_keys >= 0, "dl_attn_decode_rope: chunk_keys must be >= 0");
   DL_REQUIRE(qkv && cos_tab && sin_tab && pos_base && kv_len && k_slab && v_slab && out, "dl_attn_decode_rope: NULL pointer");
@@ -266,6 +268,26 @@ extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, cons
   // the in-kernel combine is built for the production shape only (U = 4); other variants keep the separate combine launch
   const int tag4 = (keys_in_flight == 64 && chunk_keys == 0) ? call_tag : -1;
 #define DL_FUSED_ARGS qkv, qkv_row_stride, k_slab, v_slab, slab_stride_b, slab_stride_h, kv_len, 1, out, out_row_stride, workspace, n_splits, B, n_heads, n_kv_heads, cos_tab, sin_tab, n_pos, pos_base, T_cap, chunk_keys, st
+  if (n_parts > 0) {  // fp32 partial sums of the projection's k ranges (16-bit cache types, the four-wave form): the range count is a template argument
+#define DL_PARTS_CASE(NP_)                                                                        \
+  case NP_:                                                                                       \
+    if (dtype == DL_BF16) {                                                                       \
+      if (head_dim == 128) launch_split<bf16_t, 128, 4, true, 4, NP_>(DL_FUSED_ARGS, tag4, part_stride); \
+      else launch_split<bf16_t, 64, 4, true, 4, NP_>(DL_FUSED_ARGS, tag4, part_stride);           \
+    } else {                                                                                      \
+      if (head_dim == 128) launch_split<f16_t, 128, 4, true, 4, NP_>(DL_FUSED_ARGS, tag4, part_stride);  \
+      else launch_split<f16_t, 64, 4, true, 4, NP_>(DL_FUSED_ARGS, tag4, part_stride);            \
+    }                                                                                             \
+    break
+    switch (n_parts) {
+      DL_PARTS_CASE(1);
+      DL_PARTS_CASE(2);
+      DL_PARTS_CASE(4);
+    }
+#undef DL_PARTS_CASE
+    DL_CHECK_LAUNCH("dl_attn_decode_rope_parts");
+    return DL_OK;
+  }
   DL_DISPATCH_DTYPE(dtype, T, {
     if (head_dim == 128) {
       if (keys_in_flight == 256) launch_split<T, 128, 4, true, 16>(DL_FUSED_ARGS);
@@ -280,4 +302,25 @@ extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, cons
 #undef DL_FUSED_ARGS
   DL_CHECK_LAUNCH("dl_attn_decode_rope");
   return DL_OK;
+}
+
+extern "C" int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
+                                   const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
+                                   int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
+                                   int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads, int n_kv_heads, int head_dim, int dtype,
+                                   void* stream) {
+  return attn_decode_rope_impl(qkv, qkv_row_stride, 0, 0, cos_tab, sin_tab, n_pos, pos_base, kv_len, k_slab, v_slab, slab_stride_b, slab_stride_h, T_cap, out, out_row_stride,
+                               workspace, n_splits, keys_in_flight, chunk_keys, call_tag, B, n_heads, n_kv_heads, head_dim, dtype, stream);
+}
+
+extern "C" int dl_attn_decode_rope_parts(const float* qkv_parts, int n_parts, int64_t part_stride, int64_t row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
+                                         const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab, int64_t slab_stride_b,
+                                         int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride, void* workspace, int n_splits,
+                                         int chunk_keys, int call_tag, int B, int n_heads, int n_kv_heads, int head_dim, int dtype, void* stream) {
+  DL_REQUIRE(dtype == DL_BF16 || dtype == DL_F16, "dl_attn_decode_rope_parts: bf16 / fp16 only (dtype %d): the partial sums are rounded to the cache's 16-bit type", dtype);
+  DL_REQUIRE(n_parts == 1 || n_parts == 2 || n_parts == 4, "dl_attn_decode_rope_parts: n_parts=%d must be 1, 2 or 4", n_parts);
+  DL_REQUIRE(((uintptr_t)qkv_parts & 15) == 0 && row_stride % 4 == 0 && part_stride % 4 == 0 && (n_parts == 1 || part_stride >= (int64_t)B * row_stride),
+             "dl_attn_decode_rope_parts: partial sums must be 16-byte aligned, the ranges at least B rows apart");
+  return attn_decode_rope_impl(qkv_parts, row_stride, n_parts, part_stride, cos_tab, sin_tab, n_pos, pos_base, kv_len, k_slab, v_slab, slab_stride_b, slab_stride_h, T_cap, out,
+                               out_row_stride, workspace, n_splits, 64, chunk_keys, call_tag, B, n_heads, n_kv_heads, head_dim, dtype, stream);
 }

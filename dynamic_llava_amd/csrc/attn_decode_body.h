@@ -309,6 +309,32 @@ __device__ __forceinline__ void attn_split_lds_merge(const AttnSplitState<T, D, 
   }
 }
 
+// A D-element row handed over either in the element type T (NP == 0) or as NP fp32 partial sums `part_stride` floats apart (dl_linear_packed's LP_EPI_PARTS
+// output: the projection's k ranges): added in range order and rounded to T once -- the value the projection's own store epilogue would have written.  NP is a
+// compile-time constant: straight-line code, every range's loads in flight together (a runtime loop or branch here makes hipcc wait for ALL outstanding loads
+// at the join -- the slab rows attn_split_issue requested before -- which cost the 1024-workgroup launch 2.7 us when it was tried).
+template <typename T, int NP>
+__device__ __forceinline__ void load16_row(const void* row_, int c, int64_t part_stride, float (&f)[Elem<T>::kVec]) {
+  if constexpr (NP == 0) {
+    load16<T>(reinterpret_cast<const typename Elem<T>::storage*>(row_) + c, f);
+  } else {
+    constexpr int V = Elem<T>::kVec;
+    const float* a = reinterpret_cast<const float*>(row_) + c;
+    float4 x[NP][V / 4];
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) x[r][i] = *reinterpret_cast<const float4*>(a + (int64_t)r * part_stride + 4 * i);
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) {
+      float4 t = x[0][i];
+#pragma unroll
+      for (int r = 1; r < NP; ++r) t.x += x[r][i].x, t.y += x[r][i].y, t.z += x[r][i].z, t.w += x[r][i].w;
+      f[4 * i] = Elem<T>::round(t.x), f[4 * i + 1] = Elem<T>::round(t.y), f[4 * i + 2] = Elem<T>::round(t.z), f[4 * i + 3] = Elem<T>::round(t.w);
+    }
+  }
+}
+
 // Part 2.  qrow / krow / vrow: the D-element q, k, v vectors of this head (un-rotated when FUSED; any address space).  cos_/sin_:
 // RoPE tables [n_pos, D]; pos: the new token's position.  sm_m/sm_l [NG], sm_o [NG][D]: LDS scratch of this (virtual) workgroup.
 // `write_kv`: this workgroup stores the new token's rotated key / value at slab slot T_old (one writer per kv head).
@@ -321,11 +347,11 @@ __device__ __forceinline__ void attn_split_lds_merge(const AttnSplitState<T, D, 
 struct AttnNoWait {
   __device__ __forceinline__ void operator()() const {}
 };
-template <typename T, int D, int NW, bool FUSED, int U, typename BeforeNew = AttnNoWait>
+template <typename T, int D, int NW, bool FUSED, int U, typename BeforeNew = AttnNoWait, int NP = 0>
 __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s, int vtid, const void* qrow_, const void* krow_,
                                                   const void* vrow_, const void* cos_, const void* sin_, int n_pos, int pos, float scale,
                                                   bool write_kv, int T_cap, float* sm_m, float* sm_l, float* sm_o, float& M_out, float& L_out,
-                                                  float& O_out, BeforeNew before_new = BeforeNew()) {
+                                                  float& O_out, BeforeNew before_new = BeforeNew(), int64_t part_stride = 0) {
   constexpr bool LATE = !__is_same(BeforeNew, AttnNoWait);
   using St = AttnSplitState<T, D, NW, U>;
   using S = typename St::S;
@@ -333,7 +359,6 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
   constexpr int HALF = D / 2;
   const int c = s.c, g = s.g, wid = s.wid, lane = s.lane;
   const int cpar = c < HALF ? c + HALF : c - HALF;
-  const S* qrow = reinterpret_cast<const S*>(qrow_);
   float qv[V], cs[V], sn[V];
   const bool owns_new = FUSED && s.T_old >= s.k0 && s.T_old < s.k1s && wid == 0 && g == 0;
   float kn[V], vn[V];
@@ -343,20 +368,19 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
     float own[V], par[V], kown[V], kpar[V];
     load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
     load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
-    load16<T>(qrow + c, own);
-    load16<T>(qrow + cpar, par);
+    load16_row<T, NP>(qrow_, c, part_stride, own);
+    load16_row<T, NP>(qrow_, cpar, part_stride, par);
     if (owns_new && !LATE) {
-      const S* krow = reinterpret_cast<const S*>(krow_);
-      load16<T>(krow + c, kown);
-      load16<T>(krow + cpar, kpar);
-      load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
+      load16_row<T, NP>(krow_, c, part_stride, kown);
+      load16_row<T, NP>(krow_, cpar, part_stride, kpar);
+      load16_row<T, NP>(vrow_, c, part_stride, vn);
     }
     if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
     if (owns_new && !LATE) {
       if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
     }
   } else {
-    load16<T>(qrow + c, qv);
+    load16<T>(reinterpret_cast<const S*>(qrow_) + c, qv);
   }
 
   float m, l, o[V];
@@ -366,10 +390,9 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
     before_new();
     if (owns_new) {
       float kown[V], kpar[V];
-      const S* krow = reinterpret_cast<const S*>(krow_);
-      load16<T>(krow + c, kown);
-      load16<T>(krow + cpar, kpar);
-      load16<T>(reinterpret_cast<const S*>(vrow_) + c, vn);
+      load16_row<T, NP>(krow_, c, part_stride, kown);
+      load16_row<T, NP>(krow_, cpar, part_stride, kpar);
+      load16_row<T, NP>(vrow_, c, part_stride, vn);
       if (c < HALF) rope16<T, false>(kown, kpar, cs, sn, kn); else rope16<T, true>(kown, kpar, cs, sn, kn);
     }
   }

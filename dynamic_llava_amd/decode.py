@@ -65,6 +65,7 @@ class _DecodeState:
             self.x_pk = torch.empty(n_el(H), dtype=dtype, device=device)
             self.act_pk = torch.empty(n_el(I), dtype=dtype, device=device)
             self.lp_parts = torch.empty(4 * B * H, dtype=torch.float32, device=device)
+            self.qkv_parts = torch.empty(2 * B * (nH + 2 * nKV) * d, dtype=torch.float32, device=device)  # q|k|v's two k ranges, added by the attention launch
         self.o_parts = torch.empty(8 * B * H, dtype=torch.float32, device=device) if (self.use_smallm and B <= 32 and getattr(l0, "wp_o", None) is not None) else None  # o_proj's k-range slices (dl_linear_tiles)
         self.graphs = {}  # captured decode steps, keyed by (slab, split factors, ...): see _run_decode_steps
         # dl_gemv_gu_tp's granules (batch 1; the predictor's stage 1 stages the row in LDS: H <= 5120)
@@ -190,21 +191,32 @@ class DecodeScheduler:
         sm, ws = st.use_smallm, st.lin_ws
         torch.index_select(self.model.embed_tokens.weight, 0, st.cur_ids, out=st.h)
         lp_qkv = st.use_lp_mlp and st.B >= self.packed_decode_qkv_min_batch and getattr(self.model.layers[0], "wp_qkv", None) is not None
+        qkv_parts = False
         if lp_qkv:
             nu_q, ks_q = self._lp_config(st.qkv.shape[1] // 16, False)
+            qkv_parts = self.packed_decode_qkv_parts and st.B <= self.packed_decode_qkv_parts_max_batch and ks_q == 2 and self.dtype in (torch.bfloat16, torch.float16)
         ops.rmsnorm(st.h, self.model.layers[0].input_layernorm.weight, eps, out=st.x_pk if lp_qkv else st.x, packed=lp_qkv)
         for i, layer in enumerate(self.model.layers):
             if i == SL and use_tp:  # F6: decision on the hidden state entering layer SL (DML:2377-2391)
                 self.model.output_text_score_predictor.decide(st.h, st.tp_ws, st.tp_logits, st.decision)
             lens = cache.len_of_layer(i)
-            if lp_qkv:
-                qkv = ops.linear_packed(st.x_pk, layer.wp_qkv, st.qkv.shape[1], out=st.qkv, units_per_workgroup=nu_q, k_split=ks_q, workspace=self._lp_ws if ks_q > 1 else None, err=self._lp_err,
-                                        x_packed_mk=(st.B, st.h.shape[1]))
-            else:
-                qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws, n_slices=self.smallm_wide_slices) if sm else F.linear(st.x, layer.w_qkv)
             ns = cache.n_splits(i, st.B * nH)
-            ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
-                                 call_tag=(i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1)
+            tag = (i & 0xff) if self.attn_inkernel_combine and L >= 2 else -1
+            if lp_qkv and qkv_parts and cache.keys_in_flight(ns, st.B * nH) == 64:
+                # round 6 (verdict r5 item 2c): the projection's two k ranges stay fp32 partial sums and the RoPE / append / attention launch adds them (each (row, head)
+                # workgroup the 3 x head_dim values it reads): no hand-over inside the projection's launch.  In the step (profiles/r06_decode_qkv_parts.txt): the
+                # projection 22.7 -> 20.5 us at 32 rows, but the 1024-workgroup attention launch 24.3 -> 28.2 -- a win only while that launch is small: -1.5 % per
+                # step at 16 rows, a tie at 24, +0.7..1.6 % at 32 => up to packed_decode_qkv_parts_max_batch (20) rows
+                parts_q = ops.linear_packed(st.x_pk, layer.wp_qkv, st.qkv.shape[1], out=st.qkv_parts, epilogue=ops.LP_PARTS, units_per_workgroup=nu_q, k_split=ks_q, x_packed_mk=(st.B, st.h.shape[1]))
+                ops.attn_decode_rope_parts(parts_q, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, chunk_keys=cache.spec_chunk(ns), call_tag=tag)
+            else:
+                if lp_qkv:
+                    qkv = ops.linear_packed(st.x_pk, layer.wp_qkv, st.qkv.shape[1], out=st.qkv, units_per_workgroup=nu_q, k_split=ks_q, workspace=self._lp_ws if ks_q > 1 else None, err=self._lp_err,
+                                            x_packed_mk=(st.B, st.h.shape[1]))
+                else:
+                    qkv = ops.gemm_smallm(st.x, layer.w_qkv, out=st.qkv, workspace=ws, n_slices=self.smallm_wide_slices) if sm else F.linear(st.x, layer.w_qkv)
+                ops.attn_decode_rope(qkv, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, keys_in_flight=cache.keys_in_flight(ns, st.B * nH), chunk_keys=cache.spec_chunk(ns),
+                                     call_tag=tag)
             nw = self.model.norm.weight if i + 1 == L else self.model.layers[i + 1].input_layernorm.weight
             lp = st.use_lp_mlp
             x_mlp = st.x_pk if lp else st.x  # the packed MLP reads its input in fragment order: the norm launch writes it that way
@@ -316,7 +328,7 @@ class DecodeScheduler:
         fused_ns = (cache.fused_attn_splits(0, self.fused_attn_max_splits), cache.fused_attn_splits(cfg.num_hidden_layers - 1, self.fused_attn_max_splits)) if (st.B == 1 and st.qa_gran is not None) else (1, 1)
         key = (cache.slab.data_ptr(), cache.t_cap, splits, fused_ns, self._rope[0].data_ptr(), self._eos, self._pad, getattr(self, "_min_new", 0),
                repr(cfg.sparse_config), self.attn_inkernel_combine, self.tp_side_stream, self.smallm_max_decode_batch, self.gemv_max_decode_batch, self.fuse_qkv_attn, self.fuse_gu_tp, KVSlabCache.eight_wave_single_split,
-               self.fused_attn_max_splits, self.qkv_attn_grid_cap, self.gu_grid_cap, self.packed_decode_qkv_min_batch)
+               self.fused_attn_max_splits, self.qkv_attn_grid_cap, self.gu_grid_cap, self.packed_decode_qkv_min_batch, self.packed_decode_qkv_parts, self.packed_decode_qkv_parts_max_batch)
         if not self.use_hip_graph:
             for _ in range(n_steps):
                 self._decode_step_kernels(st, cache, True)

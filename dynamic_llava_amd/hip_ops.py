@@ -74,6 +74,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
+    "dl_attn_decode_rope_parts": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    ),
     "dl_topk_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dl_compact_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     "dl_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -344,6 +348,24 @@ def attn_decode_rope(qkv, cos, sin, pos_base, kv_len, k_slab, v_slab, out, works
             k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), int(keys_in_flight), int(chunk_keys), int(call_tag), B, n_heads, n_kv_heads, head_dim, dtype_code(qkv.dtype), _stream(),
         ),
         "dl_attn_decode_rope",
+    )
+    return out
+
+
+def attn_decode_rope_parts(qkv_parts, cos, sin, pos_base, kv_len, k_slab, v_slab, out, workspace, n_splits, n_heads, n_kv_heads, head_dim, chunk_keys=0, call_tag=-1):
+    """attn_decode_rope on the projection's fp32 partial sums qkv_parts [n_parts, B, (nH+2nKV)*d] (linear_packed(..., epilogue=LP_PARTS)): added in range order and
+    rounded to out.dtype inside the launch."""
+    _dev(qkv_parts, cos, sin, pos_base, kv_len, k_slab, v_slab, out)
+    assert qkv_parts.dtype == torch.float32 and qkv_parts.dim() == 3 and qkv_parts.stride(2) == 1 and out.stride(1) == 1
+    assert kv_len.dtype == torch.int32 and pos_base.dtype == torch.int32 and cos.dtype == out.dtype == k_slab.dtype
+    assert k_slab.stride(3) == 1 and k_slab.stride(2) == head_dim and k_slab.stride() == v_slab.stride()
+    n_parts, B = qkv_parts.shape[0], qkv_parts.shape[1]
+    _check(
+        lib().dl_attn_decode_rope_parts(
+            _p(qkv_parts), n_parts, qkv_parts.stride(0), qkv_parts.stride(1), _p(cos), _p(sin), cos.shape[0], _p(pos_base), _p(kv_len), _p(k_slab), _p(v_slab), k_slab.stride(0),
+            k_slab.stride(1), k_slab.shape[2], _p(out), out.stride(0), _p(workspace), int(n_splits), int(chunk_keys), int(call_tag), B, n_heads, n_kv_heads, head_dim, dtype_code(out.dtype), _stream(),
+        ),
+        "dl_attn_decode_rope_parts",
     )
     return out
 

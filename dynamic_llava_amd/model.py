@@ -94,6 +94,8 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
         # batched decode (4..32 rows), tools/bench_decode_batch.py: the MLP on dl_linear_packed from 4 rows on (B = 16: 4.05 -> 3.79 ms per step, 24: 4.63 -> 4.03), q|k|v too from 16 rows
         # on (24: 4.05 -> 3.97, 32: 4.21 -> 4.11); o_proj stays on dl_gemm_smallm's partial sums up to 32 rows (against the library GEMM + add: 32 rows 4.20 -> 4.11)
         self.packed_decode_qkv_min_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_MIN_B", "16"))
+        self.packed_decode_qkv_parts = os.environ.get("DL_PACKED_DECODE_QKV_PARTS", "1") != "0"  # ... as fp32 partial sums of its two k ranges, added by dl_attn_decode_rope_parts
+        self.packed_decode_qkv_parts_max_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_PARTS_MAX_B", "20"))  # (tools/bench_decode_qkv_parts.py: -1.5 % per step at 16 rows, +1 % at 32)
         self.packed_decode_mlp_min_batch = int(os.environ.get("DL_PACKED_DECODE_MLP_MIN_B", "4"))
         self.packed_qkv_parts = os.environ.get("DL_PACKED_QKV_PARTS", "1") == "1"  # prefill q|k|v: partial sums added by the RoPE / KV-append launch instead of the in-launch hand-over
         self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 4..32: gate|up + SiLU * up and down_proj on dl_linear_packed
@@ -281,7 +283,7 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
             "use_hip_graph": self.use_hip_graph, "attn_inkernel_combine": self.attn_inkernel_combine, "device_prompt_layout": self.device_prompt_layout,
             "tp_side_stream": self.tp_side_stream, "gemv_max_decode_batch": self.gemv_max_decode_batch, "smallm_max_decode_batch": self.smallm_max_decode_batch,
             "fuse_qkv_attn": self.fuse_qkv_attn, "fuse_gu_tp": self.fuse_gu_tp, "fused_attn_max_splits": self.fused_attn_max_splits, "gu_grid_cap": self.gu_grid_cap,
-            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_qkv_parts": self.packed_qkv_parts, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch,
+            "qkv_attn_grid_cap": self.qkv_attn_grid_cap, "splitk_o_proj": self.splitk_o_proj, "packed_prefill_gemm": self.packed_prefill_gemm, "packed_down_proj": self.packed_down_proj, "packed_qkv_parts": self.packed_qkv_parts, "packed_decode_mlp": self.packed_decode_mlp, "packed_decode_mlp_min_batch": self.packed_decode_mlp_min_batch, "packed_decode_qkv_min_batch": self.packed_decode_qkv_min_batch, "packed_decode_qkv_parts": self.packed_decode_qkv_parts, "packed_decode_qkv_parts_max_batch": self.packed_decode_qkv_parts_max_batch,
             "smallm_wide_slices": self.smallm_wide_slices, "decode_sync_every": self.decode_sync_every, "prefill_width_bucket": self.prefill_width_bucket,
             "max_prefill_graphs": self.max_prefill_graphs,
             "tiles_o_proj": self.tiles_o_proj, "tiles_o_proj_min_decode_batch": self.tiles_o_proj_min_decode_batch,

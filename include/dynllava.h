@@ -133,6 +133,17 @@ int dl_attn_decode_rope(const void* qkv, int64_t qkv_row_stride, const void* cos
                         void* workspace, int n_splits, int keys_in_flight, int chunk_keys, int call_tag, int B, int n_heads,
                         int n_kv_heads, int head_dim, int dtype, void* stream);
 
+/* The same launch fed by the q|k|v projection's fp32 PARTIAL SUMS (dl_linear_packed with DL_LP_PARTS: one [B, row_stride] slice per k range, `part_stride` floats
+ * apart) instead of its rounded output: every (row, head) workgroup adds the n_parts (1, 2 or 4) ranges of the 3 x head_dim values it reads in range order and rounds once to
+ * `dtype` -- the value the projection's store epilogue would have written -- before RoPE (DML:260-285) / append (CU:109-268).  Decode batches of 16..32 rows: the
+ * projection's two k ranges then need no hand-over inside its launch (22.2 -> 19.7 us at 32 rows x [12288, 4096]).  bf16 / fp16; 64 keys in flight (the form
+ * batched decode steps use); everything else as dl_attn_decode_rope. */
+int dl_attn_decode_rope_parts(const float* qkv_parts, int n_parts, int64_t part_stride, int64_t row_stride, const void* cos_tab, const void* sin_tab, int n_pos,
+                              const int32_t* pos_base, const int32_t* kv_len, void* k_slab, void* v_slab,
+                              int64_t slab_stride_b, int64_t slab_stride_h, int T_cap, void* out, int64_t out_row_stride,
+                              void* workspace, int n_splits, int chunk_keys, int call_tag, int B, int n_heads,
+                              int n_kv_heads, int head_dim, int dtype, void* stream);
+
 /* ---- F2: top-k select, DML:1867 + 1898-1908.  score [B,n] in the model dtype (= log_softmax(...)[:,:,0]);
  * keep_idx [B,k] int64 ascending = the k largest scores; ties: the LOWER original index wins
  * (= stable descending sort; the reference's argsort is non-stable).  n <= 4096. */

@@ -252,10 +252,10 @@ def test_c5_13b_width_long_decode_with_eviction():
               f"(steps {sorted(hip_logits)[:10]}..., worst err / bound {worst:.3f}), boundary decisions forced: {forced}, kept {sum(dec)} of {n_check}")
 
 
-@pytest.mark.parametrize("B,width", [(4, "7b"), (7, "7b"), (16, "7b"), (20, "7b"), (24, "7b"), (28, "7b"), (32, "7b"), (12, "13b"), (32, "13b")])
+@pytest.mark.parametrize("B,width", [(4, "7b"), (7, "7b"), (16, "7b"), (20, "7b"), (24, "7b"), (28, "7b"), (32, "7b"), (12, "13b"), (16, "13b"), (32, "13b")])
 def test_mid_batch_decode_smallm_rows_equal_b1(B, width):
     """Decode batches 4..32 run q|k|v (up to 15 rows) and o_proj on dl_gemm_smallm (+ partial-sum consumers), the MLP -- and q|k|v from 16 rows on -- on
-    dl_linear_packed.  Every row of a ragged batch must match its own B=1 run
+    dl_linear_packed (16..20 rows: as fp32 partial sums of its two k ranges, added by dl_attn_decode_rope_parts -- round 6).  Every row of a ragged batch must match its own B=1 run
     (dl_gemv path): greedy tokens and per-step eviction decisions away from decision boundaries, logits in the same noise class."""
     dtype = torch.bfloat16
     cfg = fx.llava7b_config(num_hidden_layers=3) if width == "7b" else fx.llava13b_config(num_hidden_layers=3)  # 13B: 8 units per workgroup, down_proj in 3 units x 2 k ranges

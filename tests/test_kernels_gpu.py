@@ -394,6 +394,61 @@ def test_attn_decode_rope_fused_equals_unfused(ops, dtype, nH, nKV, d, n_splits,
             assert torch.equal(kc.nan_to_num(7.0), kb.nan_to_num(7.0)) and torch.equal(vc.nan_to_num(7.0), vb.nan_to_num(7.0))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nH,nKV,d", [(32, 32, 128), (8, 2, 128), (4, 4, 64)])
+@pytest.mark.parametrize("n_parts,n_splits,tag", [(2, 1, -1), (2, 3, -1), (2, 3, 5), (1, 1, -1), (4, 2, 3)])
+def test_attn_decode_rope_parts_equals_rounded_sum(ops, dtype, nH, nKV, d, n_parts, n_splits, tag):
+    """dl_attn_decode_rope_parts (q|k|v handed over as the projection's fp32 k-range partial sums, round 6) == dl_attn_decode_rope on the sum of the ranges,
+    added in range order and rounded once to the cache dtype: output and slab contents bit-identical, for one split, several splits with the separate merge
+    launch and with the in-kernel merge.  The ranges live `part_stride` > B rows apart (the decode state's buffer is sized for two ranges of B rows)."""
+    g = torch.Generator().manual_seed(23)
+    kv_len = [0, 16, 170, 631, 65, 1023, 300]
+    B, T_cap = len(kv_len), 1100
+    pos = [5, 40, 631, 700, 65, 2000, 301]
+    N = (nH + 2 * nKV) * d
+    k0 = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    v0 = torch.randn(B, nKV, T_cap, d, generator=g).to(dtype)
+    for b, T in enumerate(kv_len):
+        k0[b, :, T:] = float("nan")
+        v0[b, :, T:] = float("nan")
+    buf = torch.full((n_parts, B + 3, N), float("nan"))  # rows past B: never read
+    buf[:, :B] = torch.randn(n_parts, B, N, generator=g) / math.sqrt(n_parts)
+    total = buf[0, :B].clone()
+    for r in range(1, n_parts):
+        total = total + buf[r, :B]  # fp32, range order
+    qkv = total.to(dtype)
+    cos, sin = orc.rope_table(d, 2048, 10000.0, dtype)
+    lens = torch.tensor(kv_len, dtype=torch.int32).cuda()
+    posd = torch.tensor(pos, dtype=torch.int32).cuda()
+    ws = ops.attn_decode_workspace(B, nH, d, 8, "cuda")
+    ka, va = k0.cuda().clone(), v0.cuda().clone()
+    out_a = torch.full((B, nH * d), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_decode_rope(qkv.cuda(), cos.cuda(), sin.cuda(), posd, lens, ka, va, out_a, ws, n_splits, nH, nKV, d, call_tag=tag)
+    kb, vb = k0.cuda().clone(), v0.cuda().clone()
+    out_b = torch.full((B, nH * d), float("nan"), dtype=dtype, device="cuda")
+    parts = buf.cuda()[:, :B]  # [n_parts, B, N] view: stride(0) = (B + 3) N
+    if tag >= 0:
+        ws.zero_()
+    ops.attn_decode_rope_parts(parts, cos.cuda(), sin.cuda(), posd, lens, kb, vb, out_b, ws, n_splits, nH, nKV, d, call_tag=tag)
+    assert torch.isfinite(out_b.float()).all()
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(ka.nan_to_num(7.0), kb.nan_to_num(7.0)) and torch.equal(va.nan_to_num(7.0), vb.nan_to_num(7.0))
+
+
+def test_attn_decode_rope_parts_bad_args(ops):
+    d, nH = 128, 4
+    cos, sin = orc.rope_table(d, 64, 10000.0, torch.bfloat16)
+    lens = torch.zeros(2, dtype=torch.int32, device="cuda")
+    k = torch.zeros(2, nH, 8, d, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(2, nH * d, dtype=torch.bfloat16, device="cuda")
+    parts = torch.zeros(3, 2, 3 * nH * d, device="cuda")
+    with pytest.raises(ops.HipOpsError, match="n_parts"):
+        ops.attn_decode_rope_parts(parts, cos.cuda(), sin.cuda(), lens, lens, k, k.clone(), out, None, 1, nH, nH, d)
+    c32, s32 = orc.rope_table(d, 64, 10000.0, torch.float32)
+    with pytest.raises(ops.HipOpsError, match="bf16 / fp16"):
+        ops.attn_decode_rope_parts(parts[:2], c32.cuda(), s32.cuda(), lens, lens, k.float(), k.float(), out.float(), None, 1, nH, nH, d)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(576, 512, 4096), (36, 128, 256), (100, 1536, 512), (70, 32, 64), (1, 2048, 512)])
 @pytest.mark.parametrize("flags", [0, 1, 2, 3])
