@@ -369,11 +369,18 @@ __device__ __forceinline__ void attn_split_finish(AttnSplitState<T, D, NW, U>& s
     load16<T>(reinterpret_cast<const S*>(cos_) + (int64_t)p * D + (c % HALF), cs);  // table = cat(freqs, freqs)
     load16<T>(reinterpret_cast<const S*>(sin_) + (int64_t)p * D + (c % HALF), sn);
     load16_row<T, NP>(qrow_, c, part_stride, own);
-    load16_row<T, NP>(qrow_, cpar, part_stride, par);
     if (owns_new && !LATE) {
       load16_row<T, NP>(krow_, c, part_stride, kown);
-      load16_row<T, NP>(krow_, cpar, part_stride, kpar);
+      if constexpr (NP == 0) load16_row<T, NP>(krow_, cpar, part_stride, kpar);
       load16_row<T, NP>(vrow_, c, part_stride, vn);
+    }
+    // q's RoPE partner half (column c +- D/2) is what the lane LPK / 2 lanes away in this lane group (LPK = D / kVec lanes share a row) has just loaded (partial sums: summed and rounded): take it
+    // from there instead of requesting it a second time -- half the requests in front of the first score (round 6: 1024-workgroup launches, 32 rows)
+#pragma unroll
+    for (int i = 0; i < V; ++i) par[i] = __shfl_xor(own[i], LPK / 2);
+    if constexpr (NP > 0 && !LATE) {  // the new key's partner half the same way (every lane takes part in the exchange; only the owning lane group's values are used)
+#pragma unroll
+      for (int i = 0; i < V; ++i) kpar[i] = __shfl_xor(owns_new ? kown[i] : 0.f, LPK / 2);
     }
     if (c < HALF) rope16<T, false>(own, par, cs, sn, qv); else rope16<T, true>(own, par, cs, sn, qv);
     if (owns_new && !LATE) {
