@@ -62,7 +62,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
   // batch is in (a batch of 32 requests with 200..900 keys otherwise ends with a few CUs finishing their 900-key rows alone).  Every wave ranks the <= 64
   // lengths itself (B readlanes); which slice computes a row does not change a bit of the result.
   int b = blockIdx.z;
-  if (gridDim.z > 1 && gridDim.z <= 64) {
+  int T_ranked = -1;  // the chosen row's length, when the ranking below has it in a register already (saves the dependent kv_len[b] load: one memory round trip
+  if (gridDim.z > 1 && gridDim.z <= 64) {  // in front of the first K/V request of every workgroup)
     const int lane = tid & 63, Bn = (int)gridDim.z;
     const int my = lane < Bn ? kv_len[lane] : -1;
     int rank = 0;
@@ -72,12 +73,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_split_kernel(
     }
     const unsigned long long m = __ballot(lane < Bn && rank == (int)blockIdx.z);
     b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+    T_ranked = __builtin_amdgcn_readlane(my, b);
   }
   const int kvh = h / n_rep;
   // the new token's q|k|v row: elements of T, or (dl_attn_decode_rope_parts) the fp32 partial sums of the projection's k ranges
   constexpr int64_t esz = NP > 0 ? 4 : (int64_t)sizeof(S);
   const char* row = reinterpret_cast<const char*>(q_) + (int64_t)b * q_row_stride * esz;
-  const int T_old = kv_len[b];
+  const int T_old = T_ranked >= 0 ? T_ranked : kv_len[b];
   St st;
   attn_split_issue<T, D, NW, FUSED, U>(st, tid, k_slab_, v_slab_, stride_b, stride_h, T_old, extra, b, kvh, split, n_splits, T_cap, chunk_keys);
   float M, L, O;
