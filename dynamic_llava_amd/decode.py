@@ -206,7 +206,8 @@ class DecodeScheduler:
                 # round 6 (verdict r5 item 2c): the projection's two k ranges stay fp32 partial sums and the RoPE / append / attention launch adds them (each (row, head)
                 # workgroup the 3 x head_dim values it reads): no hand-over inside the projection's launch.  In the step (profiles/r06_decode_qkv_parts.txt): the
                 # projection 22.7 -> 20.5 us at 32 rows; the attention launch pays for the wider loads in front of its first score (24.3 -> 28.2 us in the first build,
-                # most of it removed by taking q's RoPE partner half from the neighbouring lane instead of loading it): -2.2 % per step at 16 rows, -1.8 % at 24, -0.5 % at 32
+                # most of it removed by taking q's RoPE partner half from the neighbouring lane instead of loading it): -2.2 % per step at 16 rows, -1.8 % at 24; at 32 rows
+                # -0.6 % on equal prompts, +0.5 % on configs[2]'s ragged batch => up to packed_decode_qkv_parts_max_batch (24) rows
                 parts_q = ops.linear_packed(st.x_pk, layer.wp_qkv, st.qkv.shape[1], out=st.qkv_parts, epilogue=ops.LP_PARTS, units_per_workgroup=nu_q, k_split=ks_q, x_packed_mk=(st.B, st.h.shape[1]))
                 ops.attn_decode_rope_parts(parts_q, cos, sin, cache.len_full, lens, cache.k[i], cache.v[i], st.attn, st.attn_ws, ns, nH, nKV, d, chunk_keys=cache.spec_chunk(ns), call_tag=tag)
             else:

@@ -95,7 +95,7 @@ class DynamicLlavaLlamaForCausalLM(PrefillEngine, DecodeScheduler, nn.Module):
         # on (24: 4.05 -> 3.97, 32: 4.21 -> 4.11); o_proj stays on dl_gemm_smallm's partial sums up to 32 rows (against the library GEMM + add: 32 rows 4.20 -> 4.11)
         self.packed_decode_qkv_min_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_MIN_B", "16"))
         self.packed_decode_qkv_parts = os.environ.get("DL_PACKED_DECODE_QKV_PARTS", "1") != "0"  # ... as fp32 partial sums of its two k ranges, added by dl_attn_decode_rope_parts
-        self.packed_decode_qkv_parts_max_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_PARTS_MAX_B", "32"))  # (tools/bench_decode_qkv_parts.py: -2.2 % per step at 16 rows, -1.8 % at 24, -0.5 % at 32)
+        self.packed_decode_qkv_parts_max_batch = int(os.environ.get("DL_PACKED_DECODE_QKV_PARTS_MAX_B", "24"))  # (tools/bench_decode_qkv_parts.py: -2.2 % per step at 16 rows, -1.8 % at 24; at 32 rows -0.6 % on equal prompts but +0.5 % on configs[2]'s ragged batch)
         self.packed_decode_mlp_min_batch = int(os.environ.get("DL_PACKED_DECODE_MLP_MIN_B", "4"))
         self.packed_qkv_parts = os.environ.get("DL_PACKED_QKV_PARTS", "1") == "1"  # prefill q|k|v: partial sums added by the RoPE / KV-append launch instead of the in-launch hand-over
         self.packed_decode_mlp = os.environ.get("DL_PACKED_DECODE_MLP", "1") == "1"  # decode batches 4..32: gate|up + SiLU * up and down_proj on dl_linear_packed
