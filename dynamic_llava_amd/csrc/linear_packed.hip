@@ -33,7 +33,7 @@
 // -DDL_LP_ABLATIONS (measurement builds only: HIPCC_EXTRA=-DDL_LP_ABLATIONS python -m dynamic_llava_amd.build_ext --force) also builds the ablated variants that
 // tools/bench_linear_packed.py --ablate times (no MFMA / no X loads / loaders alone); the product library does not contain them.
 
-#include "dl_common.h"
+#include "act_round.h"
 
 namespace dl {
 
@@ -355,12 +355,12 @@ __global__ __launch_bounds__(kLpThreads) void linear_packed_kernel(const LpParam
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float g = Elem<T>::round(acc[i][j][r]), u = Elem<T>::round(acc[i + 1][j][r]);
-          const float sg = Elem<T>::round(g / (1.0f + expf(-g)));  // dl_silu_mul's two roundings (DML:328)
+          const float g = hw_round<T>(acc[i][j][r]), u = hw_round<T>(acc[i + 1][j][r]);
+          const float sg = silu_rounded<T>(g);  // dl_silu_mul's two roundings (DML:328), the bits of its exact expression (act_round.h)
           o[r] = sg * u;
         }
-        const uint32_t lo = (uint32_t)Elem<T>::from_f(o[0]) | ((uint32_t)Elem<T>::from_f(o[1]) << 16);
-        const uint32_t hi = (uint32_t)Elem<T>::from_f(o[2]) | ((uint32_t)Elem<T>::from_f(o[3]) << 16);
+        const uint32_t lo = hw_pack2<T>(o[0], o[1]);
+        const uint32_t hi = hw_pack2<T>(o[2], o[3]);
         const int col = ((u0 + i) >> 1) * 16 + lg * 4;
         S_* dst = p.y_packed ? Y + lp_x_chunk_offset(row, col >> 3, kLpConsumers * TPW) + (col & 7) : Y + (int64_t)row * p.ldy + col;
         *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256) void pack_weight_tiles_kernel(const uint16_t* 
 template <typename T, int NU, int TPW, int EPI, int ABL>
 static int lp_launch(const LpParams& p, int rd, hipStream_t st) {
   // ring depth: (RD - 3) NU pieces per loader must fit the 6-bit vmcnt, RD NU 2 KiB the LDS; 50-60 KiB in flight per CU cover HBM's latency at 25 GB/s per CU
-  constexpr int RD = NU == 1 ? 24 : NU == 2 ? 16 : NU == 3 ? 12 : NU == 4 ? 10 : 8;
-  constexpr int DX = TPW >= 4 ? 2 : 3;
+  constexpr int RD = NU == 1 ? 24 : NU == 2 ? 16 : NU == 3 ? 12 : NU == 4 ? 10 : NU == 12 ? 6 : 8;
+  constexpr int DX = (TPW >= 4 || NU >= 12) ? 2 : 3;
   static_assert((RD - 3) * NU <= 63 && RD * NU * 2 <= 152, "ring too deep for vmcnt / LDS");
   (void)rd;
   auto kfn = linear_packed_kernel<T, NU, TPW, RD, DX, EPI, ABL>;
@@ -479,6 +479,12 @@ static int lp_nu(const LpParams& p, int nu, int epilogue, hipStream_t st) {
       case 4: return lp_tpw<T, 4, ABL>(p, epilogue, st);
       case 6: return lp_tpw<T, 6, ABL>(p, epilogue, st);
       case 8: return lp_tpw<T, 8, ABL>(p, epilogue, st);
+#ifdef DL_LP_MEASURE_12U  // round 6 experiment (verdict r5 item 5; HIPCC_EXTRA=-DDL_LP_MEASURE_12U, tools/bench_gate_up_12units.py): gate|up at 129..192 rows as 12 units
+      case 12:              // x 2 k ranges of partial sums for dl_silu_mul_parts -- 58.4 us + 8.7 against the shipped launch's 55.3 (profiles/r06_gate_up_12units.txt)
+        if (epilogue == LP_EPI_PARTS && (p.M + 15) / 16 > 2 * kLpConsumers && (p.M + 15) / 16 <= 3 * kLpConsumers) return lp_launch<T, 12, 3, LP_EPI_PARTS, 0>(p, 0, st);
+        set_error("dl_linear_packed: 12 units per workgroup are built for partial sums at 129..192 rows only");
+        return DL_ERR_ARG;
+#endif
     }
   }
   set_error("dl_linear_packed: units_per_workgroup=%d is not built", nu);

@@ -952,14 +952,17 @@ def test_linear_packed_vs_fp32_every_layout(ops, dtype, M, N, K, nu, ks):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,H,I,ks", [(170, 4096, 11008, 1), (117, 1024, 2816, 2), (32, 512, 1536, 1), (192, 5120, 13824, 1)])
-def test_linear_packed_epilogues_bit_equal_the_separate_launches(ops, dtype, M, H, I, ks):
+@pytest.mark.parametrize("M,H,I,ks,scale", [(170, 4096, 11008, 1, 1.0), (117, 1024, 2816, 2, 1.0), (32, 512, 1536, 1, 1.0), (192, 5120, 13824, 1, 1.0), (170, 512, 2816, 1, 6.0), (64, 256, 1536, 1, 40.0),
+                                            (48, 256, 1536, 1, 0.01)])
+def test_linear_packed_epilogues_bit_equal_the_separate_launches(ops, dtype, M, H, I, ks, scale):
     """SiLU(gate) * up on the gate / up interleaved packing == dl_silu_mul applied to the ROUNDED plain output of the same kernel (DML:328: the
     projection is rounded, silu is rounded, the product is rounded); residual epilogue == rounded output added to the residual by torch
-    (DML:1289 / 1295)."""
+    (DML:1289 / 1295).  Round 6: the epilogue evaluates silu with v_exp_f32 / v_rcp_f32 and takes the exact expression only near a rounding boundary of the
+    16-bit type (csrc/act_round.h) -- `scale` spreads the gate values over the saturating (x 6, x 40: |gate| up to ~150) and the tiny (x 0.01: fp16-subnormal
+    results) ranges, every element still bit-equal to dl_silu_mul's exact expression."""
     g = torch.Generator().manual_seed(6)
     x = torch.randn(M, H, generator=g).to(dtype).cuda()
-    w_gu = (torch.randn(2 * I, H, generator=g) / math.sqrt(H)).to(dtype).cuda()
+    w_gu = (scale * torch.randn(2 * I, H, generator=g) / math.sqrt(H)).to(dtype).cuda()
     cands = [ops.linear_packed_workspace(M, 2 * I, H, "cuda", e, 0, ks) for e in (ops.LP_SILU_PAIR, ops.LP_STORE)]  # (the chosen units per workgroup differ)
     ws = max((c for c in cands if c is not None), key=lambda c: c.numel(), default=None)
     plain = ops.linear_packed(x, ops.pack_weight_tiles(w_gu), 2 * I, k_split=ks, workspace=ws)  # same k order -> same fp32 sums whatever the unit order
