@@ -924,6 +924,208 @@ __global__ __launch_bounds__(256 * KW) void attn_prefill_whole_d64_kernel(const 
   DL_PSTAMP(7);
 }
 
+// ---- whole-head variant for head_dim 128, causal, 65..256 rows (late round 6): the decoder's post-compaction layers of a BATCHED prefill (configs[2] / [3]: 32 requests
+// x 32 heads x 158..214 rows, DML:1061-1122).  The plain kernel walks such a launch as 6144 small workgroups at 3.6 % MFMA-busy (143 us per layer,
+// profiles/r06_configs2_prefill_mfma_util.txt).  Here ONE workgroup owns a (request, head): all of its keys are staged once -- K by LDS-DMA, V transposed through
+// registers, both in matrix-core fragment order as in the head_dim-64 kernel above (64 + 64 KiB) -- and its eight waves take the 16-row query tiles, heaviest first
+// (tile n - 1 - w, then tile w - the causal triangle pairs a long tile with a short one), each wave running the in-register online softmax over the chunks at or below its
+// tile's diagonal.  No key ranges to merge, one barrier (after staging).  Same products and roundings as the head_dim-64 kernel: S^T = K Q^T, O^T = V^T P^T with P^T
+// taken straight from the S^T accumulators, scores in units of log2 e, P rounded by the hardware's RNE.
+template <typename T>
+__global__ __launch_bounds__(512) void attn_prefill_whole_d128_causal_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_, int64_t q_rs,
+                                                                             int64_t kv_rs, void* __restrict__ out_, int64_t out_rs, const int32_t* __restrict__ cu, int n_rep,
+                                                                             float scale) {
+  using S = uint16_t;
+  constexpr int D = 128, KT = 16, KC = 8, NWV = 8, NT_ = 64 * NWV;  // up to 256 keys
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  typedef __attribute__((address_space(1))) void glob_v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S* Kf = reinterpret_cast<S*>(smem);  // [key tile][dims quarter][64 lanes][8]
+  S* Vf = Kf + KT * 4 * 512;           // [dim tile][32-key chunk][64 lanes][8]
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  if (L <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kvh = h / n_rep;
+  const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
+  const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const int n_kc = (L + 31) >> 5;  // 32-key chunks; keys past L are staged as copies of key L - 1 and masked (they lie above every diagonal anyway)
+  const int n_qt = (L + 15) >> 4;
+  // ---- K: one DMA piece per (key tile, dims quarter) ----
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)smem;
+    for (int kt = w; kt < n_kc * 2; kt += NWV) {
+      int key = kt * 16 + lr;
+      key = key < L ? key : L - 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t voff = (uint32_t)key * (uint32_t)kv_rs * 2u + (uint32_t)(ks * 32 + lg * 8) * 2u;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(kt * 4 + ks) * 1024u);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"((const glob_v*)kb), "s"(dst)
+                     : "memory");
+      }
+    }
+  }
+  // ---- V: 4 keys x 8 dims per task -> V^T fragments (same slot arithmetic and swizzle as the head_dim-64 kernel, 16 dim chunks per key quad) ----
+  {
+    const int n_tasks = n_kc * 128;
+    for (int t0 = tid; t0 < n_tasks; t0 += 2 * NT_) {
+      uint4 vr[2][4];
+      int tt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t0 + u * NT_;
+        tt[u] = t < n_tasks ? t : t0;
+        const int qd = tt[u] >> 4, ch = tt[u] & 15;
+        const int kc = qd >> 3, h2 = (qd >> 2) & 1, lgf = qd & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int key = kc * 32 + h2 * 16 + lgf * 4 + j;
+          key = key < L ? key : L - 1;
+          vr[u][j] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * kv_rs + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && t0 + NT_ >= n_tasks) break;
+        const int qd = tt[u] >> 4, ch = tt[u] & 15;
+        const int kc = qd >> 3, h2 = (qd >> 2) & 1, lgf = qd & 3;
+        const uint32_t w0[4] = {vr[u][0].x, vr[u][0].y, vr[u][0].z, vr[u][0].w}, w1[4] = {vr[u][1].x, vr[u][1].y, vr[u][1].z, vr[u][1].w};
+        const uint32_t w2[4] = {vr[u][2].x, vr[u][2].y, vr[u][2].z, vr[u][2].w}, w3[4] = {vr[u][3].x, vr[u][3].y, vr[u][3].z, vr[u][3].w};
+        S* frag = Vf + ((ch >> 1) * KC + kc) * 512 + lgf * 16 * 8 + h2 * 4;
+        const int swz = ((ch >> 1) << 1 | (ch & 1)) & 7, hi8 = (ch & 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint2 lo, hi;
+          lo.x = (w0[e] & 0xffffu) | (w1[e] << 16);
+          lo.y = (w2[e] & 0xffffu) | (w3[e] << 16);
+          hi.x = (w0[e] >> 16) | (w1[e] & 0xffff0000u);
+          hi.y = (w2[e] >> 16) | (w3[e] & 0xffff0000u);
+          *reinterpret_cast<uint2*>(frag + (hi8 + ((2 * e) ^ swz)) * 8) = lo;
+          *reinterpret_cast<uint2*>(frag + (hi8 + ((2 * e + 1) ^ swz)) * 8) = hi;
+        }
+      }
+    }
+  }
+  // ---- Q of the wave's (up to two) tiles, requested before the staging is waited for: the tile's 16 rows as the B operand (lane: query lr, dims 32 ks + 8 lg ..) ----
+  uint4 qpre[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = w + u * NWV;
+    int qt = i < NWV ? n_qt - 1 - i : i - NWV;
+    qt = (i < n_qt && qt >= 0) ? qt : 0;
+    const int qi = qt * 16 + lr;
+    const int qrow = qi < L ? qi : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qpre[u][ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * q_rs + ks * 32 + lg * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its query rows) have landed
+  __syncthreads();
+
+  const float scale2 = scale * 1.44269504088896340736f;
+  const S* vrd[8];  // this lane's 16 bytes of a V^T fragment, per dim tile (the staging's swizzle)
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) vrd[dt] = Vf + dt * KC * 512 + (lg * 16 + (lr ^ (((dt << 1) | (lr >> 3)) & 7))) * 8;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = w + u * NWV;
+    if (i >= n_qt) break;
+    const int qt = i < NWV ? n_qt - 1 - i : i - NWV;  // heaviest tiles first; a wave's second tile is a short one
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qpre[u][ks];
+    const int qi = qt * 16 + lr;
+    f32x4_t acc_o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) acc_o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const int c1 = (qt >> 1) + 1;  // chunks that hold keys <= the tile's last row
+    auto step = [&](int kc, auto nch_) {
+      constexpr int NCH = decltype(nch_)::value;
+      float sv[NCH][8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 a0 = *reinterpret_cast<const uint4*>(Kf + ((2 * (kc + c)) * 4 + ks) * 512 + lane * 8);
+          const uint4 a1 = *reinterpret_cast<const uint4*>(Kf + ((2 * (kc + c) + 1) * 4 + ks) * 512 + lane * 8);
+          s0 = mfma16<T>(a0, qf[ks], s0);
+          s1 = mfma16<T>(a1, qf[ks], s1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[c][j] = (j < 4 ? s0[j & 3] : s1[j & 3]) * scale2;
+        if ((kc + c) * 32 + 31 > qt * 16) {  // (wave-uniform) the chunk reaches past the tile's first row: causal mask, and the keys past L with it (key <= query < L)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if ((kc + c) * 32 + (j >> 2) * 16 + lg * 4 + (j & 3) > qi) sv[c][j] = -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, sv[c][j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float ms = mn == -INFINITY ? 0.f : mn;
+      const float alpha = __builtin_amdgcn_exp2f(m - ms);
+      float rs = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sv[c][j] = __builtin_amdgcn_exp2f(sv[c][j] - ms);
+          rs += sv[c][j];
+        }
+      l = l * alpha + rs;
+      if (__any(mn != m)) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha;
+      }
+      m = mn;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        uint4 pf;
+        pf.x = pf_pack2<T>(sv[c][0], sv[c][1]);
+        pf.y = pf_pack2<T>(sv[c][2], sv[c][3]);
+        pf.z = pf_pack2<T>(sv[c][4], sv[c][5]);
+        pf.w = pf_pack2<T>(sv[c][6], sv[c][7]);
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const uint4 vf = *reinterpret_cast<const uint4*>(vrd[dt] + (kc + c) * 512);
+          acc_o[dt] = mfma16<T>(vf, pf, acc_o[dt]);
+        }
+      }
+    };
+    {
+      int kc = 0;
+      for (; kc + 2 <= c1; kc += 2) step(kc, std::integral_constant<int, 2>{});
+      if (kc < c1) step(kc, std::integral_constant<int, 1>{});
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (qi < L) {
+      S* ob = reinterpret_cast<S*>(out_) + (int64_t)(tok0 + qi) * out_rs + (int64_t)h * D;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        uint2 o;
+        o.x = pf_pack2<T>(acc_o[dt][0] * inv, acc_o[dt][1] * inv);
+        o.y = pf_pack2<T>(acc_o[dt][2] * inv, acc_o[dt][3] * inv);
+        *reinterpret_cast<uint2*>(ob + dt * 16 + lg * 4) = o;
+      }
+    }
+  }
+}
+
 // ---- generic path: one wave per query row, lanes over keys (scores) then over dims (output) ----
 template <typename T>
 __global__ __launch_bounds__(256) void attn_prefill_simple_kernel(const void* __restrict__ q_, const void* __restrict__ k_,
@@ -1061,6 +1263,26 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
   }
       if (kwv == 2) DL_LAUNCH_WHOLE(2) else DL_LAUNCH_WHOLE(4)
 #undef DL_LAUNCH_WHOLE
+      return;
+    }
+  }
+  if constexpr (D == 128) {
+    // whole-head kernel (late round 6): the compacted layers of a prefill -- one workgroup per (request, head).  tools/bench_attn_prefill_batched.py, 158..214 rows, us:
+    // 32 requests 47.8 (plain kernel 140.0), 8: 16.7 (54.1), 4: 13.3 (33.5), 2: 11.4 (24.0), and even ONE request's 32 workgroups on 32 CUs 8.6 against the key-split
+    // kernel's 192 workgroups 9.7 (T = 170)
+    static const int min_pairs = getenv("DL_PF_WHOLE128_MIN") ? atoi(getenv("DL_PF_WHOLE128_MIN")) : 1;  // (tuning: tools/bench_attn_prefill_batched.py)
+    bool whole = causal && !kv_len && max_seqlen > 64 && max_seqlen <= 256 && (int64_t)B * n_heads >= min_pairs && q_rs % 8 == 0 && kv_rs % 8 == 0 && out_rs % 4 == 0 &&
+                 (int64_t)max_seqlen * kv_rs * 2 < ((int64_t)1 << 31);
+    if (const char* e = getenv("DL_PF_WHOLE128")) whole = whole && atoi(e) != 0;  // A/B against the plain kernel
+    if (whole) {
+      const size_t smem = (size_t)(16 * 4 + 8 * 8) * 1024;
+      auto kfn = attn_prefill_whole_d128_causal_kernel<T>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kfn, dim3((unsigned)n_heads, (unsigned)B), dim3(512), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale);
       return;
     }
   }
