@@ -952,8 +952,12 @@ __global__ __launch_bounds__(512) void attn_prefill_whole_d128_causal_kernel(con
   const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
   const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
   const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
-  const int n_kc = (L + 31) >> 5;  // 32-key chunks; keys past L are staged as copies of key L - 1 and masked (they lie above every diagonal anyway)
   const int n_qt = (L + 15) >> 4;
+  // Few (request, head) pairs (one or two requests): gridDim.z = 2 workgroups share a head's query tiles, interleaved (tile n - 1 - slot, slot = 2 w + z): one tile per wave,
+  // half the LDS reads per workgroup; each stages the keys up to ITS last tile only.
+  const int Z = (int)gridDim.z, z = (int)blockIdx.z;
+  if (z >= n_qt) return;
+  const int n_kc = (min(L, (n_qt - z) * 16) + 31) >> 5;  // 32-key chunks this workgroup needs; keys past L are staged as copies of key L - 1 (they lie above every diagonal)
   // ---- K: one DMA piece per (key tile, dims quarter) ----
   {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)smem;
@@ -1017,8 +1021,8 @@ __global__ __launch_bounds__(512) void attn_prefill_whole_d128_causal_kernel(con
   uint4 qpre[2][4];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int i = w + u * NWV;
-    int qt = i < NWV ? n_qt - 1 - i : i - NWV;
+    const int i = (w + u * NWV) * Z + z;  // slot: the first 8 Z slots take the tiles from the last (longest) one down, the rest (Z = 1, more than 8 tiles) from tile 0 up
+    int qt = i < NWV * Z ? n_qt - 1 - i : i - NWV * Z;
     qt = (i < n_qt && qt >= 0) ? qt : 0;
     const int qi = qt * 16 + lr;
     const int qrow = qi < L ? qi : L - 1;
@@ -1034,9 +1038,9 @@ __global__ __launch_bounds__(512) void attn_prefill_whole_d128_causal_kernel(con
   for (int dt = 0; dt < 8; ++dt) vrd[dt] = Vf + dt * KC * 512 + (lg * 16 + (lr ^ (((dt << 1) | (lr >> 3)) & 7))) * 8;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int i = w + u * NWV;
+    const int i = (w + u * NWV) * Z + z;
     if (i >= n_qt) break;
-    const int qt = i < NWV ? n_qt - 1 - i : i - NWV;  // heaviest tiles first; a wave's second tile is a short one
+    const int qt = i < NWV * Z ? n_qt - 1 - i : i - NWV * Z;  // heaviest tiles first; a wave's second tile is a short one
     uint4 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qpre[u][ks];
@@ -1269,7 +1273,7 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
   if constexpr (D == 128) {
     // whole-head kernel (late round 6): the compacted layers of a prefill -- one workgroup per (request, head).  tools/bench_attn_prefill_batched.py, 158..214 rows, us:
     // 32 requests 47.8 (plain kernel 140.0), 8: 16.7 (54.1), 4: 13.3 (33.5), 2: 11.4 (24.0), and even ONE request's 32 workgroups on 32 CUs 8.6 against the key-split
-    // kernel's 192 workgroups 9.7 (T = 170)
+    // kernel's 192 workgroups 9.7 (T = 170); with two workgroups per head at <= 128 pairs (below): 7.2 / 8.5 / 9.7 at one / two / four requests
     static const int min_pairs = getenv("DL_PF_WHOLE128_MIN") ? atoi(getenv("DL_PF_WHOLE128_MIN")) : 1;  // (tuning: tools/bench_attn_prefill_batched.py)
     bool whole = causal && !kv_len && max_seqlen > 64 && max_seqlen <= 256 && (int64_t)B * n_heads >= min_pairs && q_rs % 8 == 0 && kv_rs % 8 == 0 && out_rs % 4 == 0 &&
                  (int64_t)max_seqlen * kv_rs * 2 < ((int64_t)1 << 31);
@@ -1282,7 +1286,9 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
       }
-      hipLaunchKernelGGL(kfn, dim3((unsigned)n_heads, (unsigned)B), dim3(512), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale);
+      static const int z_pairs = getenv("DL_PF_WHOLE128_ZPAIRS") ? atoi(getenv("DL_PF_WHOLE128_ZPAIRS")) : 128;  // two workgroups per head up to this many (request, head) pairs: 1 request 8.6 -> 7.2 us, 2: 11.5 -> 8.5, 4: 13.2 -> 9.7; 8: 16.7 -> 19.2 (one per head stays)
+      const unsigned zs = ((int64_t)B * n_heads <= z_pairs) ? 2u : 1u;
+      hipLaunchKernelGGL(kfn, dim3((unsigned)n_heads, (unsigned)B, zs), dim3(512), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale);
       return;
     }
   }
