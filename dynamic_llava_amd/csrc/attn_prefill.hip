@@ -924,6 +924,220 @@ __global__ __launch_bounds__(256 * KW) void attn_prefill_whole_d64_kernel(const 
   DL_PSTAMP(7);
 }
 
+// ---- whole-head variant of the kernel above for MANY (image, head) pairs (late round 6): a batched prefill's CLIP tower (configs[2] / [3]: 32 images x 16 heads).  The
+// kernel above gives every 64-row block of a head its own workgroup, and each of them stages all of the head's keys again (ten times per head, 5120 workgroups at 32
+// images: 195 us per layer, 9.5 % MFMA-busy).  Here ONE 16-wave workgroup owns an (image, head): K / V^T staged once (the same fragment images), wave w takes the query
+// tiles w, w + 16, w + 32 TOGETHER -- every K and V^T fragment it reads from LDS feeds two or three MFMAs instead of one (the loop is LDS-read-bound otherwise) --, each
+// wave sees every key of its tiles: no ranges to merge, one barrier.
+template <typename T>
+__global__ __launch_bounds__(1024) void attn_prefill_head_d64_kernel(const void* __restrict__ q_, const void* __restrict__ k_, const void* __restrict__ v_, int64_t q_rs,
+                                                                    int64_t kv_rs, void* __restrict__ out_, int64_t out_rs, const int32_t* __restrict__ cu, int n_rep,
+                                                                    float scale) {
+  using S = uint16_t;
+  constexpr int D = 64, KT = 38, KC = 19, NWV = 16, NT_ = 64 * NWV;  // up to 608 keys
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  typedef __attribute__((address_space(1))) void glob_v;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S* Kf = reinterpret_cast<S*>(smem);  // [key tile][dims half][64 lanes][8]
+  S* Vf = Kf + KT * 2 * 512;           // [dim tile][32-key chunk][64 lanes][8]
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tok0 = cu[b];
+  const int L = cu[b + 1] - tok0;
+  if (L <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int kvh = h / n_rep;
+  const S* qb = reinterpret_cast<const S*>(q_) + (int64_t)tok0 * q_rs + (int64_t)h * D;
+  const S* kb = reinterpret_cast<const S*>(k_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const S* vb = reinterpret_cast<const S*>(v_) + (int64_t)tok0 * kv_rs + (int64_t)kvh * D;
+  const int n_kc = (L + 31) >> 5;
+  const int n_qt = (L + 15) >> 4;
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8*)smem;
+    for (int kt = w; kt < n_kc * 2; kt += NWV) {
+      int key = kt * 16 + lr;
+      key = key < L ? key : L - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t voff = (uint32_t)key * (uint32_t)kv_rs * 2u + (uint32_t)(ks * 32 + lg * 8) * 2u;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(kt * 2 + ks) * 1024u);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"((const glob_v*)kb), "s"(dst)
+                     : "memory");
+      }
+    }
+  }
+  {
+    const int n_tasks = n_kc * 64;
+    for (int t0 = tid; t0 < n_tasks; t0 += 2 * NT_) {
+      uint4 vr[2][4];
+      int tt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t0 + u * NT_;
+        tt[u] = t < n_tasks ? t : t0;
+        const int qd = tt[u] >> 3, ch = tt[u] & 7;
+        const int kc = qd >> 3, h2 = (qd >> 2) & 1, lgf = qd & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int key = kc * 32 + h2 * 16 + lgf * 4 + j;
+          key = key < L ? key : L - 1;
+          vr[u][j] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * kv_rs + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && t0 + NT_ >= n_tasks) break;
+        const int qd = tt[u] >> 3, ch = tt[u] & 7;
+        const int kc = qd >> 3, h2 = (qd >> 2) & 1, lgf = qd & 3;
+        const uint32_t w0[4] = {vr[u][0].x, vr[u][0].y, vr[u][0].z, vr[u][0].w}, w1[4] = {vr[u][1].x, vr[u][1].y, vr[u][1].z, vr[u][1].w};
+        const uint32_t w2[4] = {vr[u][2].x, vr[u][2].y, vr[u][2].z, vr[u][2].w}, w3[4] = {vr[u][3].x, vr[u][3].y, vr[u][3].z, vr[u][3].w};
+        S* frag = Vf + ((ch >> 1) * KC + kc) * 512 + lgf * 16 * 8 + h2 * 4;
+        const int swz = ((ch >> 1) << 1 | (ch & 1)) & 7, hi8 = (ch & 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint2 lo, hi;
+          lo.x = (w0[e] & 0xffffu) | (w1[e] << 16);
+          lo.y = (w2[e] & 0xffffu) | (w3[e] << 16);
+          hi.x = (w0[e] >> 16) | (w1[e] & 0xffff0000u);
+          hi.y = (w2[e] >> 16) | (w3[e] & 0xffff0000u);
+          *reinterpret_cast<uint2*>(frag + (hi8 + ((2 * e) ^ swz)) * 8) = lo;
+          *reinterpret_cast<uint2*>(frag + (hi8 + ((2 * e + 1) ^ swz)) * 8) = hi;
+        }
+      }
+    }
+  }
+  // ---- Q of the wave's (up to three) tiles, requested before the staging is waited for ----
+  uint4 qf[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int qt = w + j * NWV;
+    int qrow = (qt < n_qt ? qt : w) * 16 + lr;
+    qrow = qrow < L ? qrow : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[j][ks] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * q_rs + ks * 32 + lg * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (w >= n_qt) return;
+  const int ntl = (w + 2 * NWV < n_qt) ? 3 : (w + NWV < n_qt) ? 2 : 1;  // (wave-uniform) tiles this wave carries through the keys together
+
+  const float scale2 = scale * 1.44269504088896340736f;
+  typedef __attribute__((address_space(3))) const S lds_s;  // 32-bit LDS addresses: the loop is register-tight (three tiles' accumulators, scores and query rows)
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  auto lds_ld = [](lds_s* p_) -> uint4 {
+    const u32x4_t v_ = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(p_);
+    return make_uint4(v_.x, v_.y, v_.z, v_.w);
+  };
+  lds_s* const Kl = (lds_s*)Kf + lane * 8;
+  lds_s* vrd[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vrd[dt] = (lds_s*)Vf + dt * KC * 512 + (lg * 16 + (lr ^ (((dt << 1) | (lr >> 3)) & 7))) * 8;
+  auto run = [&](auto ntl_) {
+    constexpr int NTL = decltype(ntl_)::value;
+    f32x4_t acc_o[NTL][4];
+    float m[NTL], l[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      m[j] = -INFINITY, l[j] = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc_o[j][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kc = 0; kc < n_kc; ++kc) {
+      // phase 1: the chunk's four K fragments, read once, against every tile's query rows (raw scores: the scale, in units of log2 e, rides in the exponent's fused
+      // multiply-add below).  All tiles' scores first, then their softmax: interleaving them tile by tile costs registers the compiler then spills (110 vs 102 us)
+      float sv[NTL][8];
+      {
+        uint4 a[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          a[0][ks] = lds_ld(Kl + ((2 * kc) * 2 + ks) * 512);
+          a[1][ks] = lds_ld(Kl + ((2 * kc + 1) * 2 + ks) * 512);
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s0 = mfma16<T>(a[0][ks], qf[j][ks], s0);
+            s1 = mfma16<T>(a[1][ks], qf[j][ks], s1);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sv[j][e] = e < 4 ? s0[e & 3] : s1[e & 3];
+        }
+      }
+      const bool tail = kc * 32 + 32 > L;  // (wave-uniform) the row's last chunk holds keys past L (staged as copies of key L - 1): masked
+      // phase 2: online softmax per tile, P^T packed for the second product
+      uint4 pf[NTL];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        if (tail) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kc * 32 + (e >> 2) * 16 + lg * 4 + (e & 3) >= L) sv[j][e] = -INFINITY;
+        }
+        float mx = sv[j][0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) mx = fmaxf(mx, sv[j][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx *= scale2;  // (scale2 > 0: the maximum of the scaled scores)
+        const float mn = fmaxf(m[j], mx);
+        const float ms = mn == -INFINITY ? 0.f : mn;
+        const float alpha = __builtin_amdgcn_exp2f(m[j] - ms);
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sv[j][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[j][e], scale2, -ms));  // one VALU op for scale and shift
+          rs += sv[j][e];
+        }
+        l[j] = l[j] * alpha + rs;
+        if (__any(mn != m[j])) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[j][dt][r] *= alpha;
+        }
+        m[j] = mn;
+        pf[j].x = pf_pack2<T>(sv[j][0], sv[j][1]);
+        pf[j].y = pf_pack2<T>(sv[j][2], sv[j][3]);
+        pf[j].z = pf_pack2<T>(sv[j][4], sv[j][5]);
+        pf[j].w = pf_pack2<T>(sv[j][6], sv[j][7]);
+      }
+      // phase 3: each V^T fragment, read once, against every tile's P^T
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint4 vf = lds_ld(vrd[dt] + kc * 512);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc_o[j][dt] = mfma16<T>(vf, pf[j], acc_o[j][dt]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      float lj = l[j];
+      lj += __shfl_xor(lj, 16, 64);
+      lj += __shfl_xor(lj, 32, 64);
+      const float inv = lj > 0.f ? 1.0f / lj : 0.f;
+      const int qi = (w + j * NWV) * 16 + lr;
+      if (qi < L) {
+        S* ob = reinterpret_cast<S*>(out_) + (int64_t)(tok0 + qi) * out_rs + (int64_t)h * D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 o;
+          o.x = pf_pack2<T>(acc_o[j][dt][0] * inv, acc_o[j][dt][1] * inv);
+          o.y = pf_pack2<T>(acc_o[j][dt][2] * inv, acc_o[j][dt][3] * inv);
+          *reinterpret_cast<uint2*>(ob + dt * 16 + lg * 4) = o;
+        }
+      }
+    }
+  };
+  if (ntl == 3) run(std::integral_constant<int, 3>{});
+  else if (ntl == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
 // ---- whole-head variant for head_dim 128, causal, 65..256 rows (late round 6): the decoder's post-compaction layers of a BATCHED prefill (configs[2] / [3]: 32 requests
 // x 32 heads x 158..214 rows, DML:1061-1122).  The plain kernel walks such a launch as 6144 small workgroups at 3.6 % MFMA-busy (143 us per layer,
 // profiles/r06_configs2_prefill_mfma_util.txt).  Here ONE workgroup owns a (request, head): all of its keys are staged once -- K by LDS-DMA, V transposed through
@@ -1252,6 +1466,18 @@ static void launch_mfma(const void* q, const void* k, const void* v, int64_t q_r
     if (const char* e = getenv("DL_PF_WHOLE")) whole = whole && atoi(e) != 0;  // A/B against the key-split kernel
     if (whole) {
       const size_t smem = (size_t)(38 * 2 + 4 * 19) * 1024;
+      // many (image, head) pairs: one 16-wave workgroup per pair, every fragment read feeding two or three query tiles (tools/bench_attn_prefill_batched.py --clip)
+      static const int head_pairs = getenv("DL_PF_HEAD64_MIN") ? atoi(getenv("DL_PF_HEAD64_MIN")) : 256;
+      if ((int64_t)B * n_heads >= head_pairs) {
+        auto kfn = attn_prefill_head_d64_kernel<T>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)n_heads, (unsigned)B), dim3(1024), smem, st, q, k, v, q_rs, kv_rs, out, out_rs, cu, n_rep, scale);
+        return;
+      }
       int kwv = 4;
       if (const char* e = getenv("DL_PF_WHOLE_KW")) kwv = atoi(e) == 2 ? 2 : 4;  // tuning experiments only
 #define DL_LAUNCH_WHOLE(KWV)                                                                                                             \

@@ -232,7 +232,9 @@ def _sdpa_ref(q, k, v, causal):
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("nH,nKV,d,lens", [(4, 4, 128, [170, 1, 64, 65, 200]), (8, 8, 64, [576, 36]), (16, 16, 64, [577]), (4, 2, 64, [129, 300]), (4, 2, 128, [129]), (32, 32, 128, [170]), (4, 4, 128, [117, 65, 192, 3]), (4, 4, 128, [128, 66]), (4, 2, 128, [300, 631, 17, 257]), (2, 2, 32, [37, 150, 5]),
                                              # >= 256 (request, head) pairs, head_dim 128, causal, <= 256 rows: the whole-head kernel of a batched prefill's compacted layers (late round 6)
-                                             (32, 32, 128, [170, 214, 158, 256, 65, 1, 16, 17, 33, 255]), (32, 8, 128, [200, 64, 129, 96, 31, 241, 2, 160]), (64, 64, 128, [97, 224, 5, 180])])
+                                             (32, 32, 128, [170, 214, 158, 256, 65, 1, 16, 17, 33, 255]), (32, 8, 128, [200, 64, 129, 96, 31, 241, 2, 160]), (64, 64, 128, [97, 224, 5, 180]),
+                                             # >= 256 (image, head) pairs, head_dim 64, non-causal, 257..608 rows: the 16-wave whole-head kernel of a batched CLIP tower (late round 6)
+                                             (16, 16, 64, [577] * 14 + [300, 608, 257, 590]), (32, 8, 64, [577, 576, 290, 601, 333, 480, 259, 512])])
 def test_attn_prefill(ops, dtype, causal, nH, nKV, d, lens):
     g = torch.Generator().manual_seed(8)
     total = sum(lens)

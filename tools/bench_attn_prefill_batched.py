@@ -35,3 +35,14 @@ for B, lo, hi in ((32, 158, 215), (8, 158, 215), (4, 158, 215), (2, 158, 215), (
     t = timed(lambda: ops.attn_prefill(qkv[:, : nH * d], qkv[:, nH * d : 2 * nH * d], qkv[:, 2 * nH * d :], out, cu, max(lens), nH, nKV, d, True))
     fl = sum(4 * nH * d * L * (L + 1) / 2 for L in lens)
     print(f"B={B:3d} rows {lo}..{hi - 1}: {t:8.2f} us  ({fl / t / 1e6:6.1f} TFLOP/s causal)   DL_PF_WHOLE128={os.environ.get('DL_PF_WHOLE128', '1')}", flush=True)
+
+# the CLIP tower's attention (16 heads x 64, 577 tokens, non-causal) at 1..32 images: DL_PF_HEAD64_MIN=100000 keeps the per-64-row-block kernel at every batch size
+nH2, d2 = 16, 64
+for B in (32, 16, 8, 2, 1):
+    total = 577 * B
+    qkv = torch.randn(total, 3 * nH2 * d2, generator=g).to(dt).to(dev)
+    cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * 577
+    out = torch.empty(total, nH2 * d2, dtype=dt, device=dev)
+    t = timed(lambda: ops.attn_prefill(qkv[:, : nH2 * d2], qkv[:, nH2 * d2 : 2 * nH2 * d2], qkv[:, 2 * nH2 * d2 :], out, cu, 577, nH2, nH2, d2, False))
+    fl = B * 4 * nH2 * d2 * 577 * 577
+    print(f"CLIP B={B:3d} x 577: {t:8.2f} us  ({fl / t / 1e6:6.1f} TFLOP/s)   DL_PF_HEAD64_MIN={os.environ.get('DL_PF_HEAD64_MIN', '256')}", flush=True)
