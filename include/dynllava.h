@@ -90,7 +90,8 @@ int dl_rope_kv_write_parts(void* qkv_out, const float* parts, int n_parts, const
  * head_dim in {64, 128} (f16/bf16: MFMA path) or any multiple of 4 <= 256 (f32).  * Round 6: head_dim 64, non-causal rows of 257..608 tokens (the CLIP tower's 577, the vision predictor's 576) run on a whole-row kernel -- all keys of a head on
  * chip in fragment order, softmax in registers; same arithmetic (fp32 online softmax, P rounded to the dtype before P V), another summation order: rounding class.
  * Late round 6: head_dim 128, causal rows of 65..256 tokens (the decoder's compacted layers, DML:1061-1122) the same way -- one workgroup per (request, head), its
- * query tiles paired long / short over eight waves; two workgroups per head while there are at most 128 (request, head) pairs. */
+ * query tiles paired long / short over eight waves; two workgroups per head while there are at most 128 (request, head) pairs.  The head_dim-64 rows of 256 and more
+ * (image, head) pairs (a batched CLIP tower) likewise get one 16-wave workgroup per pair. */
 int dl_attn_prefill(const void* q, const void* k, const void* v, int64_t q_row_stride, int64_t kv_row_stride,
                     void* out, int64_t out_row_stride, const int32_t* cu_seqlens, int B, int max_seqlen,
                     int n_heads, int n_kv_heads, int head_dim, int causal, int dtype, void* stream);
