@@ -48,4 +48,14 @@ __device__ __forceinline__ float silu_rounded(float g) {
   return hw_round<T>(s);
 }
 
+// cast(sigmoid(t)) = cast(1 / (1 + expf(-t))): dl_quick_gelu's second rounding, same scheme (dl_linear_tiles' QuickGELU epilogue holds its own copy of this function)
+template <typename T>
+__device__ __forceinline__ float sigmoid_rounded(float t) {
+  const float fast = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+  const bool in_range = fabsf(t) < (Elem<T>::kBf16 ? 16.0f : 8.0f);  // fp16: sigmoid below 2^-14 is subnormal in the type (another boundary grid)
+  float s = fast;
+  if (near_rounding_tie<T>(fast, 64) || !in_range) s = 1.0f / (1.0f + expf(-t));
+  return hw_round<T>(s);
+}
+
 }  // namespace dl

@@ -1,9 +1,15 @@
 // HBM-bound row kernels: RMSNorm (+fused residual add), LayerNorm (+row gather), SiLU*up.
 // One 256-thread workgroup per row, 16-byte accesses, the row cached in registers between the
 // statistics pass and the scale pass (each element is read from HBM exactly once).
-#include "dl_common.h"
+#include "act_round.h"
 
 namespace dl {
+
+// DL_EXACT_ACT=1: dl_quick_gelu / dl_silu_mul evaluate the exact expressions (expf, IEEE divide, software roundings) -- what the guarded fast forms are tested against
+static inline bool exact_act() {
+  const char* e = getenv("DL_EXACT_ACT");
+  return e && e[0] == '1';
+}
 
 constexpr int kThreads = 256;
 constexpr int kMaxVecPerThread = 8;
@@ -356,7 +362,10 @@ static int ln_wave_launch(void* x, const void* delta, int n_slices, const void* 
 }
 
 // ---- CLIP's QuickGELU (HF activations.QuickGELUActivation: `input * torch.sigmoid(1.702 * input)`), three roundings as in eager ----
-template <typename T>
+// EXACT = false (the product, 16-bit types): sigmoid on v_exp_f32 / v_rcp_f32 with the rounding-boundary guard of act_round.h -- the bits of the exact expression
+// (tests hold the two instantiations against each other; DL_EXACT_ACT=1 selects the exact one), at a third of its VALU: at a batch of images this launch was
+// VALU-bound (75 M elements x ~40 instructions: 98 us where the bytes need 60).
+template <typename T, bool EXACT>
 __global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const void* __restrict__ x_, void* __restrict__ out_, int64_t nvec) {
   constexpr int V = Elem<T>::kVec;
   using S = typename Elem<T>::storage;
@@ -367,16 +376,20 @@ __global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const void* __rest
     load16<T>(x + idx * V, a);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float t = Elem<T>::round(1.702f * a[j]);
-      const float sg = Elem<T>::round(1.0f / (1.0f + expf(-t)));
-      o[j] = a[j] * sg;
+      if constexpr (EXACT || Elem<T>::kBytes == 4) {
+        const float t = Elem<T>::round(1.702f * a[j]);
+        const float sg = Elem<T>::round(1.0f / (1.0f + expf(-t)));
+        o[j] = a[j] * sg;
+      } else {
+        o[j] = a[j] * sigmoid_rounded<T>(hw_round<T>(1.702f * a[j]));
+      }
     }
     store16<T>(out + idx * V, o);
   }
 }
 
 // ---- act_fn(gate) * up, DML:328 (two roundings: after silu, after the product) ----
-template <typename T>
+template <typename T, bool EXACT>
 __global__ __launch_bounds__(kThreads) void silu_mul_kernel(const void* __restrict__ gu_, void* __restrict__ out_, int64_t rows,
                                                              int I) {
   constexpr int V = Elem<T>::kVec;
@@ -393,7 +406,9 @@ __global__ __launch_bounds__(kThreads) void silu_mul_kernel(const void* __restri
     load16<T>(gu + r * 2 * I + I + c, u);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float sg = Elem<T>::round(g[j] / (1.0f + expf(-g[j])));
+      float sg;
+      if constexpr (EXACT || Elem<T>::kBytes == 4) sg = Elem<T>::round(g[j] / (1.0f + expf(-g[j])));
+      else sg = silu_rounded<T>(g[j]);  // (act_round.h: the exact expression's bits; dl_silu_mul_parts keeps the exact form)
       o[j] = sg * u[j];
     }
     store16<T>(out + r * I + c, o);
@@ -611,8 +626,13 @@ extern "C" int dl_quick_gelu(const void* x, void* out, int64_t n, int dtype, voi
     DL_REQUIRE(n % Elem<T>::kVec == 0, "dl_quick_gelu: n must be a multiple of %d", Elem<T>::kVec);
     const int64_t nvec = n / Elem<T>::kVec;
     const int64_t blocks = (nvec + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL((quick_gelu_kernel<T>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kThreads), 0, as_stream(stream), x, out,
+    if (exact_act()) {
+      hipLaunchKernelGGL((quick_gelu_kernel<T, true>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kThreads), 0, as_stream(stream), x, out,
                        nvec);
+    } else {
+      hipLaunchKernelGGL((quick_gelu_kernel<T, false>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kThreads), 0, as_stream(stream), x, out,
+                       nvec);
+    }
   });
   DL_CHECK_LAUNCH("dl_quick_gelu");
   return DL_OK;
@@ -641,7 +661,8 @@ extern "C" int dl_silu_mul(const void* gate_up, void* out, int64_t rows, int I, 
     const int64_t total = rows * (I / Elem<T>::kVec);
     const int64_t blocks = (total + kThreads - 1) / kThreads;
     const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
-    hipLaunchKernelGGL((silu_mul_kernel<T>), dim3(grid), dim3(kThreads), 0, as_stream(stream), gate_up, out, rows, I);
+    if (exact_act()) hipLaunchKernelGGL((silu_mul_kernel<T, true>), dim3(grid), dim3(kThreads), 0, as_stream(stream), gate_up, out, rows, I);
+    else hipLaunchKernelGGL((silu_mul_kernel<T, false>), dim3(grid), dim3(kThreads), 0, as_stream(stream), gate_up, out, rows, I);
   });
   DL_CHECK_LAUNCH("dl_silu_mul");
   return DL_OK;

@@ -87,6 +87,28 @@ def test_silu_mul(ops, dtype):
     assert _frac_exact(out, ref, dtype) > 0.98
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fast_activations_have_the_exact_expressions_bits(ops, dtype, monkeypatch):
+    """dl_silu_mul / dl_quick_gelu evaluate silu / sigmoid with v_exp_f32 / v_rcp_f32 and take the exact expression (expf, IEEE divide) only near a rounding boundary of the
+    16-bit type, for large arguments and for fp16-subnormal results (csrc/act_round.h, late round 6).  DL_EXACT_ACT=1 selects the all-exact instantiation of the same kernel:
+    every element of 4 x 2.3 M values spread from 1e-3 to 150 in magnitude must agree bit for bit; and dl_silu_mul_parts (which keeps the exact form) on the same values as
+    one fp32 slice is a second, independent anchor."""
+    g = torch.Generator().manual_seed(12)
+    for scale in (0.01, 1.0, 6.0, 40.0):
+        gu = (torch.randn(104, 2 * 11008, generator=g) * scale).to(dtype).cuda()
+        x = (torch.randn(577, 4096, generator=g) * scale).to(dtype).cuda()
+        monkeypatch.delenv("DL_EXACT_ACT", raising=False)
+        fast_s, fast_q = ops.silu_mul(gu), ops.quick_gelu(x)
+        monkeypatch.setenv("DL_EXACT_ACT", "1")
+        exact_s, exact_q = ops.silu_mul(gu), ops.quick_gelu(x)
+        monkeypatch.delenv("DL_EXACT_ACT", raising=False)
+        assert torch.equal(fast_s, exact_s), f"silu_mul, scale {scale}: {int((fast_s != exact_s).sum())} elements differ"
+        assert torch.equal(fast_q, exact_q), f"quick_gelu, scale {scale}: {int((fast_q != exact_q).sum())} elements differ"
+        parts = gu.float()[None].contiguous()
+        assert torch.equal(ops.silu_mul_parts(parts, torch.empty_like(fast_s)), fast_s)
+        assert torch.isfinite(fast_s.float()).all() and torch.isfinite(fast_q.float()).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_gather(ops, dtype):
     g = torch.Generator().manual_seed(3)
