@@ -325,21 +325,25 @@ class CLIPVisionTower(nn.Module):
     def _encoder_library(self, h, layers, cu, B, T, C, nH, d, eps):
         """Library GEMMs (bias fused) + this package's glue kernels: fp32 models, batches past `tiles_max_batch` images (the library's large-tile kernels
         are MFMA-bound there), towers whose shapes dl_linear_tiles does not take."""
-        xn = ops.layernorm(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if len(layers) else None
+        # 16-bit towers of up to 2048 channels: the wave-per-row LayerNorm launches (round 6).  One 256-thread workgroup per 1024-channel row leaves half its threads
+        # without a vector: 59 us per launch at 32 images where the bytes need 30 (tools/clip_tower_batch_time.py)
+        wave_ln = h.dtype in (torch.bfloat16, torch.float16) and C % 8 == 0 and C <= 2048
+        ln, add_ln = (ops.layernorm_rows, ops.add_layernorm_rows) if wave_ln else (ops.layernorm, ops.add_layernorm)
+        xn = ln(h, layers[0].layer_norm1.weight, layers[0].layer_norm1.bias, eps) if len(layers) else None
         for i, l in enumerate(layers):
             wq, bq = self._qkv[i]
             qkv = F.linear(xn, wq, bq)
             attn = torch.empty((B * T, C), dtype=h.dtype, device=h.device)
             ops.attn_prefill(qkv[:, :C], qkv[:, C : 2 * C], qkv[:, 2 * C :], attn, cu, T, nH, nH, d, causal=False)
             y = F.linear(attn, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias)
-            xn = ops.add_layernorm(h, y, l.layer_norm2.weight, l.layer_norm2.bias, eps)
+            xn = add_ln(h, y, l.layer_norm2.weight, l.layer_norm2.bias, eps)
             g = ops.quick_gelu(F.linear(xn, l.mlp.fc1.weight, l.mlp.fc1.bias))
             y = F.linear(g, l.mlp.fc2.weight, l.mlp.fc2.bias)
             if i + 1 < len(layers):
                 nl = layers[i + 1]
-                xn = ops.add_layernorm(h, y, nl.layer_norm1.weight, nl.layer_norm1.bias, eps)
+                xn = add_ln(h, y, nl.layer_norm1.weight, nl.layer_norm1.bias, eps)
             else:
-                ops.add_layernorm(h, y)
+                add_ln(h, y)
 
     def _encoder_tiles(self, h, layers, cu, B, T, C, nH, d, eps):
         """Round 6: every projection on dl_linear_tiles (own MFMA GEMM on operand-order weight copies; 7 launches per layer).  Activations between the

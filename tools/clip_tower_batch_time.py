@@ -34,7 +34,7 @@ def timed(x, reps=20):
     return best
 
 
-for B in (1, 2, 3, 4):
+for B in (1, 2, 3, 4, 8, 32):
     x = torch.randn(B, 3, 336, 336, device="cuda", dtype=torch.bfloat16)
     t.tiles_max_batch = 0
     lib = timed(x)
